@@ -1,0 +1,100 @@
+"""ctypes binding of libgem_hip.so (the C ABI declared in include/gem_hip.h).
+
+This is the ONLY way the Python layer reaches the device.  There is no CPU
+fallback: if the shared library is missing or no MI355X is visible, calls
+raise -- the product path never routes through oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgem_hip.so')
+
+_lib = None
+
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+
+class GemHipError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    'gemhip_version': (C.c_int, []),
+    'gemhip_last_error': (C.c_char_p, []),
+    'gemhip_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'gemhip_set_device': (C.c_int, [C.c_int]),
+    'gemhip_malloc': (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
+    'gemhip_free': (C.c_int, [C.c_void_p]),
+    'gemhip_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'gemhip_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'gemhip_synchronize': (C.c_int, [C.c_void_p]),
+    'gemhip_gf_train': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_int32,
+                                  f32p, f64p]),
+    'gemhip_gf_plan_create': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_int64, C.c_int64,
+                                        C.POINTER(C.c_void_p)]),
+    'gemhip_gf_plan_destroy': (C.c_int, [C.c_void_p]),
+    'gemhip_gf_plan_bind': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'gemhip_gf_plan_set_embedding': (C.c_int, [C.c_void_p, f32p]),
+    'gemhip_gf_plan_init_embedding': (C.c_int, [C.c_void_p, C.c_uint64, C.c_float]),
+    'gemhip_gf_plan_sweeps': (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
+    'gemhip_gf_plan_get_embedding': (C.c_int, [C.c_void_p, f32p]),
+    'gemhip_gf_plan_current': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    'gemhip_gf_plan_info': (C.c_int, [C.c_void_p, i64p]),
+    'gemhip_gf_objective': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, f32p, f64p]),
+}
+
+
+def declared_symbols():
+    """Names this binding expects; tests check them against include/gem_hip.h."""
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load libgem_hip.so (once).  Raises GemHipError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GemHipError('libgem_hip.so not built: run `python -m gem_amd.build` (needs hipcc). '
+                              'There is no CPU fallback.')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)      # AttributeError here == ABI drift; let it propagate
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise GemHipError('libgem_hip error %d: %s' % (rc, lib().gemhip_last_error().decode('utf-8', 'replace')))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().gemhip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def require_device():
+    if device_count() < 1:
+        raise GemHipError('no HIP device visible: the gem_amd backend needs an MI355X (gfx950); '
+                          'there is no CPU fallback (%s)' % lib().gemhip_last_error().decode())
+
+
+def ptr(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def as_f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)

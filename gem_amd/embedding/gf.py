@@ -1,0 +1,54 @@
+"""GraphFactorization on MI355X -- drop-in for gem.embedding.gf.GraphFactorization
+(gem/embedding/gf.py:10-104).
+
+learn_embedding() keeps the reference's contract (gf.py:81-101): falsy graph ->
+ValueError('graph needed'); the embedding is initialised as 0.01*N(0,1) from
+numpy's global RNG (so `np.random.seed` controls it exactly like the
+reference); `max_iter` sequential sweeps over graph.edges() where only edges
+with j > i fire and only row i is written; returns and stores the (n, d)
+float64 array.  The sweeps run in libgem_hip.so (gem_amd/csrc/gf.hip) in fp32 --
+the precision of the reference's own native path gem/c_src/gf.cpp.
+
+Extra kwarg (through the usual hyper-parameter mechanism): `seed` (use a private
+RandomState instead of numpy's global RNG).
+"""
+import ctypes as C
+
+import numpy as np
+
+from gem_amd import _hip
+from gem_amd.graph import edge_arrays
+from gem_amd.embedding.static_graph_embedding import StaticGraphEmbedding
+
+
+class GraphFactorization(StaticGraphEmbedding):
+    hyper_params = {
+        'print_step': 10000,
+        'method_name': 'graph_factor_sgd',
+    }
+
+    def __init__(self, *args, **kwargs):
+        super(GraphFactorization, self).__init__(*args, **kwargs)
+
+    def learn_embedding(self, graph=None, edge_f=None, is_weighted=False, no_python=True, **_ignored):
+        if not graph:
+            raise ValueError('graph needed')
+        n, src, dst, w, _ = edge_arrays(graph)
+        d = int(self._d)
+        self._node_num = n
+        seed = getattr(self, '_seed', None)
+        rng = np.random if seed is None else np.random.RandomState(seed)
+        X0 = (0.01 * rng.randn(n, d)).astype(np.float32)          # gf.py:92
+        _hip.require_device()
+        L = _hip.lib()
+        stats = (C.c_double * 4)()
+        _hip.check(L.gemhip_gf_train(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32),
+                                     _hip.ptr(_hip.as_f32(w), C.c_float), d, float(self._eta), float(self._regu),
+                                     int(self._max_iter), _hip.ptr(X0, C.c_float), stats))
+        self._stats = {'kernel_seconds': stats[0], 'updates_per_sweep': stats[1], 'rows_per_sweep': stats[2],
+                       'levels': stats[3]}
+        self._X = X0.astype(np.float64)
+        return self._X
+
+    def get_edge_weight(self, i, j):
+        return np.dot(self._X[i, :], self._X[j, :])

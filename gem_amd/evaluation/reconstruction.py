@@ -1,0 +1,126 @@
+"""Graph-reconstruction metric (MAP, precision curve) -- vectorised restatement of
+GEM's evaluator, used as THE parity metric of this backend.
+
+Mirrors, result-for-result (pinned by tests/golden/map_ref.json, which was
+produced by the reference's own code):
+  gem/evaluation/evaluate_graph_reconstruction.py:8-46   evaluateStaticGraphReconstruction
+  gem/utils/evaluation_util.py:20-36                     get_edge_list_from_adj_mtrx (i<j, adj>0)
+  gem/evaluation/metrics.py:6-24, 27-46                  computePrecisionCurve, computeMAP
+
+The reference builds Python lists of (i, j, w) tuples and sorts them (O(n^2) Python
+objects); here every node's candidate list is one stable argsort over a numpy
+row, so n ~ 2e4 is practical.  Tie order follows the reference: Python's stable
+`sorted(..., reverse=True)` keeps equal weights in ascending-j order.
+"""
+import numpy as np
+
+
+def _adjacency_bool(digraph, n):
+    A = np.zeros((n, n), dtype=bool)
+    if hasattr(digraph, 'src'):
+        A[digraph.src, digraph.dst] = True
+    else:
+        for i, j in digraph.edges():
+            A[i, j] = True
+    return A
+
+
+def average_precision_rows(score, truth, undirected=True):
+    """Per-node AP exactly as metrics.computeMAP: node i ranks candidates j (j>i when
+    undirected) with score>0 by descending score; AP_i = mean precision at the hits."""
+    n = score.shape[0]
+    ap = np.zeros(n)
+    for i in range(n):
+        lo = i + 1 if undirected else 0
+        s = score[i, lo:]
+        t = truth[i, lo:]
+        if not undirected:
+            keep = np.ones(s.shape[0], dtype=bool)
+            keep[i] = False
+            s, t = s[keep], t[keep]
+        pos = s > 0
+        s, t = s[pos], t[pos]
+        if s.size == 0:
+            continue
+        order = np.argsort(-s, kind='stable')
+        hit = t[order]
+        nh = hit.sum()
+        if nh == 0:
+            continue
+        prec = np.cumsum(hit) / np.arange(1, hit.size + 1)
+        ap[i] = prec[hit].sum() / nh
+    return ap
+
+
+def precision_curve(score, truth, undirected=True, max_k=None):
+    n = score.shape[0]
+    iu = np.triu_indices(n, 1) if undirected else np.where(~np.eye(n, dtype=bool))
+    s = score[iu]
+    t = truth[iu]
+    pos = s > 0
+    s, t = s[pos], t[pos]
+    order = np.argsort(-s, kind='stable')
+    hit = t[order]
+    if max_k is not None:
+        hit = hit[:max_k]
+    return np.cumsum(hit) / np.arange(1, hit.size + 1)
+
+
+def evaluateStaticGraphReconstruction(digraph, graph_embedding, X_stat, node_l=None, file_suffix=None,
+                                      sample_ratio_e=None, is_undirected=True, is_weighted=False):
+    """Same signature and return tuple as the reference: (MAP, prec_curv, err, err_baseline)."""
+    n = len(digraph.nodes)
+    est = graph_embedding.get_reconstructed_adj(X_stat, node_l)
+    truth = _adjacency_bool(digraph, n)
+    if sample_ratio_e:
+        raise NotImplementedError('sample_ratio_e: use sampled_map() for large graphs')
+    ap = average_precision_rows(est, truth, undirected=is_undirected)
+    if is_undirected:
+        MAP = ap.sum() / n
+    else:
+        has_out = truth.any(axis=1)
+        MAP = ap[has_out].sum() / max(int(has_out.sum()), 1)
+    prec = precision_curve(est, truth, undirected=is_undirected)
+    err = err_base = None
+    if is_weighted:
+        W = np.zeros((n, n))
+        for i, j, w in digraph.edges(data='weight', default=1):
+            W[i, j] = w
+        e = est.copy()
+        e[W == 0] = 0
+        err = np.linalg.norm(W - e)
+        err_base = np.linalg.norm(W)
+    return float(MAP), prec.tolist(), err, err_base
+
+
+def sampled_map(graph, pair_score, nodes, undirected=True):
+    """MAP over a sample of nodes for graphs where the n x n matrix cannot be formed
+    (SURVEY 8f row 1).  `pair_score(i) -> scores of node i against all nodes` (length n).
+    Equals computeMAP restricted to `nodes` (tested against the full evaluator)."""
+    n = graph.number_of_nodes()
+    if hasattr(graph, 'src'):
+        order = np.argsort(graph.src, kind='stable')
+        s_sorted = graph.src[order]
+        d_sorted = graph.dst[order]
+        starts = np.searchsorted(s_sorted, np.arange(n + 1))
+        nbrs = lambda i: d_sorted[starts[i]:starts[i + 1]]
+    else:
+        nbrs = lambda i: np.fromiter(graph.successors(i), dtype=np.int64)
+    aps = []
+    for i in nodes:
+        s = np.asarray(pair_score(i), dtype=np.float64).copy()
+        t = np.zeros(n, dtype=bool)
+        t[nbrs(i)] = True
+        lo = i + 1 if undirected else 0
+        s, t = s[lo:], t[lo:]
+        if not undirected:
+            s[i] = 0
+        pos = s > 0
+        s, t = s[pos], t[pos]
+        if s.size == 0 or t.sum() == 0:
+            aps.append(0.0)
+            continue
+        hit = t[np.argsort(-s, kind='stable')]
+        prec = np.cumsum(hit) / np.arange(1, hit.size + 1)
+        aps.append(prec[hit].sum() / hit.sum())
+    return float(np.mean(aps)) if aps else 0.0

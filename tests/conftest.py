@@ -1,0 +1,47 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN, name)
+
+
+def load_karate():
+    """tests/data/karate.edgelist exactly as tests/test_karate.py:27-35 loads it
+    (directed DiGraph, insertion order 0,31,21,...)."""
+    from gem_amd.utils import graph_util
+    return graph_util.loadGraphFromEdgeListTxt(golden_path('karate.edgelist'), directed=True).to_directed()
+
+
+def load_sbm1024():
+    """tests/data/sbm.gpickle re-encoded as an edge array in reference iteration order
+    (nodes inserted 0..1023, edges by source)."""
+    import networkx as nx
+    e = np.load(golden_path('sbm1024_edges.npy'))
+    nodes = np.load(golden_path('sbm1024_nodes.npy'))
+    G = nx.DiGraph()
+    G.add_nodes_from(nodes.tolist())
+    G.add_edges_from(map(tuple, e.tolist()))
+    return G
+
+
+@pytest.fixture(scope='session')
+def karate():
+    return load_karate()
+
+
+@pytest.fixture(scope='session')
+def sbm1024():
+    return load_sbm1024()

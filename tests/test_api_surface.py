@@ -1,0 +1,50 @@
+"""CPU tests of the plugin API surface, written after the reference's
+tests/test_embedding_classes.py:11-48 and the call sites in examples/run_karate.py:64."""
+import numpy as np
+import pytest
+
+from gem_amd.embedding.gf import GraphFactorization
+from gem_amd.embedding.hope import HOPE
+from gem_amd.embedding.node2vec import node2vec
+from gem_amd.embedding.static_graph_embedding import StaticGraphEmbedding
+
+
+@pytest.mark.parametrize('cls', [HOPE, GraphFactorization, node2vec])
+def test_construct_without_args_and_error_conventions(cls):
+    model = cls()
+    assert isinstance(model, StaticGraphEmbedding)
+    with pytest.raises(ValueError, match='graph needed'):
+        model.learn_embedding()
+    with pytest.raises(ValueError, match='graph needed'):                 # run_karate.py:64 call shape
+        model.learn_embedding(graph=None, edge_f=None, is_weighted=True, no_python=True)
+    assert model.hyper_params['method_name'] == model.get_method_name()   # test_embedding_classes.py:43
+    fresh = cls.__new__(cls)
+    fresh._X = None
+    with pytest.raises(ValueError, match='Embedding not learned yet'):
+        StaticGraphEmbedding.get_embedding(fresh)
+
+
+def test_method_names_and_summary():
+    assert HOPE(d=4, beta=0.01).get_method_name() == 'hope_gsvd'
+    assert GraphFactorization(d=2, max_iter=5, eta=1e-4, regu=1.0).get_method_name() == 'graph_factor_sgd'
+    assert node2vec(d=2).get_method_name() == 'node2vec_rw'
+    assert HOPE(d=4, beta=0.01).get_method_summary() == 'hope_gsvd_4'
+    assert GraphFactorization.hyper_params['print_step'] == 10000
+
+
+def test_kwargs_and_positional_dicts_become_attributes():
+    m = GraphFactorization({'foo': 3}, d=8, eta=0.5, regu=0.25, max_iter=7, data_set='x')
+    assert (m._d, m._eta, m._regu, m._max_iter, m._data_set, m._foo) == (8, 0.5, 0.25, 7, 'x', 3)
+    # class-level hyper_params is mutated by every constructor, as in the reference
+    assert GraphFactorization()._d == 8
+
+
+def test_reconstructed_adj_sets_embedding_and_zero_diagonal():
+    m = HOPE(d=4, beta=0.01)
+    X = np.arange(12.0).reshape(3, 4)
+    A = m.get_reconstructed_adj(X)
+    assert m.get_embedding() is X
+    assert A.shape == (3, 3) and np.all(np.diag(A) == 0)
+    assert A[0, 2] == pytest.approx(np.dot(X[0, :2], X[2, 2:]))
+    A2 = m.get_reconstructed_adj(X, node_l=[2, 0])
+    assert A2.shape == (2, 2) and A2[0, 1] == pytest.approx(np.dot(X[2, :2], X[0, 2:]))

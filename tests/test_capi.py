@@ -1,0 +1,54 @@
+"""CPU tests: libgem_hip.so loads and exports exactly what include/gem_hip.h declares.
+No compute calls here (no GPU in the CPU tier)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from gem_amd import _hip, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'gem_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(gemhip_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    build.build()
+    L = ctypes.CDLL(_hip.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(L, s), 'include/gem_hip.h declares %s but libgem_hip.so does not export it' % s
+
+
+def test_ctypes_binding_covers_the_header():
+    assert _hip.declared_symbols() == header_symbols()
+    assert _hip.lib().gemhip_version() == 100
+
+
+def test_no_silent_fallback_without_gpu():
+    """On a machine without a HIP device the product path must fail loudly."""
+    import numpy as np
+    from gem_amd.embedding.gf import GraphFactorization
+    from gem_amd.graph import EdgeListGraph
+    if _hip.device_count() > 0:
+        pytest.skip('GPU present')
+    g = EdgeListGraph(3, [0, 1], [1, 2])
+    with pytest.raises(_hip.GemHipError):
+        GraphFactorization(d=2, eta=0.1, regu=0.1, max_iter=1).learn_embedding(graph=g)
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, 'gem_amd')):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.hpp', '.cpp', '.h')):
+                t = open(os.path.join(dp, f)).read()
+                if re.search(r'^\s*(import|from)\s+oracle\b', t, flags=re.M) or 'liboracle' in t or '_ref/' in t:
+                    bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,68 @@
+"""CPU tests: the vectorised MAP / precision curve against values computed by the
+reference's own evaluator (tests/golden/map_ref.json, scripts/make_golden.py)."""
+import json
+
+import numpy as np
+import pytest
+
+from gem_amd.embedding.gf import GraphFactorization
+from gem_amd.embedding.hope import HOPE
+from gem_amd.embedding.node2vec import node2vec
+from gem_amd.evaluation import reconstruction as gr
+from conftest import golden_path
+
+with open(golden_path('map_ref.json')) as fh:
+    REF = json.load(fh)
+
+
+def test_map_matches_reference_on_gf_goldens(karate, sbm1024):
+    m = GraphFactorization(d=2, max_iter=1, eta=1e-4, regu=1.0)
+    X = np.loadtxt(golden_path('ref_karate_GraphFactorization.txt'))
+    assert gr.evaluateStaticGraphReconstruction(karate, m, X, None)[0] == pytest.approx(REF['karate_gf_golden'], abs=1e-12)
+    m = GraphFactorization(d=128, max_iter=1, eta=1e-4, regu=1.0)
+    X = np.load(golden_path('ref_sbm_GraphFactorization.npz'))['X'].astype(np.float64)
+    # the golden was saved as float32: MAP is rank based, allow the few near-tie swaps that may cause
+    assert gr.evaluateStaticGraphReconstruction(sbm1024, m, X, None)[0] == pytest.approx(REF['sbm1024_gf_golden'], abs=2e-4)
+    g = np.load(golden_path('gf_karate_train.npz'))
+    m = GraphFactorization(d=8, max_iter=1, eta=0.05, regu=0.01)
+    assert gr.evaluateStaticGraphReconstruction(karate, m, g['X'], None)[0] == pytest.approx(REF['karate_gf_train'], abs=1e-12)
+    g = np.load(golden_path('gf_sbm1024_d32.npz'))
+    m = GraphFactorization(d=32, max_iter=1, eta=0.02, regu=0.01)
+    assert gr.evaluateStaticGraphReconstruction(sbm1024, m, g['X'], None)[0] == pytest.approx(
+        REF['sbm1024_gf_d32_5sweeps'], abs=1e-12)
+
+
+def test_map_matches_reference_on_hope_and_n2v_goldens(karate, sbm1024):
+    m = HOPE(d=4, beta=0.01)
+    X = np.loadtxt(golden_path('ref_karate_HOPE.txt'))
+    assert gr.evaluateStaticGraphReconstruction(karate, m, X, None)[0] == pytest.approx(REF['karate_hope_golden'], abs=1e-12)
+    X = np.load(golden_path('hope_karate_d4.npz'))['X']
+    assert gr.evaluateStaticGraphReconstruction(karate, m, X, None)[0] == pytest.approx(REF['karate_hope_fresh'], abs=1e-12)
+    m = HOPE(d=32, beta=0.01)
+    X = np.load(golden_path('hope_sbm1024_d32.npz'))['X']
+    assert gr.evaluateStaticGraphReconstruction(sbm1024, m, X, None)[0] == pytest.approx(REF['sbm1024_hope_d32'], abs=1e-12)
+    m = node2vec(d=2, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
+    X = np.loadtxt(golden_path('ref_karate_node2vec.txt'))
+    assert gr.evaluateStaticGraphReconstruction(karate, m, X, None)[0] == pytest.approx(REF['karate_n2v_golden'], abs=1e-12)
+
+
+def test_reconstructed_adj_equals_pairwise_edge_weight(karate):
+    rng = np.random.RandomState(1)
+    X = rng.randn(34, 4)
+    for m in (HOPE(d=4, beta=0.01), GraphFactorization(d=4, max_iter=1, eta=0.1, regu=0.1)):
+        A = m.get_reconstructed_adj(X)
+        for i, j in ((0, 1), (5, 3), (33, 0), (7, 7)):
+            want = 0.0 if i == j else m.get_edge_weight(i, j)
+            assert A[i, j] == pytest.approx(want, rel=1e-12, abs=1e-15)
+
+
+def test_sampled_map_equals_full(sbm1024):
+    g = np.load(golden_path('gf_sbm1024_d32.npz'))
+    X = g['X']
+    m = GraphFactorization(d=32, max_iter=1, eta=0.02, regu=0.01)
+    est = m.get_reconstructed_adj(X)
+    truth = gr._adjacency_bool(sbm1024, 1024)
+    ap = gr.average_precision_rows(est, truth)
+    nodes = [0, 17, 500, 1000, 1023]
+    got = gr.sampled_map(sbm1024, lambda i: np.where(np.arange(1024) == i, 0.0, X @ X[i]), nodes)
+    assert got == pytest.approx(ap[nodes].mean(), abs=1e-12)
