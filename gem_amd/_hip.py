@@ -47,6 +47,25 @@ _SIGS = {
     'gemhip_gf_plan_current': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'gemhip_gf_plan_info': (C.c_int, [C.c_void_p, i64p]),
     'gemhip_gf_objective': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, f32p, f64p]),
+    'gemhip_n2v_train': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_float, C.c_float, C.c_uint64, C.c_int32, f32p, f64p]),
+    'gemhip_n2v_create': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.POINTER(C.c_void_p)]),
+    'gemhip_n2v_destroy': (C.c_int, [C.c_void_p]),
+    'gemhip_n2v_build_alias': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'gemhip_n2v_get_alias': (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
+    'gemhip_n2v_walks': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int64,
+                                   C.c_int64, C.c_void_p]),
+    'gemhip_n2v_set_walks': (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int32, C.c_int64]),
+    'gemhip_n2v_get_walks': (C.c_int, [C.c_void_p, i32p]),
+    'gemhip_n2v_walks_ptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p, i32p]),
+    'gemhip_n2v_vocab': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'gemhip_n2v_counts_ptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    'gemhip_n2v_build_unigram': (C.c_int, [C.c_void_p, i32p, f32p, i32p]),
+    'gemhip_sgns_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    'gemhip_sgns_set_tables': (C.c_int, [C.c_void_p, f32p, f32p]),
+    'gemhip_sgns_get_tables': (C.c_int, [C.c_void_p, f32p, f32p]),
+    'gemhip_sgns_train': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                    C.c_int64, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p]),
 }
 
 
@@ -90,6 +109,10 @@ def require_device():
 
 def ptr(a, ctype):
     return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+N2V_PAD_ZERO, N2V_UNIGRAM_QUIRK, N2V_DETERMINISTIC, N2V_UNIFORM_FIRST_HOP = 1, 2, 4, 8
+N2V_SNAP_COMPAT = 11
 
 
 def as_i32(a):

@@ -1,0 +1,743 @@
+// n2v.hip -- node2vec for MI355X (gfx950): transition tables, biased walks, vocabulary
+// counts, and skip-gram with negative sampling (SGNS).
+//
+// Replaces gem/embedding/node2vec.py:27-54, i.e. the subprocess call of the SNAP binary
+// gem/c_exe/node2vec (`-i -o -d -l -r -k -e -p -q -v -dr -w`) and the text files around
+// it.  Phases (symbols of the ELF) and their device equivalents:
+//   PreprocessTransitionProbs/GetNodeAlias -> n2v_alias_rows_kernel (first-order Vose tables;
+//        2nd-order bias by rejection sampling inside the walk, no sum(deg^2) tables)
+//   SimulateWalk/AliasDrawInt             -> n2v_walk_kernel   (one lane = one walker)
+//   LearnVocab                            -> n2v_vocab_kernel
+//   InitUnigramTable                      -> host Vose in fp64 (O(n), once)
+//   InitPosEmb/InitNegEmb                 -> sgns_init_kernel
+//   TrainModel (Hogwild over walks)       -> sgns_kernel       (one wavefront = one walk)
+//
+// All randomness is a counter-based Philox4x32-10 stream keyed by (seed, walk, position,
+// purpose): results do not depend on scheduling, and the CPU oracle reproduces walks,
+// counts and alias tables bit for bit.
+#include "common.hpp"
+#include <vector>
+#include <cmath>
+#include <algorithm>
+
+using namespace gemhip;
+
+namespace {
+enum { TAG_WALK = 1, TAG_WIN = 2, TAG_NEG = 3, TAG_INIT = 4 };
+constexpr int SGNS_NEG = 5;             // SNAP: NegSamN = 5 (compile-time constant there too)
+constexpr float SGNS_MAX_EXP = 6.0f;    // SNAP: MaxExp
+
+__host__ __device__ __forceinline__ uint32_t mulhi_range(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
+
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// Stateless stand-in for SNAP's NIdsV.Shuffle(): 4-round Feistel bijection, cycle-walked into [0,n).
+__host__ __device__ __forceinline__ uint32_t perm_node(uint32_t j, uint32_t n, uint32_t hb, uint64_t key)
+{
+    const uint32_t mask = (1u << hb) - 1u;
+    do {
+        uint32_t L = j >> hb, R = j & mask;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t k = (uint32_t)(key >> ((r & 1u) * 32)) + r * 0x9E3779B9u;
+            const uint32_t t = L ^ (fmix32(R + k) & mask);
+            L = R; R = t;
+        }
+        j = (L << hb) | R;
+    } while (j >= n);
+    return j;
+}
+}  // namespace
+
+struct gemhip_n2v {
+    int64_t n = 0, nnz = 0;
+    int device = 0;
+    bool uniform_rows = true;         // every row has equal weights -> no alias tables needed
+    int64_t *d_row_ptr = nullptr;
+    int32_t *d_col = nullptr;         // columns sorted inside each row
+    float *d_w = nullptr;
+    float *d_U = nullptr;             // first-order alias tables (per-row segments)
+    int32_t *d_K = nullptr;
+    // walks
+    int32_t *d_walks = nullptr;
+    int64_t walks_cap = 0;            // tokens allocated
+    int64_t nwalks = 0;               // local walks held
+    int32_t walk_len = 0;
+    int64_t walk_id_offset = 0;       // global id of local walk 0
+    // vocabulary / unigram
+    int32_t *d_counts = nullptr;
+    float *d_UT = nullptr;
+    int32_t *d_KT = nullptr;
+    bool unigram_ready = false;
+    // embeddings
+    int32_t d = 0;
+    float *SynPos = nullptr, *SynNeg = nullptr;
+    bool own_syn = false;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ alias tables
+// GetNodeAlias (ELF @0x4115f0): one thread per CSR row, sequential Vose in fp32.  The two
+// stacks share the row's segment of `work` (small grows up from 0, large down from N-1).
+__global__ void n2v_alias_rows_kernel(int64_t n, const int64_t *__restrict__ row_ptr, const float *__restrict__ w,
+                                      float *__restrict__ U, int32_t *__restrict__ K, int32_t *__restrict__ work_all)
+{
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int64_t a = row_ptr[v];
+    const int32_t N = (int32_t)(row_ptr[v + 1] - a);
+    if (N == 0) return;
+    const float *wt = w + a; float *Ur = U + a; int32_t *Kr = K + a; int32_t *work = work_all + a;
+    float sum = 0.0f;
+    for (int32_t i = 0; i < N; ++i) sum += wt[i];
+    int32_t ns = 0, nl = 0;
+    for (int32_t i = 0; i < N; ++i) {
+        Kr[i] = 0;
+        const float u = (wt[i] / sum) * (float)N;
+        Ur[i] = u;
+        if (u < 1.0f) work[ns++] = i; else work[N - 1 - nl++] = i;
+    }
+    while (ns > 0 && nl > 0) {
+        const int32_t s = work[--ns];
+        const int32_t l = work[N - nl]; --nl;
+        Kr[s] = l;
+        const float u = Ur[l] + Ur[s] - 1.0f;
+        Ur[l] = u;
+        if (u < 1.0f) work[ns++] = l; else work[N - 1 - nl++] = l;
+    }
+    while (ns > 0) Ur[work[--ns]] = 1.0f;
+    while (nl > 0) { Ur[work[N - nl]] = 1.0f; --nl; }
+}
+
+// ------------------------------------------------------------------------- walks
+__device__ __forceinline__ bool has_edge_sorted(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, int32_t t, int32_t x)
+{
+    int64_t lo = row_ptr[t];
+    const int64_t end = row_ptr[t + 1];
+    int64_t hi = end;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (col[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo < end && col[lo] == x;
+}
+
+// SimulateWalk (ELF @0x411a00).  One lane per walk; tokens are buffered 16 at a time in
+// registers so each lane writes 64 contiguous bytes (dwordx4 stores) instead of 4-byte scatters.
+template <bool SECOND, bool WEIGHTED>
+__global__ __launch_bounds__(256) void n2v_walk_kernel(int64_t n, uint32_t hb, const int64_t *__restrict__ row_ptr,
+                                                       const int32_t *__restrict__ col, const float *__restrict__ U,
+                                                       const int32_t *__restrict__ K, float ip, float iq, float amax,
+                                                       int32_t walk_len, uint64_t seed, int32_t flags, int64_t walk_begin,
+                                                       int64_t count, int32_t *__restrict__ walks)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= count) return;
+    const int64_t wid = walk_begin + tid;
+    const uint32_t round = (uint32_t)(wid / n), j = (uint32_t)(wid % n);
+    int32_t cur = (int32_t)perm_node(j, (uint32_t)n, hb, seed ^ ((uint64_t)(round + 1) * 0x9E3779B97F4A7C15ull));
+    int32_t prev = -1;
+    const int32_t pad = (flags & 1) ? 0 : -1;
+    const bool uniform_first = (flags & 8) != 0;
+    bool alive = true;
+    int32_t *out = walks + tid * walk_len;
+    const bool vec_ok = (walk_len & 3) == 0;
+
+    for (int32_t base = 0; base < walk_len; base += 16) {
+        int32_t buf[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int32_t len = base + k;       // number of tokens already emitted == index of this token
+            int32_t tok = pad;
+            if (len == 0) tok = cur;
+            else if (len < walk_len && alive) {
+                const int64_t a = row_ptr[cur];
+                const uint32_t deg = (uint32_t)(row_ptr[cur + 1] - a);
+                if (deg == 0) alive = false;
+                else {
+                    int32_t nxt = -1;
+                    for (uint32_t trial = 0;; ++trial) {
+                        const u32x4 r = philox4x32_10(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)len,
+                                                      (uint32_t)TAG_WALK | (trial << 8));
+                        uint32_t slot = mulhi_range(r.x, deg);
+                        if (WEIGHTED && !(len == 1 && uniform_first)) {
+                            if (!(u01(r.y) < U[a + slot])) slot = (uint32_t)K[a + slot];
+                        }
+                        const int32_t x = col[a + slot];
+                        if (!SECOND || len == 1) { nxt = x; break; }
+                        const float alpha = (x == prev) ? ip : (has_edge_sorted(row_ptr, col, prev, x) ? 1.0f : iq);
+                        if (u01(r.z) * amax < alpha || trial >= 4095u) { nxt = x; break; }
+                    }
+                    prev = cur; cur = nxt; tok = nxt;
+                }
+            }
+            buf[k] = tok;
+        }
+        if (vec_ok) {
+#pragma unroll
+            for (int k = 0; k < 16; k += 4)
+                if (base + k < walk_len) *reinterpret_cast<int4 *>(out + base + k) = make_int4(buf[k], buf[k + 1], buf[k + 2], buf[k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (base + k < walk_len) out[base + k] = buf[k];
+        }
+    }
+}
+
+// LearnVocab (ELF @0x40d560): token histogram.
+__global__ void n2v_vocab_kernel(const int32_t *__restrict__ walks, int64_t ntokens, int32_t *__restrict__ counts)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntokens; i += stride) {
+        const int32_t t = walks[i];
+        if (t >= 0) atomicAdd(&counts[t], 1);
+    }
+}
+
+// -------------------------------------------------------------------------- SGNS
+// InitPosEmb (ELF @0x40e270): (U(0,1)-0.5)/d ; InitNegEmb: zeros.
+__global__ void sgns_init_kernel(float *SynPos, float *SynNeg, int64_t total, int32_t d, uint64_t seed)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * 4 >= total) return;
+    const u32x4 r = philox4x32_10(seed, (uint32_t)t, (uint32_t)((uint64_t)t >> 32), 0u, (uint32_t)TAG_INIT);
+    const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+    for (int k = 0; k < 4; ++k)
+        if (t * 4 + k < total) {
+            SynPos[t * 4 + k] = (u01(v[k]) - 0.5f) / (float)d;
+            SynNeg[t * 4 + k] = 0.0f;
+        }
+}
+
+template <int VEC>
+__device__ __forceinline__ void ld_row(const float *p, int d, int lane, int c, float (&v)[VEC])
+{
+    const int idx = (c * WAVE + lane) * VEC;
+    if constexpr (VEC == 2) {
+        if (idx < d) { const float2 t = *reinterpret_cast<const float2 *>(p + idx); v[0] = t.x; v[1] = t.y; }
+        else { v[0] = 0.f; v[1] = 0.f; }
+    } else {
+        v[0] = idx < d ? p[idx] : 0.f;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void st_row(float *p, int d, int lane, int c, const float (&v)[VEC])
+{
+    const int idx = (c * WAVE + lane) * VEC;
+    if (idx < d) {
+        if constexpr (VEC == 2) *reinterpret_cast<float2 *>(p + idx) = make_float2(v[0], v[1]);
+        else p[idx] = v[0];
+    }
+}
+
+struct SgnsArgs {
+    const int32_t *walks; int64_t walk_lo, walk_hi; int32_t walk_len; int32_t window;
+    float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
+    const float *UT; const int32_t *KT; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
+    float *SynPos; float *SynNeg; int32_t nwaves;
+};
+
+// gradient scale of TrainModel: (label - sigma(f)) * alpha with the +-MaxExp clamps
+__device__ __forceinline__ float sgns_grad(float f, float label, float alpha)
+{
+    if (f > SGNS_MAX_EXP) return (label - 1.0f) * alpha;
+    if (f < -SGNS_MAX_EXP) return label * alpha;
+    return (label - 1.0f + 1.0f / (1.0f + expf(f))) * alpha;
+}
+
+// TrainModel (ELF @0x40d6a0).  One wavefront owns one walk: tokens and the pre-drawn
+// negative targets of the current centre sit in LDS; the centre's positive row SynNeg[word]
+// stays in registers across all its contexts; per context the context row and the five
+// negative rows are fetched together (6 coalesced 4d-byte reads in flight), reduced with
+// DPP wave sums, and written back.  Hogwild across wavefronts, exactly sequential inside one.
+template <int VEC, int NV>
+__global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int per_wave = A.walk_len + 2 * A.window * SGNS_NEG;
+    int32_t *tok = lds + wave * per_wave;
+    int32_t *negs = tok + A.walk_len;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (gw >= A.nwaves) return;
+    const int d = A.d;
+    const int win = A.window;
+    const bool quirk = (A.flags & 2) != 0;
+
+    for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
+        const int32_t *walk = A.walks + wl * A.walk_len;
+        for (int k = lane; k < A.walk_len; k += WAVE) tok[k] = walk[k];
+        __builtin_amdgcn_wave_barrier();
+        const int64_t wid = A.walk_id_offset + wl;
+        const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
+
+        for (int pos = 0; pos < A.walk_len; ++pos) {
+            const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
+            if (word < 0) continue;
+            // alpha: refreshed every 10000 words of the global count (TrainModel)
+            const int64_t t = A.token_offset + wl * A.walk_len + pos;
+            const int64_t tq = t - (t % 10000);
+            float alpha = A.alpha0 * (1.0f - (float)((double)tq / (double)A.denom));
+            alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
+            const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
+            const int b = (int)(rw.x % (uint32_t)win);
+            // draw every negative target of this centre at once: sample s = (a, j) -> lane-parallel table lookups
+            const int nsamp = 2 * win * SGNS_NEG;
+            for (int s = lane; s < nsamp; s += WAVE) {
+                const int ai = s / SGNS_NEG;                 // 0 .. 2*win-1  (context slot, skipping the centre)
+                const int a = ai < win ? ai : ai + 1;
+                const int j = s - ai * SGNS_NEG + 1;
+                const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos | ((uint32_t)a << 16),
+                                               (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
+                const uint32_t slot = mulhi_range(rn.x, A.n);
+                const int32_t X = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
+                negs[s] = (u01(rn.y) < A.UT[X]) ? X : A.KT[X];
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            float yp[NV][VEC];                               // SynNeg[word]: positive target of every context of this centre
+            float *pp = A.SynNeg + (int64_t)word * d;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
+
+            for (int a = b; a < 2 * win + 1 - b; ++a) {
+                if (a == win) continue;
+                const int cp = pos - win + a;
+                if (cp < 0 || cp >= A.walk_len) continue;
+                const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[cp]);
+                if (ctx < 0) continue;
+                const int ai = a < win ? a : a - 1;
+                int32_t tgt[SGNS_NEG];
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readfirstlane(negs[ai * SGNS_NEG + j]);
+
+                float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
+                float *pc = A.SynPos + (int64_t)ctx * d;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) {
+                    const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
+                }
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) neu[c][v] = 0.f;
+
+                {   // j = 0: positive target (label 1), row lives in registers
+                    float part = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) part += xc[c][v] * yp[c][v];
+                    const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yp[c][v]; yp[c][v] += g * xc[c][v]; }
+                }
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) {
+                    if (tgt[j] == word) continue;                        // TrainModel: `if (Target == Word) continue`
+                    // a target drawn twice for this context must see the first update (sequential semantics)
+#pragma unroll
+                    for (int jp = 0; jp < j; ++jp)
+                        if (tgt[jp] == tgt[j] && tgt[jp] != word) {
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int v = 0; v < VEC; ++v) yn[j][c][v] = yn[jp][c][v];
+                        }
+                    float part = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) part += xc[c][v] * yn[j][c][v];
+                    const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yn[j][c][v]; yn[j][c][v] += g * xc[c][v]; }
+                    float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+                }
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
+                    st_row<VEC>(pc, d, lane, c, xc[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
+template <int VEC, int NV>
+void launch_sgns(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL((sgns_kernel<VEC, NV>), dim3(blocks), dim3(threads), lds, s, A);
+}
+sgns_fn pick_sgns(int d)
+{
+    if (d % 2 == 0) {
+        const int nv = (d + 127) / 128;
+        if (nv <= 1) return launch_sgns<2, 1>;
+        if (nv <= 2) return launch_sgns<2, 2>;
+        if (nv <= 4) return launch_sgns<2, 4>;
+        return nullptr;
+    }
+    const int nv = (d + 63) / 64;
+    if (nv <= 1) return launch_sgns<1, 1>;
+    if (nv <= 2) return launch_sgns<1, 2>;
+    if (nv <= 4) return launch_sgns<1, 4>;
+    return nullptr;
+}
+
+uint32_t half_bits(uint64_t n)
+{
+    uint32_t bits = 1;
+    while (((uint64_t)1 << bits) < n) ++bits;
+    return (bits + 1) / 2;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------- host API
+extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
+                                 gemhip_n2v_t *out)
+{
+    GEMHIP_REQUIRE(out != nullptr, "n2v_create: out is NULL");
+    *out = nullptr;
+    GEMHIP_REQUIRE(n > 0 && n < (int64_t)0x7fffffff, "n2v_create: n=%lld out of range", (long long)n);
+    GEMHIP_REQUIRE(nnz >= 0 && row_ptr && (nnz == 0 || col), "n2v_create: bad CSR arrays");
+    GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "n2v_create: row_ptr[0]=%lld row_ptr[n]=%lld nnz=%lld",
+                   (long long)row_ptr[0], (long long)row_ptr[n], (long long)nnz);
+    // sort columns inside each row (needed by the has_edge test of the 2nd-order walk); weights follow
+    std::vector<int32_t> c(col, col + nnz);
+    std::vector<float> ww;
+    if (w) ww.assign(w, w + nnz);
+    bool uniform = true;
+    std::vector<std::pair<int32_t, float>> tmp;
+    for (int64_t v = 0; v < n; ++v) {
+        const int64_t a = row_ptr[v], b = row_ptr[v + 1];
+        GEMHIP_REQUIRE(a <= b && b <= nnz, "n2v_create: row_ptr not monotone at row %lld", (long long)v);
+        bool sorted = true;
+        for (int64_t e = a; e < b; ++e) {
+            GEMHIP_REQUIRE(c[e] >= 0 && c[e] < n, "n2v_create: column %d outside [0,%lld)", c[e], (long long)n);
+            if (e > a && c[e] < c[e - 1]) sorted = false;
+            if (w && w[e] != w[a]) uniform = false;
+            if (w) GEMHIP_REQUIRE(w[e] > 0.f, "n2v_create: non-positive weight at edge %lld", (long long)e);
+        }
+        if (!sorted) {
+            tmp.clear();
+            for (int64_t e = a; e < b; ++e) tmp.emplace_back(c[e], w ? ww[e] : 1.f);
+            std::stable_sort(tmp.begin(), tmp.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+            for (int64_t e = a; e < b; ++e) { c[e] = tmp[e - a].first; if (w) ww[e] = tmp[e - a].second; }
+        }
+    }
+    auto *h = new gemhip_n2v();
+    h->n = n; h->nnz = nnz; h->uniform_rows = uniform;
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
+    hipError_t e = hipMalloc((void **)&h->d_row_ptr, (n + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMemcpy(h->d_row_ptr, row_ptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_col, std::max<int64_t>(nnz, 4) * sizeof(int32_t));
+    if (e == hipSuccess && nnz) e = hipMemcpy(h->d_col, c.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !uniform) {
+        e = hipMalloc((void **)&h->d_w, nnz * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(h->d_w, ww.data(), nnz * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_counts, n * sizeof(int32_t));
+    if (e != hipSuccess) { gemhip_n2v_destroy(h); return fail(GEMHIP_E_HIP, "n2v_create: device upload failed: %s", hipGetErrorString(e)); }
+    *out = h;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
+{
+    if (!h) return GEMHIP_OK;
+    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks);
+    hipFree(h->d_counts); hipFree(h->d_UT); hipFree(h->d_KT);
+    if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
+    delete h;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_build_alias(gemhip_n2v_t h, void *stream)
+{
+    GEMHIP_REQUIRE(h, "n2v_build_alias: NULL handle");
+    if (h->uniform_rows || h->d_U) return GEMHIP_OK;
+    int32_t *work = nullptr;
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_U, h->nnz * sizeof(float)));
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_K, h->nnz * sizeof(int32_t)));
+    GEMHIP_CHECK(hipMalloc((void **)&work, h->nnz * sizeof(int32_t)));
+    hipLaunchKernelGGL(n2v_alias_rows_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->n,
+                       h->d_row_ptr, h->d_w, h->d_U, h->d_K, work);
+    GEMHIP_CHECK(hipGetLastError());
+    GEMHIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    GEMHIP_CHECK(hipFree(work));
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_get_alias(gemhip_n2v_t h, float *U_host, int32_t *K_host, int32_t *col_sorted_host)
+{
+    GEMHIP_REQUIRE(h, "n2v_get_alias: NULL handle");
+    if (col_sorted_host && h->nnz) GEMHIP_CHECK(hipMemcpy(col_sorted_host, h->d_col, h->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h->uniform_rows) return 1;          // no tables: rows are uniform
+    GEMHIP_REQUIRE(h->d_U, "n2v_get_alias: build_alias not called");
+    if (U_host) GEMHIP_CHECK(hipMemcpy(U_host, h->d_U, h->nnz * sizeof(float), hipMemcpyDeviceToHost));
+    if (K_host) GEMHIP_CHECK(hipMemcpy(K_host, h->d_K, h->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GEMHIP_OK;
+}
+
+static int ensure_walk_buffer(gemhip_n2v_t h, int64_t nwalks, int32_t walk_len)
+{
+    const int64_t need = nwalks * walk_len;
+    if (need > h->walks_cap) {
+        hipFree(h->d_walks); h->d_walks = nullptr; h->walks_cap = 0;
+        GEMHIP_CHECK(hipMalloc((void **)&h->d_walks, std::max<int64_t>(need, 4) * sizeof(int32_t)));
+        h->walks_cap = need;
+    }
+    h->nwalks = nwalks; h->walk_len = walk_len;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_walks(gemhip_n2v_t h, float p, float q, int32_t num_walks, int32_t walk_len, uint64_t seed,
+                                int32_t flags, int64_t walk_begin, int64_t walk_end, void *stream)
+{
+    GEMHIP_REQUIRE(h, "n2v_walks: NULL handle");
+    GEMHIP_REQUIRE(p > 0.f && q > 0.f, "n2v_walks: p=%g q=%g must be > 0", (double)p, (double)q);
+    GEMHIP_REQUIRE(num_walks >= 1 && walk_len >= 1 && walk_len < 65536, "n2v_walks: num_walks=%d walk_len=%d", num_walks, walk_len);
+    const int64_t total = h->n * (int64_t)num_walks;
+    GEMHIP_REQUIRE(0 <= walk_begin && walk_begin <= walk_end && walk_end <= total, "n2v_walks: bad walk range [%lld,%lld) of %lld",
+                   (long long)walk_begin, (long long)walk_end, (long long)total);
+    if (!h->uniform_rows && !h->d_U) { if (int rc = gemhip_n2v_build_alias(h, stream)) return rc; }
+    const int64_t count = walk_end - walk_begin;
+    if (int rc = ensure_walk_buffer(h, count, walk_len)) return rc;
+    h->walk_id_offset = walk_begin;
+    h->unigram_ready = false;
+    if (count == 0) return GEMHIP_OK;
+    const bool second = !(p == 1.0f && q == 1.0f);
+    const float ip = 1.0f / p, iq = 1.0f / q;
+    const float amax = std::max(1.0f, std::max(ip, iq));
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t hb = half_bits((uint64_t)h->n);
+#define N2V_WALK(S, W) hipLaunchKernelGGL((n2v_walk_kernel<S, W>), grid, block, 0, s, h->n, hb, h->d_row_ptr, h->d_col, h->d_U, h->d_K, ip, \
+                                          iq, amax, walk_len, seed, flags, walk_begin, count, h->d_walks)
+    if (second) { if (h->uniform_rows) N2V_WALK(true, false); else N2V_WALK(true, true); }
+    else        { if (h->uniform_rows) N2V_WALK(false, false); else N2V_WALK(false, true); }
+#undef N2V_WALK
+    GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_set_walks(gemhip_n2v_t h, const int32_t *walks_host, int64_t nwalks, int32_t walk_len, int64_t walk_id_offset)
+{
+    GEMHIP_REQUIRE(h && walks_host && nwalks >= 0 && walk_len >= 1 && walk_len < 65536, "n2v_set_walks: bad arguments");
+    if (int rc = ensure_walk_buffer(h, nwalks, walk_len)) return rc;
+    h->walk_id_offset = walk_id_offset;
+    h->unigram_ready = false;
+    if (nwalks) GEMHIP_CHECK(hipMemcpy(h->d_walks, walks_host, nwalks * walk_len * sizeof(int32_t), hipMemcpyHostToDevice));
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_get_walks(gemhip_n2v_t h, int32_t *walks_host)
+{
+    GEMHIP_REQUIRE(h && walks_host, "n2v_get_walks: NULL argument");
+    GEMHIP_CHECK(hipDeviceSynchronize());
+    if (h->nwalks) GEMHIP_CHECK(hipMemcpy(walks_host, h->d_walks, h->nwalks * h->walk_len * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_walks_ptr(gemhip_n2v_t h, void **d_walks, int64_t *nwalks, int32_t *walk_len)
+{
+    GEMHIP_REQUIRE(h && d_walks, "n2v_walks_ptr: NULL argument");
+    *d_walks = h->d_walks;
+    if (nwalks) *nwalks = h->nwalks;
+    if (walk_len) *walk_len = h->walk_len;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_vocab(gemhip_n2v_t h, void *stream)
+{
+    GEMHIP_REQUIRE(h, "n2v_vocab: NULL handle");
+    hipStream_t s = (hipStream_t)stream;
+    GEMHIP_CHECK(hipMemsetAsync(h->d_counts, 0, h->n * sizeof(int32_t), s));
+    const int64_t ntok = h->nwalks * h->walk_len;
+    if (ntok) {
+        const int64_t blocks = std::min<int64_t>((ntok + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(n2v_vocab_kernel, dim3((unsigned)blocks), dim3(256), 0, s, h->d_walks, ntok, h->d_counts);
+        GEMHIP_CHECK(hipGetLastError());
+    }
+    h->unigram_ready = false;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_counts_ptr(gemhip_n2v_t h, void **d_counts)
+{
+    GEMHIP_REQUIRE(h && d_counts, "n2v_counts_ptr: NULL argument");
+    *d_counts = h->d_counts;
+    return GEMHIP_OK;
+}
+
+// InitUnigramTable (ELF @0x40e520): count^0.75, Vose in fp64, stacks popped from the back.
+extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, float *UT_out, int32_t *KT_out)
+{
+    GEMHIP_REQUIRE(h, "n2v_build_unigram: NULL handle");
+    GEMHIP_CHECK(hipDeviceSynchronize());
+    const int64_t n = h->n;
+    std::vector<int32_t> cnt(n), K(n, 0), small, large;
+    GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<double> U(n);
+    double total = 0.0;
+    for (int64_t i = 0; i < n; ++i) { U[i] = std::pow((double)cnt[i], 0.75); total += U[i]; }
+    GEMHIP_REQUIRE(total > 0.0, "n2v_build_unigram: empty vocabulary (no walks?)");
+    for (int64_t i = 0; i < n; ++i) U[i] /= total;
+    small.reserve(n); large.reserve(n);
+    for (int64_t i = 0; i < n; ++i) {
+        U[i] = U[i] * (double)n;
+        if (U[i] < 1.0) small.push_back((int32_t)i); else large.push_back((int32_t)i);
+    }
+    while (!small.empty() && !large.empty()) {
+        const int32_t s = small.back(); small.pop_back();
+        const int32_t l = large.back(); large.pop_back();
+        K[s] = l;
+        U[l] = U[l] + U[s] - 1.0;
+        if (U[l] < 1.0) small.push_back(l); else large.push_back(l);
+    }
+    for (int32_t s : small) U[s] = 1.0;
+    for (int32_t l : large) U[l] = 1.0;
+    std::vector<float> Uf(n);
+    for (int64_t i = 0; i < n; ++i) Uf[i] = (float)U[i];
+    if (!h->d_UT) GEMHIP_CHECK(hipMalloc((void **)&h->d_UT, n * sizeof(float)));
+    if (!h->d_KT) GEMHIP_CHECK(hipMalloc((void **)&h->d_KT, n * sizeof(int32_t)));
+    GEMHIP_CHECK(hipMemcpy(h->d_UT, Uf.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    GEMHIP_CHECK(hipMemcpy(h->d_KT, K.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->unigram_ready = true;
+    if (counts_out) std::copy(cnt.begin(), cnt.end(), counts_out);
+    if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
+    if (KT_out) std::copy(K.begin(), K.end(), KT_out);
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_init(gemhip_n2v_t h, int32_t d, uint64_t seed, void *dSynPos, void *dSynNeg)
+{
+    GEMHIP_REQUIRE(h && d >= 1, "sgns_init: bad arguments");
+    GEMHIP_REQUIRE(pick_sgns(d) != nullptr, "sgns_init: d=%d unsupported (even d <= 512, odd d <= 256)", d);
+    GEMHIP_REQUIRE((dSynPos == nullptr) == (dSynNeg == nullptr), "sgns_init: pass both or neither external table");
+    if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); h->own_syn = false; }
+    const size_t bytes = (size_t)h->n * d * sizeof(float);
+    if (dSynPos) { h->SynPos = (float *)dSynPos; h->SynNeg = (float *)dSynNeg; }
+    else {
+        GEMHIP_CHECK(hipMalloc((void **)&h->SynPos, bytes));
+        GEMHIP_CHECK(hipMalloc((void **)&h->SynNeg, bytes));
+        h->own_syn = true;
+    }
+    h->d = d;
+    const int64_t total = h->n * (int64_t)d;
+    const int64_t threads = (total + 3) / 4;
+    hipLaunchKernelGGL(sgns_init_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, h->SynPos, h->SynNeg, total, d, seed);
+    GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_set_tables(gemhip_n2v_t h, const float *SynPos_host, const float *SynNeg_host)
+{
+    GEMHIP_REQUIRE(h && h->SynPos && SynPos_host && SynNeg_host, "sgns_set_tables: bad arguments (call sgns_init first)");
+    const size_t bytes = (size_t)h->n * h->d * sizeof(float);
+    GEMHIP_CHECK(hipMemcpy(h->SynPos, SynPos_host, bytes, hipMemcpyHostToDevice));
+    GEMHIP_CHECK(hipMemcpy(h->SynNeg, SynNeg_host, bytes, hipMemcpyHostToDevice));
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_get_tables(gemhip_n2v_t h, float *SynPos_host, float *SynNeg_host)
+{
+    GEMHIP_REQUIRE(h && h->SynPos, "sgns_get_tables: no tables");
+    GEMHIP_CHECK(hipDeviceSynchronize());
+    const size_t bytes = (size_t)h->n * h->d * sizeof(float);
+    if (SynPos_host) GEMHIP_CHECK(hipMemcpy(SynPos_host, h->SynPos, bytes, hipMemcpyDeviceToHost));
+    if (SynNeg_host) GEMHIP_CHECK(hipMemcpy(SynNeg_host, h->SynNeg, bytes, hipMemcpyDeviceToHost));
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0, int32_t epochs, int32_t epoch,
+                                 int64_t walk_lo, int64_t walk_hi, int64_t tokens_total, int64_t token_offset, uint64_t seed,
+                                 int32_t flags, void *stream)
+{
+    GEMHIP_REQUIRE(h && h->SynPos, "sgns_train: call sgns_init first");
+    GEMHIP_REQUIRE(h->unigram_ready, "sgns_train: call n2v_vocab + n2v_build_unigram first");
+    GEMHIP_REQUIRE(neg == SGNS_NEG, "sgns_train: neg=%d unsupported (the reference binary fixes NegSamN=5)", neg);
+    GEMHIP_REQUIRE(window >= 1 && window < 16384, "sgns_train: window=%d", window);
+    GEMHIP_REQUIRE(epochs >= 1 && epoch >= 0 && epoch < epochs && epoch < 256, "sgns_train: epoch %d of %d", epoch, epochs);
+    GEMHIP_REQUIRE(0 <= walk_lo && walk_lo <= walk_hi && walk_hi <= h->nwalks, "sgns_train: bad local walk range");
+    GEMHIP_REQUIRE(tokens_total >= 1, "sgns_train: tokens_total=%lld", (long long)tokens_total);
+    if (walk_hi == walk_lo) return GEMHIP_OK;
+    SgnsArgs A;
+    A.walks = h->d_walks; A.walk_lo = walk_lo; A.walk_hi = walk_hi; A.walk_len = h->walk_len; A.window = window;
+    A.alpha0 = alpha0; A.denom = (int64_t)epochs * tokens_total + 1;
+    // the kernel computes t = token_offset + wl*walk_len + pos with wl the LOCAL walk index
+    A.token_offset = token_offset; A.walk_id_offset = h->walk_id_offset; A.epoch = epoch;
+    A.UT = h->d_UT; A.KT = h->d_KT; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
+    A.SynPos = h->SynPos; A.SynNeg = h->SynNeg;
+    const bool deterministic = (flags & 4) != 0;
+    const size_t per_wave = (size_t)(h->walk_len + 2 * window * SGNS_NEG) * sizeof(int32_t);
+    int blocks, threads;
+    if (deterministic) { blocks = 1; threads = 64; A.nwaves = 1; }
+    else {
+        threads = 256;
+        const int64_t want = (walk_hi - walk_lo + 3) / 4;
+        blocks = (int)std::min<int64_t>(want, 256 * 8);          // 256 CUs x 8 blocks of 4 waves = 32 waves per CU
+        A.nwaves = blocks * 4;
+    }
+    const size_t lds = per_wave * (threads / 64);
+    GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window too large for LDS staging (%zu bytes)", lds);
+    pick_sgns(h->d)(A, blocks, threads, lds, (hipStream_t)stream);
+    GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+// One-shot drop-in for `node2vec -i -o -d -l -r -k -e -p -q -dr -w` (node2vec.py:34-53).
+extern "C" int gemhip_n2v_train(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, int32_t d,
+                                int32_t walk_len, int32_t num_walks, int32_t window, int32_t epochs, float p, float q,
+                                uint64_t seed, int32_t flags, float *X_out, double *stats)
+{
+    GEMHIP_REQUIRE(X_out != nullptr, "n2v_train: X_out is NULL");
+    gemhip_n2v_t h = nullptr;
+    int rc = gemhip_n2v_create(n, nnz, row_ptr, col, w, &h);
+    if (rc) return rc;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (auto &e : ev) if (!rc && hipEventCreate(&e) != hipSuccess) rc = fail(GEMHIP_E_HIP, "n2v_train: hipEventCreate");
+    const int64_t nwalks = n * (int64_t)num_walks;
+    if (!rc) { hipEventRecord(ev[0], 0); rc = gemhip_n2v_walks(h, p, q, num_walks, walk_len, seed, flags, 0, nwalks, nullptr); }
+    if (!rc) rc = gemhip_n2v_vocab(h, nullptr);
+    if (!rc) { hipEventRecord(ev[1], 0); rc = gemhip_n2v_build_unigram(h, nullptr, nullptr, nullptr); }
+    if (!rc) rc = gemhip_sgns_init(h, d, seed, nullptr, nullptr);
+    if (!rc) hipEventRecord(ev[2], 0);
+    for (int ep = 0; !rc && ep < epochs; ++ep)
+        rc = gemhip_sgns_train(h, window, SGNS_NEG, 0.025f, epochs, ep, 0, nwalks, nwalks * walk_len, (int64_t)ep * nwalks * walk_len,
+                               seed, flags, nullptr);
+    if (!rc) { hipEventRecord(ev[3], 0); rc = gemhip_sgns_get_tables(h, X_out, nullptr); }
+    if (!rc && stats) {
+        float a = 0, b = 0;
+        hipEventElapsedTime(&a, ev[0], ev[1]);
+        hipEventElapsedTime(&b, ev[2], ev[3]);
+        stats[0] = a * 1e-3; stats[1] = b * 1e-3; stats[2] = (double)nwalks * walk_len; stats[3] = h->uniform_rows ? 1.0 : 0.0;
+    }
+    for (auto &e : ev) if (e) hipEventDestroy(e);
+    gemhip_n2v_destroy(h);
+    return rc;
+}

@@ -104,6 +104,76 @@ int gemhip_gf_objective(int64_t n, int64_t m, const int32_t *src,
                         const int32_t *dst, const float *w, int32_t d,
                         const float *X_host, double *out);
 
+/* ------------------------------------------------------------------ node2vec
+ * Replaces: gem/embedding/node2vec.py:27-54 (node2vec.learn_embedding), i.e. the
+ * subprocess call of the prebuilt SNAP binary gem/c_exe/node2vec with
+ * `-i:tempGraph.graph -o:tempGraph.emb -d -l -r -k -e -p -q -v -dr -w`
+ * (node2vec.py:35-46) and the text files around it (graph_util.py:137-140, 161-169).
+ *
+ * Graph: CSR by source (row_ptr int64[n+1], col int32[nnz], w float32[nnz] or NULL
+ * for unit weights) -- what the binary builds from the "%d %d %f" edge list.
+ *
+ * flags (bit set): 1 = short walks are padded with token 0 and trained on, like the
+ * binary's zero-initialised walk matrix (else padded with -1 and skipped);
+ * 2 = negative sampling indexes the alias table the way the binary's RndUnigramInt
+ * does (KTable[floor(u*n)], see oracle/n2v_oracle.c); 4 = deterministic: SGNS runs
+ * on ONE wavefront in walk order (bit-reproducible, for parity tests; slow);
+ * 8 = first hop of a walk is uniform over neighbours, like SimulateWalk.
+ * GEMHIP_N2V_SNAP_COMPAT = 1|2|8 mirrors the reference binary. */
+#define GEMHIP_N2V_PAD_ZERO 1
+#define GEMHIP_N2V_UNIGRAM_QUIRK 2
+#define GEMHIP_N2V_DETERMINISTIC 4
+#define GEMHIP_N2V_UNIFORM_FIRST_HOP 8
+#define GEMHIP_N2V_SNAP_COMPAT 11
+
+typedef struct gemhip_n2v *gemhip_n2v_t;
+
+/* One-shot drop-in for the binary: X_out [n][d] float32 = SynPos in node-id order
+ * (what loadEmbedding reads back).  alpha0 = 0.025, 5 negatives as in the binary.
+ * stats (optional, 4 doubles): {walk_seconds, sgns_seconds, tokens, rows_uniform}. */
+int gemhip_n2v_train(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col,
+                     const float *w, int32_t d, int32_t walk_len, int32_t num_walks,
+                     int32_t window, int32_t epochs, float p, float q, uint64_t seed,
+                     int32_t flags, float *X_out, double *stats);
+
+/* Staged form (graph, walks and tables resident in HBM; used by bench.py, the
+ * multi-GPU driver and the parity tests). */
+int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col,
+                      const float *w, gemhip_n2v_t *out);
+int gemhip_n2v_destroy(gemhip_n2v_t h);
+/* PreprocessTransitionProbs: first-order Vose alias tables per row (no-op when every
+ * row has equal weights).  2nd-order bias is applied by rejection inside the walk. */
+int gemhip_n2v_build_alias(gemhip_n2v_t h, void *stream);
+/* Fetch tables/sorted columns for tests.  Returns 1 (not an error) when rows are uniform
+ * and no tables exist. */
+int gemhip_n2v_get_alias(gemhip_n2v_t h, float *U_host, int32_t *K_host, int32_t *col_sorted_host);
+/* SimulateWalk for global walk ids [walk_begin, walk_end) of n*num_walks (walk id
+ * r*n + j starts at the j-th node of round r's permutation): this rank's shard. */
+int gemhip_n2v_walks(gemhip_n2v_t h, float p, float q, int32_t num_walks, int32_t walk_len,
+                     uint64_t seed, int32_t flags, int64_t walk_begin, int64_t walk_end,
+                     void *stream);
+int gemhip_n2v_set_walks(gemhip_n2v_t h, const int32_t *walks_host, int64_t nwalks,
+                         int32_t walk_len, int64_t walk_id_offset);
+int gemhip_n2v_get_walks(gemhip_n2v_t h, int32_t *walks_host);
+int gemhip_n2v_walks_ptr(gemhip_n2v_t h, void **d_walks, int64_t *nwalks, int32_t *walk_len);
+/* LearnVocab: token counts of the local walks into a device int32[n] (counts_ptr exposes
+ * it so a multi-GPU driver can all-reduce it), then InitUnigramTable on the host. */
+int gemhip_n2v_vocab(gemhip_n2v_t h, void *stream);
+int gemhip_n2v_counts_ptr(gemhip_n2v_t h, void **d_counts);
+int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, float *UT_out, int32_t *KT_out);
+/* InitPosEmb / InitNegEmb.  dSynPos/dSynNeg: optional caller-owned DEVICE tables
+ * [n][d] float32 (both or neither). */
+int gemhip_sgns_init(gemhip_n2v_t h, int32_t d, uint64_t seed, void *dSynPos, void *dSynNeg);
+int gemhip_sgns_set_tables(gemhip_n2v_t h, const float *SynPos_host, const float *SynNeg_host);
+int gemhip_sgns_get_tables(gemhip_n2v_t h, float *SynPos_host, float *SynNeg_host);
+/* TrainModel over LOCAL walks [walk_lo, walk_hi) for epoch `epoch` of `epochs`.
+ * tokens_total = tokens of ALL ranks per epoch (the binary's AllWords), token_offset =
+ * global word count before local walk 0 -- together they drive the linear alpha decay. */
+int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0,
+                      int32_t epochs, int32_t epoch, int64_t walk_lo, int64_t walk_hi,
+                      int64_t tokens_total, int64_t token_offset, uint64_t seed,
+                      int32_t flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,23 @@ def lib():
         L.oracle_gf_train_f64.restype = None
         L.oracle_gf_objective.argtypes = [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, f32p, f64p]
         L.oracle_gf_objective.restype = None
+        i64p, u32p = C.POINTER(C.c_int64), C.POINTER(C.c_uint32)
+        L.oracle_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p]
+        L.oracle_perm.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.oracle_perm.restype = C.c_uint32
+        L.oracle_alias_build_f32.argtypes = [C.c_int32, f32p, f32p, i32p, i32p]
+        L.oracle_n2v_alias_rows.argtypes = [C.c_int64, i64p, f32p, f32p, i32p]
+        L.oracle_n2v_walks.argtypes = [C.c_int64, i64p, i32p, f32p, i32p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_uint64,
+                                       C.c_int32, C.c_int64, C.c_int64, i32p]
+        L.oracle_n2v_vocab.argtypes = [C.c_int64, C.c_int64, i32p, i32p]
+        L.oracle_unigram_build.argtypes = [C.c_int64, i32p, f64p, i32p]
+        L.oracle_sgns_train.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_float,
+                                        C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, f32p, i32p, C.c_uint64,
+                                        C.c_int32, f32p, f32p]
+        L.oracle_sgns_init.argtypes = [C.c_int64, C.c_int32, C.c_uint64, f32p, f32p]
+        for f in ('oracle_philox', 'oracle_alias_build_f32', 'oracle_n2v_alias_rows', 'oracle_n2v_walks', 'oracle_n2v_vocab',
+                  'oracle_unigram_build', 'oracle_sgns_train', 'oracle_sgns_init'):
+            getattr(L, f).restype = None
         _lib = L
     return _lib
 
@@ -82,3 +99,78 @@ def gf_objective(n, src, dst, w, d, X):
     lib().oracle_gf_objective(n, len(src), _p(src, C.c_int32), _p(dst, C.c_int32), _p(w, C.c_float), d, _p(X, C.c_float),
                               _p(out, C.c_double))
     return float(out[0]), float(out[1])
+
+
+# ------------------------------------------------------------------ node2vec
+def sorted_csr(n, src, dst, w=None):
+    """CSR with columns sorted inside each row (what the device uses for walks)."""
+    src = np.asarray(src); dst = np.asarray(dst)
+    perm = np.lexsort((dst, src))
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=n), out=row_ptr[1:])
+    col = np.ascontiguousarray(dst[perm], dtype=np.int32)
+    ww = None if w is None else np.ascontiguousarray(np.asarray(w, dtype=np.float32)[perm])
+    return row_ptr, col, ww
+
+
+def n2v_alias_rows(row_ptr, w):
+    n = len(row_ptr) - 1
+    U = np.zeros(len(w), dtype=np.float32); K = np.zeros(len(w), dtype=np.int32)
+    lib().oracle_n2v_alias_rows(n, _p(row_ptr, C.c_int64), _p(w, C.c_float), _p(U, C.c_float), _p(K, C.c_int32))
+    return U, K
+
+
+def n2v_walks(row_ptr, col, U, K, p, q, num_walks, walk_len, seed, flags, walk_begin=0, walk_end=None):
+    n = len(row_ptr) - 1
+    if walk_end is None:
+        walk_end = n * num_walks
+    out = np.empty((walk_end - walk_begin, walk_len), dtype=np.int32)
+    lib().oracle_n2v_walks(n, _p(row_ptr, C.c_int64), _p(col, C.c_int32), _p(U, C.c_float), _p(K, C.c_int32), p, q, num_walks,
+                           walk_len, seed, flags, walk_begin, walk_end, _p(out, C.c_int32))
+    return out
+
+
+def n2v_vocab(n, walks):
+    walks = np.ascontiguousarray(walks, dtype=np.int32)
+    c = np.zeros(n, dtype=np.int32)
+    lib().oracle_n2v_vocab(n, walks.size, _p(walks, C.c_int32), _p(c, C.c_int32))
+    return c
+
+
+def unigram_build(counts):
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    U = np.zeros(len(counts)); K = np.zeros(len(counts), dtype=np.int32)
+    lib().oracle_unigram_build(len(counts), _p(counts, C.c_int32), _p(U, C.c_double), _p(K, C.c_int32))
+    return U.astype(np.float32), K
+
+
+def sgns_init(n, d, seed):
+    P = np.empty((n, d), dtype=np.float32); N = np.empty((n, d), dtype=np.float32)
+    lib().oracle_sgns_init(n, d, seed, _p(P, C.c_float), _p(N, C.c_float))
+    return P, N
+
+
+def sgns_train(walks, window, alpha0, epochs, epoch, tokens_total, token_offset, walk_id_offset, UT, KT, seed, flags, SynPos,
+               SynNeg, neg=5):
+    """In place on SynPos/SynNeg (float32 C-contiguous)."""
+    walks = np.ascontiguousarray(walks, dtype=np.int32)
+    n, d = SynPos.shape
+    lib().oracle_sgns_train(n, d, walks.shape[0], walks.shape[1], _p(walks, C.c_int32), window, neg, alpha0, epochs, epoch,
+                            tokens_total, token_offset, walk_id_offset, _p(UT, C.c_float), _p(KT, C.c_int32), seed, flags,
+                            _p(SynPos, C.c_float), _p(SynNeg, C.c_float))
+
+
+def n2v_train(n, src, dst, w, d, walk_len, num_walks, window, epochs, p, q, seed, flags):
+    """Whole pipeline on the CPU, sequential: the meaning of the reference binary for one seed."""
+    row_ptr, col, ww = sorted_csr(n, src, dst, w)
+    uniform = ww is None or all(np.all(ww[row_ptr[v]:row_ptr[v + 1]] == ww[row_ptr[v]]) for v in range(n) if row_ptr[v + 1] > row_ptr[v])
+    U = K = None
+    if not uniform:
+        U, K = n2v_alias_rows(row_ptr, ww)
+    walks = n2v_walks(row_ptr, col, U, K, p, q, num_walks, walk_len, seed, flags)
+    UT, KT = unigram_build(n2v_vocab(n, walks))
+    P, N = sgns_init(n, d, seed)
+    tot = walks.size
+    for ep in range(epochs):
+        sgns_train(walks, window, 0.025, epochs, ep, tot, ep * tot, 0, UT, KT, seed, flags, P, N)
+    return P, walks

@@ -1,0 +1,304 @@
+/*
+ * oracle/n2v_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the node2vec path GEM runs through the prebuilt SNAP binary
+ * gem/c_exe/node2vec (call site gem/embedding/node2vec.py:34-48).  PARITY UNPINNED at
+ * the vector level: the binary seeds its RNG with time() and trains Hogwild over OpenMP
+ * threads, so the reference has no reproducible output; its source is third-party
+ * (snap-stanford/snap, examples/node2vec + snap-adv/{n2v,biasedrandomwalk,word2vec}.cpp,
+ * not vendored, not version pinned -- gem/c_exe/readme.txt:1; ELF banner "Apr 9 2017").
+ * This file restates the published algorithm; constants and the sampling quirks were
+ * checked against the ELF's symbols/disassembly:
+ *   GetNodeAlias      @0x4115f0  Vose alias build, stacks popped from the back
+ *   AliasDrawInt      @0x411360  X=floor(u*N); Y<prob[X] ? X : alias[X]
+ *   SimulateWalk      @0x411a00  first hop UNIFORM, then alias draws; stops at sinks;
+ *                                walks live in a zero-initialised matrix (short walks
+ *                                leave trailing 0 tokens, trained as node 0)
+ *   PreprocessNode    @0x411f40  2nd-order weights w/p (x==t), w (x in N(t)), w/q (else)
+ *   LearnVocab        @0x40d560  token counts
+ *   InitUnigramTable  @0x40e520  count^0.75, Vose in fp64
+ *   RndUnigramInt     @0x40d5f0  X = KTable[floor(u*n)]  (sic: the alias of a random
+ *                                slot, not the slot) ; Y<UTable[X] ? X : KTable[X]
+ *   InitPosEmb        @0x40e270  (U(0,1)-0.5)/d ;  InitNegEmb @0x40e040 zeros
+ *   TrainModel        @0x40d6a0  StartAlpha .025, floor .025e-4, alpha refreshed every
+ *                                10000 words, window shrink b=rand%k, 1+5 targets,
+ *                                sigmoid clamp +-6 (table in the ELF; exact here)
+ * Statistical parity against the real binary is tested in tests/ (MAP of >=3 SNAP runs
+ * in tests/golden/n2v_ref.json).
+ *
+ * Randomness: the reference's TRnd stream is not reproducible, so oracle and device
+ * share a COUNTER-BASED stream (Philox4x32-10, restated below): every draw is a pure
+ * function of (seed, walk, step/position, purpose).  Integer outputs (walks, counts,
+ * alias tables) must match the device bit for bit; embeddings to fp32 tolerance.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------ Philox4x32-10 */
+typedef struct { uint32_t x, y, z, w; } u32x4;
+
+static u32x4 philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u32x4 o = {c0, c1, c2, c3};
+    return o;
+}
+static float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+/* floor(u * n) for u = r / 2^32, exact in integers */
+static uint32_t mulhi_range(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
+
+/* purposes (counter word c3, low byte) */
+enum { TAG_WALK = 1, TAG_WIN = 2, TAG_NEG = 3, TAG_INIT = 4 };
+
+void oracle_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out)
+{
+    u32x4 r = philox(seed, c0, c1, c2, c3);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+/* ---------------------------------------------- start-node permutation (shuffle)
+ * SNAP shuffles the node list before every walk round (NIdsV.Shuffle).  Stateless
+ * stand-in: a 4-round Feistel bijection on 2*hb bits, cycle-walked into [0, n). */
+static uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+uint32_t oracle_perm(uint32_t j, uint32_t n, uint64_t key)
+{
+    uint32_t bits = 1;
+    while (((uint64_t)1 << bits) < n) ++bits;
+    const uint32_t hb = (bits + 1) / 2, mask = (1u << hb) - 1u;
+    do {
+        uint32_t L = j >> hb, R = j & mask;
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t k = (uint32_t)(key >> ((r & 1u) * 32)) + r * 0x9E3779B9u;
+            const uint32_t t = L ^ (fmix32(R + k) & mask);
+            L = R; R = t;
+        }
+        j = (L << hb) | R;
+    } while (j >= n);
+    return j;
+}
+
+/* ----------------------------------------------------------- Vose alias (fp32)
+ * GetNodeAlias: P normalised to sum 1; U[i]=P[i]*N; small/large stacks filled in
+ * index order and popped from the BACK; leftovers get U=1.  K initialised to 0.
+ * `work` is scratch of N ints (small stack grows up from 0, large stack down from N-1). */
+void oracle_alias_build_f32(int32_t N, const float *wts, float *U, int32_t *K, int32_t *work)
+{
+    float sum = 0.0f;
+    for (int32_t i = 0; i < N; ++i) sum += wts[i];
+    int32_t ns = 0, nl = 0;
+    for (int32_t i = 0; i < N; ++i) {
+        K[i] = 0;
+        U[i] = (wts[i] / sum) * (float)N;
+        if (U[i] < 1.0f) work[ns++] = i; else work[N - 1 - nl++] = i;
+    }
+    while (ns > 0 && nl > 0) {
+        const int32_t s = work[--ns];
+        const int32_t l = work[N - nl]; --nl;
+        K[s] = l;
+        U[l] = U[l] + U[s] - 1.0f;
+        if (U[l] < 1.0f) work[ns++] = l; else work[N - 1 - nl++] = l;
+    }
+    while (ns > 0) U[work[--ns]] = 1.0f;
+    while (nl > 0) { U[work[N - nl]] = 1.0f; --nl; }
+}
+
+/* per-row first-order tables over a CSR graph */
+void oracle_n2v_alias_rows(int64_t n, const int64_t *row_ptr, const float *w, float *U, int32_t *K)
+{
+    int64_t maxdeg = 1;
+    for (int64_t v = 0; v < n; ++v)
+        if (row_ptr[v + 1] - row_ptr[v] > maxdeg) maxdeg = row_ptr[v + 1] - row_ptr[v];
+    int32_t *work = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxdeg);
+    for (int64_t v = 0; v < n; ++v) {
+        const int64_t a = row_ptr[v], deg = row_ptr[v + 1] - a;
+        if (deg > 0) oracle_alias_build_f32((int32_t)deg, w + a, U + a, K + a, work);
+    }
+    free(work);
+}
+
+/* ------------------------------------------------------------------- walks
+ * CSR with columns SORTED inside each row (needed for the has_edge(t,x) test).
+ * U/K = first-order alias tables (NULL => all weights in a row equal => uniform pick).
+ * Second order (p,q != 1): rejection sampling -- propose x ~ w(v,.), accept with
+ * a(t,x)/amax, a = 1/p if x==t, 1 if (t->x) is an edge, 1/q otherwise.  Same
+ * distribution as SNAP's per-(t,v) alias tables (PreprocessNode) without their
+ * sum-of-squared-degrees memory.
+ * flags bit0: pad short walks with 0 (SNAP) else -1; bit3: uniform first hop (SNAP). */
+static int has_edge_sorted(const int64_t *row_ptr, const int32_t *col, int32_t t, int32_t x)
+{
+    int64_t lo = row_ptr[t], hi = row_ptr[t + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (col[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo < row_ptr[t + 1] && col[lo] == x;
+}
+
+void oracle_n2v_walks(int64_t n, const int64_t *row_ptr, const int32_t *col, const float *U, const int32_t *K,
+                      float p, float q, int32_t num_walks, int32_t walk_len, uint64_t seed, int32_t flags,
+                      int64_t walk_begin, int64_t walk_end, int32_t *walks /* [(walk_end-walk_begin)][walk_len] */)
+{
+    (void)num_walks;
+    const int32_t pad = (flags & 1) ? 0 : -1;
+    const int second = !(p == 1.0f && q == 1.0f);
+    const float ip = 1.0f / p, iq = 1.0f / q;
+    float amax = 1.0f;
+    if (ip > amax) amax = ip;
+    if (iq > amax) amax = iq;
+    for (int64_t wid = walk_begin; wid < walk_end; ++wid) {
+        int32_t *out = walks + (wid - walk_begin) * walk_len;
+        const uint32_t round = (uint32_t)(wid / n), j = (uint32_t)(wid % n);
+        int32_t cur = (int32_t)oracle_perm(j, (uint32_t)n, seed ^ ((uint64_t)(round + 1) * 0x9E3779B97F4A7C15ull));
+        int32_t prev = -1;
+        int32_t len = 0;
+        out[len++] = cur;
+        while (len < walk_len) {
+            const int64_t a = row_ptr[cur];
+            const uint32_t deg = (uint32_t)(row_ptr[cur + 1] - a);
+            if (deg == 0) break;
+            int32_t nxt = -1;
+            for (uint32_t trial = 0;; ++trial) {
+                const u32x4 r = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)len, TAG_WALK | (trial << 8));
+                uint32_t slot = mulhi_range(r.x, deg);
+                if (U && !(len == 1 && (flags & 8))) {
+                    if (!(u01(r.y) < U[a + slot])) slot = (uint32_t)K[a + slot];
+                }
+                const int32_t x = col[a + slot];
+                if (!second || len == 1) { nxt = x; break; }
+                const float alpha = (x == prev) ? ip : (has_edge_sorted(row_ptr, col, prev, x) ? 1.0f : iq);
+                if (u01(r.z) * amax < alpha || trial >= 4095) { nxt = x; break; }
+            }
+            prev = cur; cur = nxt;
+            out[len++] = cur;
+        }
+        for (; len < walk_len; ++len) out[len] = pad;
+    }
+}
+
+/* LearnVocab: token counts (pad tokens -1 are skipped; SNAP's pad 0 counts as node 0) */
+void oracle_n2v_vocab(int64_t n, int64_t ntokens, const int32_t *walks, int32_t *counts)
+{
+    memset(counts, 0, sizeof(int32_t) * (size_t)n);
+    for (int64_t i = 0; i < ntokens; ++i)
+        if (walks[i] >= 0) ++counts[walks[i]];
+}
+
+/* InitUnigramTable: count^0.75 normalised, Vose in fp64, same stack discipline. */
+void oracle_unigram_build(int64_t n, const int32_t *counts, double *U, int32_t *K)
+{
+    double total = 0.0;
+    for (int64_t i = 0; i < n; ++i) { U[i] = pow((double)counts[i], 0.75); total += U[i]; K[i] = 0; }
+    for (int64_t i = 0; i < n; ++i) U[i] /= total;
+    int32_t *small = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *large = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int64_t ns = 0, nl = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        U[i] = U[i] * (double)n;
+        if (U[i] < 1.0) small[ns++] = (int32_t)i; else large[nl++] = (int32_t)i;
+    }
+    while (ns > 0 && nl > 0) {
+        const int32_t s = small[--ns], l = large[--nl];
+        K[s] = l;
+        U[l] = U[l] + U[s] - 1.0;
+        if (U[l] < 1.0) small[ns++] = l; else large[nl++] = l;
+    }
+    while (ns > 0) U[small[--ns]] = 1.0;
+    while (nl > 0) U[large[--nl]] = 1.0;
+    free(small); free(large);
+}
+
+/* ---------------------------------------------------------------- SGNS (fp32)
+ * TrainModel over walks [0, nwalks) in order, single thread (the sequential meaning of
+ * the reference loop).  SynPos/SynNeg: [n][d] fp32, updated in place.
+ * flags bit0: tokens < 0 are skipped (only when pad=-1); bit1: SNAP's RndUnigramInt quirk.
+ * alpha(t) = alpha0*(1 - t/(epochs*tokens_total+1)), floor alpha0*1e-4, refreshed when
+ * t % 10000 == 0 where t = token_offset + running count  (TrainModel's WordCntAll). */
+static float sgns_alpha(float alpha0, int64_t t, int64_t denom)
+{
+    const int64_t tq = t - (t % 10000);
+    float a = alpha0 * (1.0f - (float)((double)tq / (double)denom));
+    if (a < alpha0 * 0.0001f) a = alpha0 * 0.0001f;
+    return a;
+}
+
+void oracle_sgns_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, int32_t window,
+                       int32_t neg, float alpha0, int32_t epochs, int32_t epoch, int64_t tokens_total,
+                       int64_t token_offset, int64_t walk_id_offset, const float *UT, const int32_t *KT, uint64_t seed,
+                       int32_t flags, float *SynPos, float *SynNeg)
+{
+    float *neu1e = (float *)malloc(sizeof(float) * (size_t)d);
+    const int64_t denom = (int64_t)epochs * tokens_total + 1;
+    for (int64_t wl = 0; wl < nwalks; ++wl) {
+        const int32_t *walk = walks + wl * walk_len;
+        const int64_t wid = walk_id_offset + wl;
+        for (int32_t pos = 0; pos < walk_len; ++pos) {
+            const int64_t t = token_offset + wl * walk_len + pos;
+            const float alpha = sgns_alpha(alpha0, t, denom);
+            const int32_t word = walk[pos];
+            if (word < 0) continue;
+            const u32x4 rw = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos, TAG_WIN | ((uint32_t)epoch << 8));
+            const int32_t b = (int32_t)(rw.x % (uint32_t)window);
+            for (int32_t a = b; a < window * 2 + 1 - b; ++a) {
+                if (a == window) continue;
+                const int32_t cp = pos - window + a;
+                if (cp < 0 || cp >= walk_len) continue;
+                const int32_t ctx = walk[cp];
+                if (ctx < 0) continue;
+                float *xc = SynPos + (size_t)ctx * d;
+                for (int32_t k = 0; k < d; ++k) neu1e[k] = 0.0f;
+                for (int32_t j = 0; j < neg + 1; ++j) {
+                    int32_t target; float label;
+                    if (j == 0) { target = word; label = 1.0f; }
+                    else {
+                        const u32x4 rn = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32),
+                                                (uint32_t)pos | ((uint32_t)a << 16), TAG_NEG | ((uint32_t)epoch << 8) | ((uint32_t)j << 16));
+                        const uint32_t slot = mulhi_range(rn.x, (uint32_t)n);
+                        const int32_t X = (flags & 2) ? KT[slot] : (int32_t)slot;
+                        target = (u01(rn.y) < UT[X]) ? X : KT[X];
+                        if (target == word) continue;
+                        label = 0.0f;
+                    }
+                    float *yt = SynNeg + (size_t)target * d;
+                    float f = 0.0f;
+                    for (int32_t k = 0; k < d; ++k) f += xc[k] * yt[k];
+                    float g;
+                    if (f > 6.0f) g = (label - 1.0f) * alpha;
+                    else if (f < -6.0f) g = label * alpha;
+                    else g = (label - 1.0f + 1.0f / (1.0f + expf(f))) * alpha;
+                    for (int32_t k = 0; k < d; ++k) {
+                        neu1e[k] += g * yt[k];
+                        yt[k] += g * xc[k];
+                    }
+                }
+                for (int32_t k = 0; k < d; ++k) xc[k] += neu1e[k];
+            }
+        }
+    }
+    free(neu1e);
+}
+
+/* InitPosEmb: (U(0,1) - 0.5) / d from the counter stream; InitNegEmb: zeros */
+void oracle_sgns_init(int64_t n, int32_t d, uint64_t seed, float *SynPos, float *SynNeg)
+{
+    const int64_t total = n * (int64_t)d;
+    for (int64_t t = 0; t * 4 < total; ++t) {
+        const u32x4 r = philox(seed, (uint32_t)t, (uint32_t)((uint64_t)t >> 32), 0u, TAG_INIT);
+        const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+        for (int k = 0; k < 4; ++k)
+            if (t * 4 + k < total) SynPos[t * 4 + k] = (u01(v[k]) - 0.5f) / (float)d;
+    }
+    memset(SynNeg, 0, sizeof(float) * (size_t)total);
+}

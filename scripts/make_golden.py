@@ -138,25 +138,30 @@ def main():
     maps['sbm1024_gf_golden'] = ref_map(sbm, mg, tgt)[0]
 
     # ---------------- node2vec: the SNAP ELF, argv of node2vec.py:35-46 ----------------
-    n2v = {'karate_d2': [], 'sbm1024_d128': [], 'sbm1024_d16': []}
+    # The binary shares ONE time-seeded TRnd between its OpenMP threads without locking; with
+    # several threads the racing generator visibly degrades the embedding (SBM-1024 MAP 0.10
+    # vs 0.18 single-threaded).  Both are recorded: *_t1 = OMP_NUM_THREADS=1 (the race-free
+    # meaning of the algorithm, the parity target), *_t8 = 8 threads as GEM runs it by default.
+    n2v = {}
     cwd = os.getcwd()
     tmp = tempfile.mkdtemp()
     os.chdir(tmp)
     try:
         import time
-        for r in range(5):
-            m = node2vec(d=2, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
-            X = quiet(m.learn_embedding, graph=kar, is_weighted=True, no_python=True)
-            n2v['karate_d2'].append(ref_map(kar, m, X)[0])
-            time.sleep(1.1)                       # the ELF seeds with time()
-        for d, key, reps in ((16, 'sbm1024_d16', 3), (128, 'sbm1024_d128', 2)):
-            for r in range(reps):
-                m = node2vec(d=d, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
-                X = quiet(m.learn_embedding, graph=sbm, is_weighted=True, no_python=True)
-                n2v[key].append(ref_map(sbm, m, X)[0])
-                if r == 0:
-                    np.savez_compressed(os.path.join(OUT, 'n2v_snap_%s.npz' % key), X=X.astype(np.float32))
+        for thr in ('1', '8'):
+            os.environ['OMP_NUM_THREADS'] = thr
+            for G, gname, d, reps in ((kar, 'karate', 2, 5), (sbm, 'sbm1024', 16, 3), (sbm, 'sbm1024', 128, 2)):
+                key = '%s_d%d_t%s' % (gname, d, thr)
+                n2v[key] = []
+                for r in range(reps):
+                    m = node2vec(d=d, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
+                    X = quiet(m.learn_embedding, graph=G, is_weighted=True, no_python=True)
+                    n2v[key].append(ref_map(G, m, X)[0])
+                    if r == 0 and gname == 'sbm1024':
+                        np.savez_compressed(os.path.join(OUT, 'n2v_snap_%s.npz' % key), X=X.astype(np.float32))
+                    time.sleep(1.1)                   # the ELF seeds with time()
     finally:
+        os.environ.pop('OMP_NUM_THREADS', None)
         os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)
     mg = node2vec(d=2, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)

@@ -1,0 +1,185 @@
+"""GPU parity tests for node2vec: walks / vocabulary / alias tables bit-exact vs the oracle (integer
+work), SGNS in deterministic mode vs the oracle to fp32 tolerance, Hogwild mode statistically
+(MAP) vs the oracle and vs the real SNAP binary's MAP, properties at BASELINE scale."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+import oracle
+from gem_amd import _hip
+from gem_amd.embedding.node2vec import node2vec
+from gem_amd.evaluation import reconstruction as gr
+from gem_amd.graph import edge_arrays, sbm_graph, to_csr
+from conftest import golden_path
+from test_oracle_n2v import small_graph
+
+pytestmark = pytest.mark.gpu
+SNAP = 11
+
+
+class Dev(object):
+    def __init__(self, n, src, dst, w):
+        self.n = n
+        self.row_ptr, self.col, self.w = to_csr(n, src, dst, w)          # unsorted within rows on purpose: the library sorts
+        self.h = C.c_void_p()
+        _hip.check(_hip.lib().gemhip_n2v_create(n, len(self.col), _hip.ptr(self.row_ptr, C.c_int64), _hip.ptr(self.col, C.c_int32),
+                                                _hip.ptr(self.w, C.c_float), C.byref(self.h)))
+        self.L = _hip.lib()
+
+    def close(self):
+        _hip.check(self.L.gemhip_n2v_destroy(self.h))
+
+    def walks(self, p, q, r, l, seed, flags, lo=0, hi=None):
+        hi = self.n * r if hi is None else hi
+        _hip.check(self.L.gemhip_n2v_walks(self.h, p, q, r, l, seed, flags, lo, hi, None))
+        out = np.empty((hi - lo, l), np.int32)
+        _hip.check(self.L.gemhip_n2v_get_walks(self.h, _hip.ptr(out, C.c_int32)))
+        return out
+
+    def unigram(self):
+        _hip.check(self.L.gemhip_n2v_vocab(self.h, None))
+        c = np.empty(self.n, np.int32); U = np.empty(self.n, np.float32); K = np.empty(self.n, np.int32)
+        _hip.check(self.L.gemhip_n2v_build_unigram(self.h, _hip.ptr(c, C.c_int32), _hip.ptr(U, C.c_float), _hip.ptr(K, C.c_int32)))
+        return c, U, K
+
+    def sgns(self, d, window, epochs, seed, flags, P0=None, N0=None):
+        _hip.check(self.L.gemhip_sgns_init(self.h, d, seed, None, None))
+        if P0 is not None:
+            _hip.check(self.L.gemhip_sgns_set_tables(self.h, _hip.ptr(P0, C.c_float), _hip.ptr(N0, C.c_float)))
+        nw = C.c_int64(); wl = C.c_int32(); p = C.c_void_p()
+        _hip.check(self.L.gemhip_n2v_walks_ptr(self.h, C.byref(p), C.byref(nw), C.byref(wl)))
+        tot = nw.value * wl.value
+        for ep in range(epochs):
+            _hip.check(self.L.gemhip_sgns_train(self.h, window, 5, 0.025, epochs, ep, 0, nw.value, tot, ep * tot, seed, flags, None))
+        P = np.empty((self.n, d), np.float32); N = np.empty((self.n, d), np.float32)
+        _hip.check(self.L.gemhip_sgns_get_tables(self.h, _hip.ptr(P, C.c_float), _hip.ptr(N, C.c_float)))
+        return P, N
+
+
+@pytest.mark.parametrize('p,q,weighted', [(1.0, 1.0, False), (1.0, 1.0, True), (0.25, 4.0, True), (4.0, 0.5, False)])
+def test_walks_and_tables_bit_exact(p, q, weighted):
+    n, src, dst, w = small_graph(weighted, seed=3, n=200, m=3000)
+    dev = Dev(n, src, dst, w)
+    row_ptr, col, ww = oracle.sorted_csr(n, src, dst, w)
+    U = K = None
+    if weighted:
+        U, K = oracle.n2v_alias_rows(row_ptr, ww)
+        _hip.check(dev.L.gemhip_n2v_build_alias(dev.h, None))
+        Ud = np.empty(len(col), np.float32); Kd = np.empty(len(col), np.int32); cd = np.empty(len(col), np.int32)
+        assert dev.L.gemhip_n2v_get_alias(dev.h, _hip.ptr(Ud, C.c_float), _hip.ptr(Kd, C.c_int32), _hip.ptr(cd, C.c_int32)) == 0
+        assert np.array_equal(cd, col) and np.array_equal(Kd, K) and np.array_equal(Ud.view(np.int32), U.view(np.int32))
+    for flags in (SNAP, 0):
+        for l in (80, 13, 1):
+            got = dev.walks(p, q, 3, l, 99, flags)
+            want = oracle.n2v_walks(row_ptr, col, U, K, p, q, 3, l, 99, flags)
+            assert np.array_equal(got, want)
+    got = dev.walks(p, q, 3, 80, 99, SNAP, 150, 411)                     # a rank's shard
+    assert np.array_equal(got, oracle.n2v_walks(row_ptr, col, U, K, p, q, 3, 80, 99, SNAP, 150, 411))
+    c, UT, KT = dev.unigram()
+    assert np.array_equal(c, oracle.n2v_vocab(n, got))
+    UTo, KTo = oracle.unigram_build(c)
+    assert np.array_equal(KT, KTo) and np.array_equal(UT, UTo)
+    dev.close()
+
+
+def test_karate_walks_with_sinks_bit_exact(karate):
+    n, src, dst, w, _ = edge_arrays(karate)
+    dev = Dev(n, src, dst, w)
+    row_ptr, col, _ = oracle.sorted_csr(n, src, dst, w)
+    for flags in (SNAP, 8):
+        assert np.array_equal(dev.walks(1.0, 1.0, 10, 80, 5, flags), oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, 10, 80, 5, flags))
+    dev.close()
+
+
+@pytest.mark.parametrize('gname,d,window,l,epochs,flags', [('karate', 2, 10, 80, 1, SNAP), ('karate', 8, 3, 20, 2, 8),
+                                                           ('sbm1024', 16, 10, 40, 1, SNAP), ('sbm1024', 128, 5, 24, 1, SNAP),
+                                                           ('karate', 7, 4, 30, 1, SNAP), ('karate', 256, 2, 10, 1, SNAP)])
+def test_sgns_deterministic_matches_oracle(gname, d, window, l, epochs, flags, request):
+    """flags|4: one wavefront walks the corpus in order == TrainModel single-threaded.  karate (n=34)
+    makes the same row come up as context/negative constantly, exercising the in-wave RAW paths."""
+    G = request.getfixturevalue(gname)
+    n, src, dst, w, _ = edge_arrays(G)
+    dev = Dev(n, src, dst, w)
+    r = 10 if gname == 'karate' else 1
+    walks = dev.walks(1.0, 1.0, r, l, 21, flags)
+    if gname == 'sbm1024':
+        walks = walks[:96]
+        _hip.check(dev.L.gemhip_n2v_set_walks(dev.h, _hip.ptr(walks, C.c_int32), walks.shape[0], l, 0))
+    c, UT, KT = dev.unigram()
+    P, N = dev.sgns(d, window, epochs, 21, flags | 4)
+    Po, No = oracle.sgns_init(n, d, 21)
+    tot = walks.size
+    for ep in range(epochs):
+        oracle.sgns_train(walks, window, 0.025, epochs, ep, tot, ep * tot, 0, UT, KT, 21, flags, Po, No)
+    for got, want in ((P, Po), (N, No)):
+        scale = float(np.abs(want).max())
+        assert float(np.abs(got - want).max()) <= 2e-4 * scale + 1e-6, (np.abs(got - want).max(), scale)
+    dev.close()
+
+
+def test_init_tables_bit_exact():
+    n, src, dst, w = small_graph(False, n=50, m=300)
+    dev = Dev(n, src, dst, w)
+    dev.walks(1.0, 1.0, 1, 8, 1, SNAP); dev.unigram()
+    _hip.check(dev.L.gemhip_sgns_init(dev.h, 24, 5, None, None))
+    P = np.empty((n, 24), np.float32); N = np.empty((n, 24), np.float32)
+    _hip.check(dev.L.gemhip_sgns_get_tables(dev.h, _hip.ptr(P, C.c_float), _hip.ptr(N, C.c_float)))
+    Po, No = oracle.sgns_init(n, 24, 5)
+    assert np.array_equal(P, Po) and np.array_equal(N, No)
+    dev.close()
+
+
+def test_hogwild_map_parity_with_oracle_and_snap(karate, sbm1024):
+    """The production (parallel) mode through the plugin API: MAP within 3% of the sequential
+    oracle's and of the real binary run race-free (n2v_ref.json *_t1); never below the racy 8-thread binary."""
+    ref = json.load(open(golden_path('n2v_ref.json')))
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    maps = []
+    for seed in (1, 2, 3):
+        m = node2vec(d=16, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, seed=seed)
+        Y = m.learn_embedding(graph=sbm1024, edge_f=None, is_weighted=True, no_python=True)
+        assert Y.shape == (n, 16) and Y.dtype == np.float64 and np.isfinite(Y).all()
+        maps.append(gr.evaluateStaticGraphReconstruction(sbm1024, m, Y, None)[0])
+    t1 = np.mean(ref['sbm1024_d16_t1'])
+    assert abs(np.mean(maps) - t1) <= 0.03 * t1, (maps, ref['sbm1024_d16_t1'])
+    assert np.mean(maps) > np.mean(ref['sbm1024_d16_t8'])
+    m = node2vec(d=128, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, seed=4)
+    Y = m.learn_embedding(graph=sbm1024, is_weighted=True, no_python=True)
+    M = gr.evaluateStaticGraphReconstruction(sbm1024, m, Y, None)[0]
+    t1 = np.mean(ref['sbm1024_d128_t1'])
+    assert abs(M - t1) <= 0.03 * t1, (M, ref['sbm1024_d128_t1'])
+    # karate: reference acceptance test (tests/test_karate.py:57-60,78) + MAP inside the binary's observed band
+    tgt = np.loadtxt(golden_path('ref_karate_node2vec.txt'))
+    maps = []
+    for seed in range(6):
+        m = node2vec(d=2, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, seed=seed)
+        Y = m.learn_embedding(graph=karate, is_weighted=True, no_python=True)
+        assert abs(np.mean(tgt - Y)) < 0.3
+        maps.append(gr.evaluateStaticGraphReconstruction(karate, m, Y, None)[0])
+    band = ref['karate_d2_t1'] + ref['karate_d2_t8']
+    assert min(band) - 0.1 <= np.mean(maps) <= max(band) + 0.1, maps
+
+
+def test_baseline_scale_properties():
+    """SBM 100k/1M (a tenth of BASELINE configs[3]; the full size runs in bench.py): walk validity,
+    shard == slice, vocabulary conservation, finite bounded embeddings."""
+    g = sbm_graph(100000, 1000000, 32, seed=20260926)
+    n, src, dst, w, _ = edge_arrays(g)
+    dev = Dev(n, src, dst, w)
+    walks = dev.walks(1.0, 1.0, 2, 80, 7, SNAP)
+    assert walks.shape == (2 * n, 80) and walks.min() >= 0 and walks.max() < n
+    assert np.array_equal(np.sort(walks[:n, 0]), np.arange(n)) and np.array_equal(np.sort(walks[n:, 0]), np.arange(n))
+    key = set((src.astype(np.int64) * n + dst).tolist())
+    sel = walks[::997]
+    pairs = sel[:, :-1].astype(np.int64) * n + sel[:, 1:]
+    assert all(int(k) in key for k in pairs.ravel())                      # every hop is an edge (no sinks in this graph)
+    c, UT, KT = dev.unigram()
+    assert c.sum() == walks.size
+    part = dev.walks(1.0, 1.0, 2, 80, 7, SNAP, 50000, 50000 + 4096)
+    assert np.array_equal(part, walks[50000:50000 + 4096])
+    dev.walks(1.0, 1.0, 2, 80, 7, SNAP); dev.unigram()
+    P, N = dev.sgns(128, 10, 1, 7, SNAP)
+    assert np.isfinite(P).all() and np.isfinite(N).all() and 0.05 < np.abs(P).max() < 50
+    dev.close()
