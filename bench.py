@@ -1,26 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the gem_amd hot path (see DESIGN.md "Measurement").
+"""bench.py -- headline benchmark of the gem_amd hot path (DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gf|node2vec|hope]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload node2vec|gf|hope]
 
-One JSON line on stdout (rank 0).  A "step" is one pass of the hot path over the
-synthetic graph that is already resident in HBM:
-    gf        one SGD sweep over all edges of SBM(1M nodes, 10M edges), d=128
-For N>1 launch with torch.distributed.run (one rank per GPU, RCCL): the path is sharded
-by SOURCE NODE and the only collective is the all-gather of the owned row
-blocks of the embedding table after each sweep.
+One JSON line on stdout (rank 0).  A "step" is one pass of the hot path over a synthetic graph
+that is already resident in HBM when the timed region starts:
+    node2vec  one full node2vec.learn_embedding on SBM(1M nodes, 10M edges): walks (r=10, l=80,
+              p=q=1) + vocabulary + unigram table + SGNS (k=10, 5 negatives, 1 epoch), d=128.
+              BASELINE.json quotes its metric on this graph (configs[3]); edges/sec =
+              graph.number_of_edges() / wall of the pass.
+    gf        one SGD sweep over all edges of the same SBM, d=128; edges/sec = edges x sweeps / wall.
+For N>1 launch with torch.distributed.run (one rank per GPU, RCCL).  Both paths shard by SOURCE /
+START NODE (gem_amd/multi_gpu.py): total work is fixed => "scaling": "strong".
 
-`roofline.achieved` = algorithmic bytes per launch (3*4d+12 = 1548 B per
-edge-update at d=128, times the updates one launch performs) / average launch duration,
-measured here with HIP events on the launch stream.  `cpu_baseline` times the CPU oracle
-port (gf.cpp:152-164 restated in C, single thread -- the reference loop is single threaded)
-on a bounded number of sweeps of the same graph on this box's host cores.
+`roofline`: for the dominant kernel, algorithmic bytes per launch (SURVEY 8d per-unit figure x units
+the launch processes) / average launch duration measured with HIP events on the launch stream.
+`cpu_baseline`: the reference CPU path timed on this box's host cores on a bounded sample.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,70 +33,62 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from gem_amd import _hip
-from gem_amd.graph import sbm_graph, edge_arrays
+from gem_amd import _hip, multi_gpu
+from gem_amd.graph import sbm_graph, edge_arrays, to_csr
 
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-class GFWorkload(object):
-    """BASELINE metric on the 1M-node SBM: edges/sec for Graph Factorization, d=128."""
-    name = 'sbm1m_10m_gf_d128'
-    metric = 'edges/sec'
-    unit = 'edges/s'
-    dtype = 'f32'
-    kernel = 'gf_sweep_kernel'
+def make_graph(args):
+    t = time.time()
+    g = sbm_graph(args.nodes, args.edges, args.blocks, seed=20260923 + 4)
+    log('SBM graph: %d nodes, %d directed edges, %d blocks (%.1fs)' % (g.n, g.number_of_edges(), args.blocks, time.time() - t))
+    return g
 
-    def __init__(self, args, rank, world):
-        self.rank, self.world = rank, world
-        self.n, self.m_target, self.blocks, self.d = args.nodes, args.edges, args.blocks, args.d
-        self.eta, self.regu = 1e-2, 1e-2      # "trainable" setting (SURVEY 8d); arithmetic per edge is identical
-        t = time.time()
-        g = sbm_graph(self.n, self.m_target, self.blocks, seed=20260923 + 4)
+
+class GFWorkload(object):
+    metric, unit, dtype, kernel = 'edges/sec', 'edges/s', 'f32', 'gf_sweep_kernel'
+    default_steps, default_warmup = 50, 5
+
+    def __init__(self, args, rank, world, comm):
+        self.name = 'sbm%dk_%dk_gf_d%d' % (args.nodes // 1000, args.edges // 1000, args.d)
+        self.world, self.d = world, args.d
+        self.eta, self.regu = 1e-2, 1e-2      # "trainable" setting; arithmetic per edge identical to run_sbm.py's
+        g = make_graph(args)
         self.n_edges = g.number_of_edges()
         n, src, dst, w, _ = edge_arrays(g)
         self.graph = (n, src, dst, w)
-        # pad n so every rank owns an equal contiguous block of source rows
-        self.n_pad = (n + world - 1) // world * world
-        self.r0 = rank * (self.n_pad // world)
-        self.r1 = min(self.r0 + self.n_pad // world, n)
-        L = _hip.lib()
-        self.plan = C.c_void_p()
-        _hip.check(L.gemhip_gf_plan_create(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, self.d,
-                                           self.r0, max(self.r1, self.r0), C.byref(self.plan)))
-        info = (C.c_int64 * 8)()
-        _hip.check(L.gemhip_gf_plan_info(self.plan, info))
-        self.updates, self.rows, self.levels = info[0], info[1], info[2]
-        self.algo_bytes = info[5]
         dev = torch.device('cuda', torch.cuda.current_device())
-        gen = torch.Generator(device=dev); gen.manual_seed(1234)
-        self.Xa = (0.01 * torch.randn(self.n_pad, self.d, device=dev, generator=gen, dtype=torch.float32)).contiguous()
-        self.Xb = self.Xa.clone()
-        self.X = [self.Xa, self.Xb]
-        _hip.check(L.gemhip_gf_plan_bind(self.plan, C.c_void_p(self.Xa.data_ptr()), C.c_void_p(self.Xb.data_ptr())))
-        self.cur = 0
-        self.L = L
-        log('[rank %d] graph %d nodes %d edges, plan rows %d updates %d levels %d (setup %.1fs)' %
-            (rank, n, self.n_edges, self.rows, self.updates, self.levels, time.time() - t))
+        n_pad = (n + world - 1) // world * world
+        gen = torch.Generator(device=dev); gen.manual_seed(1234)          # same init on every rank
+        Xa = (0.01 * torch.randn(n_pad, self.d, device=dev, generator=gen, dtype=torch.float32)).contiguous()
+        Xb = Xa.clone()
+        r0, r1 = rank * (n_pad // world), min((rank + 1) * (n_pad // world), n)
+        self.b = multi_gpu.HipBackendGF(n, src, dst, None, self.d, r0, r1, Xa, Xb)
+        self.job = multi_gpu.GFSharded(self.b, comm, rank, world, n)
+        self.kernel_ms, self.launches = 0.0, 0
+        log('[rank %d] GF plan: rows %d updates %d levels %d' % (rank, self.b.rows, self.b.updates, self.b.levels))
 
     def step(self):
-        s = torch.cuda.current_stream().cuda_stream
-        _hip.check(self.L.gemhip_gf_plan_sweeps(self.plan, 1, self.eta, self.regu, C.c_void_p(s)))
-        self.cur ^= 1
-        if self.world > 1:
-            new = self.X[self.cur]
-            own = new[self.r0:self.r0 + self.n_pad // self.world].clone()
-            dist.all_gather_into_tensor(new, own)
+        self.last = self.job.sweep(self.eta, self.regu)
 
     def units_per_step(self):
-        return self.n_edges            # graph.number_of_edges() per sweep (SURVEY 8d)
+        return self.n_edges
 
-    def kernel_launches_per_step(self):
-        return self.levels
+    def roofline(self, dev_ms_total, steps):
+        launches = steps * self.b.levels
+        avg_s = dev_ms_total * 1e-3 / launches
+        algo = self.b.algo_bytes / self.b.levels        # 1548 B x updates
+        compulsory = (self.b.rows * 2 * 4 * self.d + self.b.updates * (4 * self.d + 8)) / self.b.levels
+        ach = algo / avg_s / 1e9
+        return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                'traffic': None, 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
+                'note': 'algorithmic = 1548 B/update (X_i r+w, X_j r per update); the kernel keeps X_i in registers for a whole row, '
+                        'so its compulsory HBM bytes are %.3g per launch = %.0f GB/s' % (compulsory, compulsory / avg_s / 1e9)}
 
     def cpu_baseline(self, budget_s=15.0):
         import oracle
@@ -103,14 +98,102 @@ class GFWorkload(object):
         sweeps = max(1, min(20, int(budget_s / max(one, 1e-3))))
         t = time.time(); oracle.gf_train_f32(n, src, dst, w, self.d, self.eta, self.regu, sweeps, X0); el = time.time() - t
         return {'value': self.n_edges * sweeps / el, 'unit': self.unit, 'cores': 1, 'kind': 'port',
-                'sample': '%d sweeps of the same %d-edge graph, oracle/gf_oracle.c (gf.cpp:152-164), 1 thread' % (sweeps, self.n_edges)}
+                'sample': '%d sweeps of the same %d-edge graph, oracle/gf_oracle.c (gf.cpp:152-164 restated; the reference loop is '
+                          'single-threaded)' % (sweeps, self.n_edges)}
 
     def check(self):
-        x = self.X[self.cur]
-        assert bool(torch.isfinite(x).all()), 'non-finite embedding'
+        assert bool(torch.isfinite(self.last).all()), 'non-finite embedding'
 
 
-WORKLOADS = {'gf': GFWorkload}
+class N2VWorkload(object):
+    metric, unit, dtype, kernel = 'edges/sec', 'edges/s', 'f32', 'sgns_kernel'
+    default_steps, default_warmup = 2, 1
+
+    def __init__(self, args, rank, world, comm):
+        self.name = 'sbm%dk_%dk_node2vec_d%d_r%d_l%d_k%d' % (args.nodes // 1000, args.edges // 1000, args.d, args.num_walks,
+                                                            args.walk_len, args.window)
+        self.args, self.rank, self.world = args, rank, world
+        g = make_graph(args)
+        self.g = g
+        self.n_edges = g.number_of_edges()
+        n, src, dst, w, _ = edge_arrays(g)
+        row_ptr, col, ww = to_csr(n, src, dst, w)
+        self.b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, args.d)
+        self.job = multi_gpu.Node2VecSharded(self.b, comm, rank, world, n, args.num_walks, args.walk_len, args.window, 1,
+                                             seed=20260923, flags=_hip.N2V_SNAP_COMPAT, sync_chunks=args.sync_chunks)
+        self.sgns_ms, self.sgns_launches, self.pairs = 0.0, 0, 0
+        self._orig_train = self.b.train
+        self.b.train = self._timed_train
+        self.evs = []
+
+    def _timed_train(self, *a):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); self._orig_train(*a); e1.record()
+        self.evs.append((e0, e1))
+
+    def reset_counters(self):
+        torch.cuda.synchronize()
+        self.evs = []
+        self.b.pairs(reset=True)
+
+    def step(self):
+        self.P = self.job.run(1.0, 1.0)
+
+    def units_per_step(self):
+        return self.n_edges
+
+    def roofline(self, dev_ms_total, steps):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.evs)
+        launches = len(self.evs)
+        pairs = self.b.pairs(reset=False)
+        avg_s = ms * 1e-3 / launches
+        algo = (14 * 4 * self.args.d + 24) * pairs / launches       # 14*4d B per (centre,context) pair + ids
+        ach = algo / avg_s / 1e9
+        tokens = (self.job.hi - self.job.lo) * self.args.walk_len
+        return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                'traffic': None, 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
+                'pairs_per_launch': pairs / launches, 'tokens_per_launch': tokens,
+                'sgns_fraction_of_step': ms / dev_ms_total,
+                'note': 'algorithmic = 7168+24 B per (centre,context) pair at d=128 (SynPos r+w, 6 x SynNeg r+w); the kernel keeps the '
+                        'positive SynNeg row in registers across a centre\'s contexts (12/14 of that reaches memory)'}
+
+    def cpu_baseline(self, budget_s=25.0):
+        """The real reference binary (oracle/_ref/node2vec = gem/c_exe/node2vec) on a bounded sample: a
+        2^14-node SBM of the same density and block size, same r/l/k/d, all host cores (how GEM runs it).
+        SGNS cost is linear in tokens, so edges/s carries over (tokens/edge identical)."""
+        import oracle
+        from gem_amd.utils import graph_util
+        a = self.args
+        n_s = 16384
+        gs = sbm_graph(n_s, n_s * (a.edges // a.nodes), max(1, n_s // (a.nodes // a.blocks)), seed=7)
+        cores = os.cpu_count() or 1
+        if os.path.exists(oracle.REF_N2V):
+            tmp = tempfile.mkdtemp()
+            gf = os.path.join(tmp, 'g.graph')
+            with open(gf, 'w') as fh:
+                fh.writelines('%d %d %f\n' % (i, j, 1.0) for i, j in zip(gs.src.tolist(), gs.dst.tolist()))
+            t = time.time()
+            subprocess.call([oracle.REF_N2V, '-i:' + gf, '-o:' + os.path.join(tmp, 'g.emb'), '-d:%d' % a.d, '-l:%d' % a.walk_len,
+                             '-r:%d' % a.num_walks, '-k:%d' % a.window, '-e:1', '-p:1.000000', '-q:1.000000', '-dr', '-w'],
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS=str(cores)))
+            el = time.time() - t
+            return {'value': gs.number_of_edges() / el, 'unit': self.unit, 'cores': cores, 'kind': 'reference',
+                    'sample': 'gem/c_exe/node2vec (SNAP ELF) end to end incl. its text IO on an SBM with %d nodes / %d edges (same '
+                              'density, block size, d, r, l, k), %.1fs' % (n_s, gs.number_of_edges(), el)}
+        n, src, dst, w, _ = edge_arrays(gs)
+        t = time.time()
+        oracle.n2v_train(n, src, dst, None, a.d, a.walk_len, 1, a.window, 1, 1.0, 1.0, 1, 11)
+        el = (time.time() - t) * a.num_walks
+        return {'value': gs.number_of_edges() / el, 'unit': self.unit, 'cores': 1, 'kind': 'port',
+                'sample': 'oracle/n2v_oracle.c, r=1 timed and scaled x%d (linear in tokens), SBM %d nodes' % (a.num_walks, n_s)}
+
+    def check(self):
+        assert bool(torch.isfinite(self.P).all()), 'non-finite embedding'
+        assert float(self.P.abs().max()) > 1e-3
+
+
+WORKLOADS = {'gf': GFWorkload, 'node2vec': N2VWorkload}
 
 
 def main():
@@ -118,11 +201,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--workload', default=os.environ.get('GEM_BENCH_WORKLOAD', 'gf'), choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default=os.environ.get('GEM_BENCH_WORKLOAD', 'node2vec'), choices=sorted(WORKLOADS))
     ap.add_argument('--nodes', type=int, default=1000000)
     ap.add_argument('--edges', type=int, default=10000000)
     ap.add_argument('--blocks', type=int, default=100)
     ap.add_argument('--d', type=int, default=128)
+    ap.add_argument('--num-walks', type=int, default=10)
+    ap.add_argument('--walk-len', type=int, default=80)
+    ap.add_argument('--window', type=int, default=10)
+    ap.add_argument('--sync-chunks', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -130,7 +217,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)')
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
     torch.cuda.set_device(local)
     _hip.check(_hip.lib().gemhip_set_device(local))
     if world > 1:
@@ -139,9 +226,10 @@ def main():
     if args.gpus != world and rank == 0:
         log('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world))
 
-    wl = WORKLOADS[args.workload](args, rank, world)
-    K = args.steps if args.steps is not None else 50
-    W = args.warmup if args.warmup is not None else 5
+    comm = multi_gpu.TorchComm(world)
+    wl = WORKLOADS[args.workload](args, rank, world, comm)
+    K = args.steps if args.steps is not None else wl.default_steps
+    W = args.warmup if args.warmup is not None else wl.default_warmup
 
     def barrier():
         if world > 1:
@@ -151,6 +239,8 @@ def main():
     for _ in range(W):
         wl.step()
     barrier()
+    if hasattr(wl, 'reset_counters'):
+        wl.reset_counters()
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -167,22 +257,15 @@ def main():
     el = float(t.item())
 
     if rank == 0:
-        value = wl.units_per_step() * K / el
-        launches = K * wl.kernel_launches_per_step()
         out = {
-            'metric': wl.metric, 'value': value, 'unit': wl.unit, 'n_gpus': world, 'steps': K, 'warmup': W,
+            'metric': wl.metric, 'value': wl.units_per_step() * K / el, 'unit': wl.unit, 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': el * 1e3 / K, 'higher_is_better': True, 'scaling': 'strong' if world > 1 else 'weak',
             'vs_baseline': None, 'dtype': wl.dtype, 'data': 'synthetic',
             'config': {'workload': wl.name, 'nodes': args.nodes, 'directed_edges': wl.n_edges, 'd': args.d,
                        'sharding': 'source-node x%d' % world},
         }
         if world == 1:
-            avg_launch_s = dev_ms * 1e-3 / launches
-            achieved = wl.algo_bytes / wl.kernel_launches_per_step() / avg_launch_s / 1e9
-            out['roofline'] = {'bound': 'hbm', 'kernel': wl.kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                               'algorithmic_bytes_per_launch': wl.algo_bytes / wl.kernel_launches_per_step(),
-                               'avg_launch_us': avg_launch_s * 1e6}
+            out['roofline'] = wl.roofline(dev_ms, K)
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -26,6 +26,7 @@ namespace {
 enum { TAG_WALK = 1, TAG_WIN = 2, TAG_NEG = 3, TAG_INIT = 4 };
 constexpr int SGNS_NEG = 5;             // SNAP: NegSamN = 5 (compile-time constant there too)
 constexpr float SGNS_MAX_EXP = 6.0f;    // SNAP: MaxExp
+constexpr int HOGWILD_ROWS_PER_WAVE = 128;
 
 __host__ __device__ __forceinline__ uint32_t mulhi_range(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
 
@@ -77,6 +78,9 @@ struct gemhip_n2v {
     int32_t d = 0;
     float *SynPos = nullptr, *SynNeg = nullptr;
     bool own_syn = false;
+    int32_t max_waves = 0;            // 0 = auto (see gemhip_sgns_train)
+    unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
+    bool own_counts = true;
 };
 
 namespace {
@@ -215,15 +219,27 @@ __global__ void sgns_init_kernel(float *SynPos, float *SynNeg, int64_t total, in
         }
 }
 
+// Embedding rows are shared, concurrently updated state (Hogwild).  gfx950 has one L1 per CU that is
+// never refreshed by other CUs' stores and one write-back L2 per XCD that is not coherent with the
+// other seven, so PLAIN loads/stores let every CU train on its own stale copy of the table (measured:
+// SBM-1024 MAP 0.177 on one CU -> 0.09 on many).  All row traffic therefore uses relaxed AGENT-scope
+// atomic accesses (global_load/store ... sc1): they bypass L1, are coherent across XCDs per location,
+// and cost the same bytes.  8 bytes per lane when d is even, 4 otherwise.
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gu32 = __attribute__((address_space(1))) unsigned int;
+
 template <int VEC>
 __device__ __forceinline__ void ld_row(const float *p, int d, int lane, int c, float (&v)[VEC])
 {
     const int idx = (c * WAVE + lane) * VEC;
     if constexpr (VEC == 2) {
-        if (idx < d) { const float2 t = *reinterpret_cast<const float2 *>(p + idx); v[0] = t.x; v[1] = t.y; }
-        else { v[0] = 0.f; v[1] = 0.f; }
+        if (idx < d) {
+            const unsigned long long t = __hip_atomic_load((gu64 *)(p + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[0] = __builtin_bit_cast(float, (unsigned int)t);
+            v[1] = __builtin_bit_cast(float, (unsigned int)(t >> 32));
+        } else { v[0] = 0.f; v[1] = 0.f; }
     } else {
-        v[0] = idx < d ? p[idx] : 0.f;
+        v[0] = idx < d ? __builtin_bit_cast(float, __hip_atomic_load((gu32 *)(p + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
     }
 }
 template <int VEC>
@@ -231,8 +247,13 @@ __device__ __forceinline__ void st_row(float *p, int d, int lane, int c, const f
 {
     const int idx = (c * WAVE + lane) * VEC;
     if (idx < d) {
-        if constexpr (VEC == 2) *reinterpret_cast<float2 *>(p + idx) = make_float2(v[0], v[1]);
-        else p[idx] = v[0];
+        if constexpr (VEC == 2) {
+            const unsigned long long t = (unsigned long long)__builtin_bit_cast(unsigned int, v[0]) |
+                                         ((unsigned long long)__builtin_bit_cast(unsigned int, v[1]) << 32);
+            __hip_atomic_store((gu64 *)(p + idx), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store((gu32 *)(p + idx), __builtin_bit_cast(unsigned int, v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -240,7 +261,7 @@ struct SgnsArgs {
     const int32_t *walks; int64_t walk_lo, walk_hi; int32_t walk_len; int32_t window;
     float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
     const float *UT; const int32_t *KT; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
-    float *SynPos; float *SynNeg; int32_t nwaves;
+    float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs;
 };
 
 // gradient scale of TrainModel: (label - sigma(f)) * alpha with the +-MaxExp clamps
@@ -271,6 +292,7 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
     const int win = A.window;
     const bool quirk = (A.flags & 2) != 0;
 
+    unsigned long long npairs = 0;
     for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
         const int32_t *walk = A.walks + wl * A.walk_len;
         for (int k = lane; k < A.walk_len; k += WAVE) tok[k] = walk[k];
@@ -314,6 +336,7 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
                 const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[cp]);
                 if (ctx < 0) continue;
                 const int ai = a < win ? a : a - 1;
+                ++npairs;
                 int32_t tgt[SGNS_NEG];
 #pragma unroll
                 for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readfirstlane(negs[ai * SGNS_NEG + j]);
@@ -383,6 +406,7 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
 }
 
 using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
@@ -461,6 +485,8 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
         if (e == hipSuccess) e = hipMemcpy(h->d_w, ww.data(), nnz * sizeof(float), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_counts, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_pairs, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_pairs, 0, sizeof(unsigned long long));
     if (e != hipSuccess) { gemhip_n2v_destroy(h); return fail(GEMHIP_E_HIP, "n2v_create: device upload failed: %s", hipGetErrorString(e)); }
     *out = h;
     return GEMHIP_OK;
@@ -470,7 +496,8 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
 {
     if (!h) return GEMHIP_OK;
     hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks);
-    hipFree(h->d_counts); hipFree(h->d_UT); hipFree(h->d_KT);
+    if (h->own_counts) hipFree(h->d_counts);
+    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_pairs);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
     delete h;
     return GEMHIP_OK;
@@ -587,6 +614,25 @@ extern "C" int gemhip_n2v_vocab(gemhip_n2v_t h, void *stream)
     return GEMHIP_OK;
 }
 
+extern "C" int gemhip_n2v_bind_counts(gemhip_n2v_t h, void *d_counts)
+{
+    GEMHIP_REQUIRE(h && d_counts, "n2v_bind_counts: NULL argument");
+    if (h->own_counts) hipFree(h->d_counts);
+    h->d_counts = (int32_t *)d_counts; h->own_counts = false; h->unigram_ready = false;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_pairs(gemhip_n2v_t h, int64_t *pairs, int32_t reset)
+{
+    GEMHIP_REQUIRE(h && pairs, "sgns_pairs: NULL argument");
+    GEMHIP_CHECK(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    GEMHIP_CHECK(hipMemcpy(&v, h->d_pairs, sizeof v, hipMemcpyDeviceToHost));
+    if (reset) GEMHIP_CHECK(hipMemset(h->d_pairs, 0, sizeof v));
+    *pairs = (int64_t)v;
+    return GEMHIP_OK;
+}
+
 extern "C" int gemhip_n2v_counts_ptr(gemhip_n2v_t h, void **d_counts)
 {
     GEMHIP_REQUIRE(h && d_counts, "n2v_counts_ptr: NULL argument");
@@ -655,6 +701,13 @@ extern "C" int gemhip_sgns_init(gemhip_n2v_t h, int32_t d, uint64_t seed, void *
     return GEMHIP_OK;
 }
 
+extern "C" int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves)
+{
+    GEMHIP_REQUIRE(h && max_waves >= 0, "n2v_set_max_waves: bad arguments");
+    h->max_waves = max_waves;
+    return GEMHIP_OK;
+}
+
 extern "C" int gemhip_sgns_set_tables(gemhip_n2v_t h, const float *SynPos_host, const float *SynNeg_host)
 {
     GEMHIP_REQUIRE(h && h->SynPos && SynPos_host && SynNeg_host, "sgns_set_tables: bad arguments (call sgns_init first)");
@@ -692,16 +745,23 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     // the kernel computes t = token_offset + wl*walk_len + pos with wl the LOCAL walk index
     A.token_offset = token_offset; A.walk_id_offset = h->walk_id_offset; A.epoch = epoch;
     A.UT = h->d_UT; A.KT = h->d_KT; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
-    A.SynPos = h->SynPos; A.SynNeg = h->SynNeg;
+    A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     const bool deterministic = (flags & 4) != 0;
     const size_t per_wave = (size_t)(h->walk_len + 2 * window * SGNS_NEG) * sizeof(int32_t);
     int blocks, threads;
     if (deterministic) { blocks = 1; threads = 64; A.nwaves = 1; }
     else {
         threads = 256;
-        const int64_t want = (walk_hi - walk_lo + 3) / 4;
-        blocks = (int)std::min<int64_t>(want, 256 * 8);          // 256 CUs x 8 blocks of 4 waves = 32 waves per CU
-        A.nwaves = blocks * 4;
+        // Hogwild concurrency.  Each in-flight wavefront has ~7 embedding rows open (read-modify-write) at any
+        // time; when (waves x 7) approaches n, concurrent writers overwrite each other's updates and the
+        // embedding degrades (measured: tests/test_n2v_gpu.py).  Cap the number of concurrent
+        // wavefronts at n/HOGWILD_ROWS_PER_WAVE; at BASELINE scale (n >= 1M) the cap is the machine
+        // (256 CUs x 32 waves) and never binds.
+        int64_t cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / HOGWILD_ROWS_PER_WAVE);
+        cap = std::min<int64_t>(cap, 256 * 32);
+        const int64_t waves = std::min<int64_t>(cap, walk_hi - walk_lo);
+        blocks = (int)((waves + 3) / 4);
+        A.nwaves = (int32_t)waves;
     }
     const size_t lds = per_wave * (threads / 64);
     GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window too large for LDS staging (%zu bytes)", lds);

@@ -160,10 +160,18 @@ int gemhip_n2v_walks_ptr(gemhip_n2v_t h, void **d_walks, int64_t *nwalks, int32_
  * it so a multi-GPU driver can all-reduce it), then InitUnigramTable on the host. */
 int gemhip_n2v_vocab(gemhip_n2v_t h, void *stream);
 int gemhip_n2v_counts_ptr(gemhip_n2v_t h, void **d_counts);
+/* Use a caller-owned DEVICE int32[n] as the count buffer (e.g. a torch tensor to all-reduce). */
+int gemhip_n2v_bind_counts(gemhip_n2v_t h, void *d_counts);
 int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, float *UT_out, int32_t *KT_out);
 /* InitPosEmb / InitNegEmb.  dSynPos/dSynNeg: optional caller-owned DEVICE tables
  * [n][d] float32 (both or neither). */
 int gemhip_sgns_init(gemhip_n2v_t h, int32_t d, uint64_t seed, void *dSynPos, void *dSynNeg);
+/* (centre, context) pairs trained since creation / the last reset -- the unit of SURVEY 8(d)'s
+ * SGNS byte count (14*4d bytes per pair). */
+int gemhip_sgns_pairs(gemhip_n2v_t h, int64_t *pairs, int32_t reset);
+/* Cap on concurrently training wavefronts (Hogwild width).  0 = auto: min(machine, n/128),
+ * which keeps lost updates negligible on small graphs and never binds at n >= 1M. */
+int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves);
 int gemhip_sgns_set_tables(gemhip_n2v_t h, const float *SynPos_host, const float *SynNeg_host);
 int gemhip_sgns_get_tables(gemhip_n2v_t h, float *SynPos_host, float *SynNeg_host);
 /* TrainModel over LOCAL walks [walk_lo, walk_hi) for epoch `epoch` of `epochs`.
