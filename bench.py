@@ -193,7 +193,66 @@ class N2VWorkload(object):
         assert float(self.P.abs().max()) > 1e-3
 
 
-WORKLOADS = {'gf': GFWorkload, 'node2vec': N2VWorkload}
+class HopeWorkload(object):
+    """BASELINE configs[2]: SBM 100k nodes / 1M edges, HOPE d=128 (k=64), beta=0.01; embeddings/sec = n / wall."""
+    metric, unit, dtype, kernel = 'embeddings/sec', 'embeddings/s', 'f32', 'hope_spmm_kernel'
+    default_steps, default_warmup = 5, 1
+
+    def __init__(self, args, rank, world, comm):
+        if args.nodes == 1000000 and args.edges == 10000000:
+            args.nodes, args.edges, args.blocks = 100000, 1000000, 32
+        self.name = 'sbm%dk_%dk_hope_d%d_beta0.01' % (args.nodes // 1000, args.edges // 1000, args.d)
+        self.args = args
+        g = make_graph(args)
+        self.n_edges = g.number_of_edges()
+        n, src, dst, w, _ = edge_arrays(g)
+        self.n = n
+        self.row_ptr, self.col, _ = to_csr(n, src, dst, None)
+        self.k = args.d // 2
+        self.U = np.empty((n, self.k), np.float32); self.V = np.empty((n, self.k), np.float32); self.sig = np.empty(self.k, np.float32)
+        self.stats = (C.c_double * 8)()
+        self.dev_s, self.spmm, self.spmm_cols, self.calls = 0.0, 0.0, 0.0, 0
+
+    def reset_counters(self):
+        self.dev_s, self.spmm, self.spmm_cols, self.calls = 0.0, 0.0, 0.0, 0
+
+    def step(self):
+        _hip.check(_hip.lib().gemhip_hope(self.n, len(self.col), _hip.ptr(self.row_ptr, C.c_int64), _hip.ptr(self.col, C.c_int32), None,
+                                          0.01, self.k, 16, 3, 20, 1e-5, 20260923, _hip.ptr(self.U, C.c_float), _hip.ptr(self.V, C.c_float),
+                                          _hip.ptr(self.sig, C.c_float), self.stats))
+        self.dev_s += self.stats[0]; self.spmm += self.stats[1]; self.spmm_cols += self.stats[2]; self.calls += 1
+
+    def units_per_step(self):
+        return self.n
+
+    def roofline(self, dev_ms_total, steps):
+        # SURVEY 8d: SpMM compulsory bytes = 8 nnz + 4(n+1) + 2*4*n*b per launch (b = dense block columns of that launch)
+        launches = self.spmm
+        bavg = self.spmm_cols / launches
+        algo = 8.0 * self.n_edges + 4.0 * (self.n + 1) + 8.0 * self.n * bavg
+        return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+                'algorithmic_bytes_per_launch': algo, 'spmm_launches_per_step': launches / self.calls, 'avg_block_columns': bavg,
+                'device_seconds_per_step': self.dev_s / self.calls, 'restarts': self.stats[5], 'katz_terms': self.stats[3],
+                'note': 'per-kernel launch time comes from the rocprofv3 summary in profiles/ (the solver interleaves SpMM, MFMA Gram/GEMM '
+                        'and host eigensolves inside one blocking C call)'}
+
+    def cpu_baseline(self, budget_s=30.0):
+        from oracle import hope_oracle
+        import scipy.sparse as sp
+        t = time.time()
+        n = self.n
+        A = sp.csr_matrix((np.ones(len(self.col)), self.col, self.row_ptr), shape=(n, n))
+        X, s = hope_oracle.hope_operator(A, 0.01, self.args.d, tol=1e-5)
+        el = time.time() - t
+        return {'value': n / el, 'unit': self.unit, 'cores': os.cpu_count() or 1, 'kind': 'port',
+                'sample': 'oracle/hope_oracle.py hope_operator (scipy svds on the implicit Katz operator with sparse LU; hope.py:28-36 cannot '
+                          'form its dense S at this n), same graph, tol=1e-5, %.1fs' % el}
+
+    def check(self):
+        assert np.isfinite(self.U).all() and np.all(np.diff(self.sig) >= 0) and self.sig[0] > 0
+
+
+WORKLOADS = {'gf': GFWorkload, 'node2vec': N2VWorkload, 'hope': HopeWorkload}
 
 
 def main():

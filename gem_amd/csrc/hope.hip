@@ -1,0 +1,698 @@
+// hope.hip -- HOPE (Katz-proximity truncated SVD) for MI355X (gfx950).
+//
+// Replaces gem/embedding/hope.py:28-36:
+//     A  = nx.to_numpy_matrix(graph)                    dense n x n, rows in graph.nodes order
+//     S  = inv(I - beta A) . (beta A)                   dense O(n^3)
+//     u, s, vt = scipy.sparse.linalg.svds(S, k=d//2)    ARPACK, s ascending
+//     X  = [u sqrt(s) | vt.T sqrt(s)]
+// S is never formed here.  S = sum_{t>=1} (beta A)^t, so S.Y and S^T.Y are fixed-point iterations of
+// CSR SpMMs (Z <- W + beta A Z), HBM-bound; the top-k singular triplets come from a restarted
+// randomized BLOCK KRYLOV method on S^T S with full re-orthogonalisation and a Rayleigh-Ritz step.
+// The dense tall-skinny products it needs -- Gram matrices X^T Y and basis updates X.C -- run on the
+// matrix cores with the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); the tiny projected eigenproblems
+// (<= 512 x 512) are solved on the host in fp64 (Householder tridiagonalisation + implicit QL).
+//
+// Kernels and what bounds them (n rows, b block columns, m basis columns):
+//   hope_spmm_kernel    Y = alpha A X (+W)    HBM/MALL: nnz*(8 + 4b) gather + 8 n b      [dominant]
+//   hope_gram_kernel    P = X^T Y per slab    MFMA fp32 (2 n m1 m2 flop), operands stream from L2
+//   hope_tsgemm_kernel  O = S + a X C         MFMA fp32 (2 n m b flop)
+#include "common.hpp"
+#include <vector>
+#include <cmath>
+#include <algorithm>
+#include <cstring>
+
+using namespace gemhip;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ SpMM (CSR)
+// One wavefront per row; lane l owns columns l, l+64, ... of the dense block (a neighbour row of
+// the block is one contiguous 4b-byte read).  (col,val) pairs are read 64 at a time, coalesced,
+// and broadcast with v_readlane; four neighbour rows are kept in flight.
+template <int CPL>
+__global__ __launch_bounds__(256) void hope_spmm_kernel(int64_t n, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                        const float *__restrict__ val, float alpha, const float *__restrict__ X, int ldx,
+                                                        const float *__restrict__ Wadd, int ldw, float *__restrict__ Y, int ldy, int b)
+{
+    const int lane = lane_id();
+    const int64_t i = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
+    float acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+    for (int64_t e = e0; e < e1; e += WAVE) {
+        const int cnt = (int)((e1 - e) < (int64_t)WAVE ? (e1 - e) : (int64_t)WAVE);
+        const int32_t cj = lane < cnt ? col[e + lane] : 0;
+        const float vj = lane < cnt ? val[e + lane] : 0.f;
+        for (int k = 0; k < cnt; k += 4) {
+            float xr[4][CPL];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = (k + u) < cnt ? (k + u) : (cnt - 1);
+                const float *px = X + (int64_t)bcast_lane(cj, kk) * ldx;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) { const int cc = lane + c * WAVE; xr[u][c] = cc < b ? px[cc] : 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = (k + u) < cnt ? bcast_lane(vj, (k + u) < cnt ? (k + u) : 0) : 0.f;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) acc[c] += v * xr[u][c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int cc = lane + c * WAVE;
+        if (cc < b) Y[i * ldy + cc] = alpha * acc[c] + (Wadd ? Wadd[i * ldw + cc] : 0.f);
+    }
+}
+
+// ------------------------------------------------------- Gram  P[slab] = X^T Y  (MFMA fp32)
+// One wavefront per 32x32 output tile and row slab.  v_mfma_f32_32x32x2_f32 consumes two rows
+// per issue: lane l supplies X[r + (l>>5)][ci + (l&31)] and Y[r + (l>>5)][cj + (l&31)] -- both
+// coalesced 128-byte row segments.  Slab partials are summed in fp64 by hope_reduce_kernel
+// (deterministic, no atomics).
+__global__ __launch_bounds__(256) void hope_gram_kernel(int64_t n, const float *__restrict__ X, int ldx, int m1, const float *__restrict__ Y,
+                                                        int ldy, int m2, int64_t rows_per_slab, int t2, int ntiles, float *__restrict__ P,
+                                                        int m1p, int m2p)
+{
+    const int lane = lane_id();
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int ti = tile / t2, tj = tile - ti * t2;
+    const int ci = ti * 32 + (lane & 31), cj = tj * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_slab;
+    const int64_t r_end = r_begin + rows_per_slab < n ? r_begin + rows_per_slab : n;
+    const bool vi = ci < m1, vj = cj < m2;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    int64_t r = r_begin;
+    for (; r + 8 <= r_end; r += 8) {
+        float a[4], bb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t rr = r + 2 * u + h;
+            a[u] = vi ? X[rr * ldx + ci] : 0.f;
+            bb[u] = vj ? Y[rr * ldy + cj] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb[u], acc, 0, 0, 0);
+    }
+    for (; r < r_end; r += 2) {
+        const int64_t rr = r + h;
+        const float a = (vi && rr < r_end) ? X[rr * ldx + ci] : 0.f;
+        const float bb = (vj && rr < r_end) ? Y[rr * ldy + cj] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+    }
+    float *Ps = P + (int64_t)blockIdx.y * m1p * m2p;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;       // C/D map of the 32x32 MFMA
+        Ps[(int64_t)row * m2p + tj * 32 + (lane & 31)] = acc[q];
+    }
+}
+
+__global__ void hope_reduce_kernel(const float *__restrict__ P, int nslabs, int64_t stride, int m1, int m2, int m2p, double *__restrict__ G)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m1 * m2) return;
+    const int i = idx / m2, j = idx - i * m2;
+    double s = 0.0;
+    for (int k = 0; k < nslabs; ++k) s += (double)P[k * stride + (int64_t)i * m2p + j];
+    G[idx] = s;
+}
+
+// ------------------------------------------- tall-skinny GEMM  O = Src + alpha X C  (MFMA fp32)
+// One wavefront per 32-row x 32-column output tile.  The MFMA's k pairs are re-labelled so that lane
+// half h covers k0+4h..k0+4h+3 over four issues: every lane reads 16 contiguous bytes of its X row.
+__global__ __launch_bounds__(256) void hope_tsgemm_kernel(int64_t n, const float *__restrict__ X, int ldx, int m, const float *__restrict__ Cm,
+                                                          int ldc, int b2, float alpha, const float *Src, int lds_,
+                                                          float *Out, int ldo, int ct_count)
+{
+    const int lane = lane_id();
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t rt = tile / ct_count;
+    const int ct = (int)(tile - rt * ct_count);
+    if (rt * 32 >= n) return;
+    const int64_t irow = rt * 32 + (lane & 31);
+    const int jcol = ct * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const bool vr = irow < n, vc = jcol < b2;
+    const float *px = X + irow * ldx;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int k0 = 0; k0 < m; k0 += 8) {
+        float a[4], bb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = k0 + 4 * h + t;
+            a[t] = (vr && k < m) ? px[k] : 0.f;
+            bb[t] = (vc && k < m) ? Cm[(int64_t)k * ldc + jcol] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bb[t], acc, 0, 0, 0);
+    }
+    if (!vc) return;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int64_t row = rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (row < n) {
+            const float s = Src ? Src[row * lds_ + jcol] : 0.f;
+            Out[row * ldo + jcol] = s + alpha * acc[q];
+        }
+    }
+}
+
+__global__ void hope_randn_kernel(float *X, int64_t n, int b, int ld, uint64_t seed)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = n * b;
+    if (t * 4 >= total) return;
+    const u32x4 r = philox4x32_10(seed, (uint32_t)t, (uint32_t)((uint64_t)t >> 32), 0x686Fu /* 'ho' */, 0u);
+    const float u1 = 1.0f - u01(r.x), u2 = u01(r.y), u3 = 1.0f - u01(r.z), u4 = u01(r.w);
+    const float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+    float s0, c0, s1, c1;
+    sincosf(6.28318530717958647692f * u2, &s0, &c0);
+    sincosf(6.28318530717958647692f * u4, &s1, &c1);
+    const float z[4] = {ra * c0, ra * s0, rb * c1, rb * s1};
+    for (int k = 0; k < 4; ++k) {
+        const int64_t e = t * 4 + k;
+        if (e < total) X[(e / b) * ld + (e % b)] = z[k];
+    }
+}
+
+// ------------------------------------------------------------- host: symmetric eigensolver (fp64)
+// Householder tridiagonalisation + implicit-shift QL (the classical EISPACK tred2/tql2 pair).
+// A (n x n, row-major, symmetric) is overwritten by the eigenvectors (columns); w gets the
+// eigenvalues in ASCENDING order.
+void sym_eig(int n, std::vector<double> &V, std::vector<double> &d)
+{
+    std::vector<double> e(n, 0.0);
+    d.assign(n, 0.0);
+    auto A = [&](int i, int j) -> double & { return V[(size_t)i * n + j]; };
+    for (int j = 0; j < n; ++j) d[j] = A(n - 1, j);
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) { d[j] = A(i - 1, j); A(i, j) = 0.0; A(j, i) = 0.0; }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h -= f * g;
+            d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                A(j, i) = f;
+                g = e[j] + A(j, j) * f;
+                for (int k = j + 1; k <= i - 1; ++k) { g += A(k, j) * d[k]; e[k] += A(k, j) * f; }
+                e[j] = g;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; g = e[j];
+                for (int k = j; k <= i - 1; ++k) A(k, j) -= (f * e[k] + g * d[k]);
+                d[j] = A(i - 1, j);
+                A(i, j) = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        A(n - 1, i) = A(i, i);
+        A(i, i) = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) d[k] = A(k, i + 1) / h;
+            for (int j = 0; j <= i; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= i; ++k) g += A(k, i + 1) * A(k, j);
+                for (int k = 0; k <= i; ++k) A(k, j) -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; ++k) A(k, i + 1) = 0.0;
+    }
+    for (int j = 0; j < n; ++j) { d[j] = A(n - 1, j); A(n - 1, j) = 0.0; }
+    A(n - 1, n - 1) = 1.0;
+    e[0] = 0.0;
+    // QL
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = std::pow(2.0, -52.0);
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }
+        if (m > l) {
+            int iter = 0;
+            do {
+                ++iter;
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; ++k) {
+                        h = A(k, i + 1);
+                        A(k, i + 1) = s * A(k, i) + c * h;
+                        A(k, i) = c * A(k, i) - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1 && iter < 200);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    for (int i = 0; i < n - 1; ++i) {                   // sort ascending
+        int k = i; double p = d[i];
+        for (int j = i + 1; j < n; ++j) if (d[j] < p) { k = j; p = d[j]; }
+        if (k != i) {
+            d[k] = d[i]; d[i] = p;
+            for (int j = 0; j < n; ++j) std::swap(A(j, i), A(j, k));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------- solver state
+struct Hope {
+    int64_t n = 0, nnz = 0;
+    float beta = 0.f;
+    int64_t *rp = nullptr, *rpT = nullptr;
+    int32_t *ci = nullptr, *ciT = nullptr;
+    float *va = nullptr, *vaT = nullptr;
+    float *P = nullptr; size_t P_bytes = 0;          // Gram slab partials
+    double *G = nullptr; size_t G_elems = 0;         // device fp64 Gram
+    float *Csmall = nullptr; size_t C_elems = 0;     // device small matrix for tsgemm
+    hipStream_t s = nullptr;
+    double spmm_count = 0, spmm_cols = 0;            // statistics
+    int err = 0;
+    ~Hope()
+    {
+        hipFree(rp); hipFree(rpT); hipFree(ci); hipFree(ciT); hipFree(va); hipFree(vaT); hipFree(P); hipFree(G); hipFree(Csmall);
+    }
+};
+
+#define HOPE_TRY(h, x) do { if (!(h).err) { hipError_t _e = (x); if (_e != hipSuccess) { (h).err = fail(GEMHIP_E_HIP, "hope: %s: %s", #x, hipGetErrorString(_e)); } } } while (0)
+
+void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const float *Wadd, int ldw, float *Y, int ldy, int b)
+{
+    if (H.err) return;
+    const int64_t blocks = (H.n + 3) / 4;
+    const dim3 grid((unsigned)((blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD)), blk(256);
+    const int64_t *rp = transpose ? H.rpT : H.rp; const int32_t *ci = transpose ? H.ciT : H.ci; const float *va = transpose ? H.vaT : H.va;
+    const int cpl = (b + 63) / 64;
+#define SPMM(C) hipLaunchKernelGGL((hope_spmm_kernel<C>), grid, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b)
+    if (cpl <= 1) SPMM(1); else if (cpl <= 2) SPMM(2); else if (cpl <= 4) SPMM(4); else SPMM(8);
+#undef SPMM
+    H.spmm_count += 1; H.spmm_cols += b;
+}
+
+// G (host, fp64, m1 x m2 row-major) = X[:, :m1]^T Y[:, :m2]
+void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int m2, std::vector<double> &Gh)
+{
+    Gh.assign((size_t)m1 * m2, 0.0);
+    if (H.err || m1 == 0 || m2 == 0) return;
+    const int t1 = (m1 + 31) / 32, t2 = (m2 + 31) / 32, m1p = t1 * 32, m2p = t2 * 32;
+    const int64_t rows_per_slab = 4096;
+    const int nslabs = (int)((H.n + rows_per_slab - 1) / rows_per_slab);
+    const size_t need = (size_t)nslabs * m1p * m2p * sizeof(float);
+    if (need > H.P_bytes) { hipFree(H.P); H.P = nullptr; H.P_bytes = 0; HOPE_TRY(H, hipMalloc((void **)&H.P, need)); if (!H.err) H.P_bytes = need; }
+    if ((size_t)m1 * m2 > H.G_elems) { hipFree(H.G); H.G = nullptr; H.G_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.G, (size_t)m1 * m2 * sizeof(double))); if (!H.err) H.G_elems = (size_t)m1 * m2; }
+    if (H.err) return;
+    const int ntiles = t1 * t2;
+    hipLaunchKernelGGL(hope_gram_kernel, dim3((ntiles + 3) / 4, nslabs), dim3(256), 0, H.s, H.n, X, ldx, m1, Y, ldy, m2, rows_per_slab, t2, ntiles,
+                       H.P, m1p, m2p);
+    hipLaunchKernelGGL(hope_reduce_kernel, dim3((m1 * m2 + 255) / 256), dim3(256), 0, H.s, H.P, nslabs, (int64_t)m1p * m2p, m1, m2, m2p, H.G);
+    HOPE_TRY(H, hipMemcpyAsync(Gh.data(), H.G, (size_t)m1 * m2 * sizeof(double), hipMemcpyDeviceToHost, H.s));
+    HOPE_TRY(H, hipStreamSynchronize(H.s));
+}
+
+// Out[:, :b2] = (Src ? Src : 0) + alpha * X[:, :m] * C   (C host fp64 m x b2 row-major)
+void tsgemm(Hope &H, const float *X, int ldx, int m, const std::vector<double> &Ch, int b2, float alpha, const float *Src, int lds_, float *Out, int ldo)
+{
+    if (H.err || b2 == 0) return;
+    std::vector<float> Cf((size_t)std::max(m, 1) * b2);
+    for (size_t i = 0; i < (size_t)m * b2; ++i) Cf[i] = (float)Ch[i];
+    if (Cf.size() > H.C_elems) { hipFree(H.Csmall); H.Csmall = nullptr; H.C_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.Csmall, Cf.size() * sizeof(float))); if (!H.err) H.C_elems = Cf.size(); }
+    if (H.err) return;
+    HOPE_TRY(H, hipMemcpyAsync(H.Csmall, Cf.data(), (size_t)m * b2 * sizeof(float), hipMemcpyHostToDevice, H.s));
+    HOPE_TRY(H, hipStreamSynchronize(H.s));          // Cf is a stack-lifetime buffer
+    const int ct = (b2 + 31) / 32;
+    const int64_t tiles = ((H.n + 31) / 32) * ct;
+    hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, H.Csmall, b2, b2, alpha, Src, lds_, Out,
+                       ldo, ct);
+}
+
+// Orthonormalise the b columns of Y (n x b, ld) into Out via the Gram eigen-decomposition
+// Y <- Y W L^-1/2, dropping directions with relative energy below `tol` (rank revealing), twice.
+// Returns the number of columns kept.
+int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, double abs_floor = 0.0)
+{
+    int keep = b;
+    for (int pass = 0; pass < 2 && keep > 0 && !H.err; ++pass) {
+        std::vector<double> G, w;
+        gram(H, Y, ld, keep, Y, ld, keep, G);
+        if (H.err) return 0;
+        sym_eig(keep, G, w);                                  // ascending; G columns = eigenvectors
+        const double lmax = std::max(w[keep - 1], 0.0);
+        int first = 0;
+        while (first < keep && !(w[first] > tol * lmax && w[first] > abs_floor && w[first] > 0.0)) ++first;
+        const int nk = keep - first;
+        if (nk == 0) return 0;
+        std::vector<double> C((size_t)keep * nk);
+        for (int i = 0; i < keep; ++i)
+            for (int j = 0; j < nk; ++j) C[(size_t)i * nk + j] = G[(size_t)i * keep + (keep - 1 - j)] / std::sqrt(w[keep - 1 - j]);
+        tsgemm(H, Y, ld, keep, C, nk, 1.0f, nullptr, 0, Tmp, ldt);
+        HOPE_TRY(H, hipMemcpy2DAsync(Y, (size_t)ld * sizeof(float), Tmp, (size_t)ldt * sizeof(float), (size_t)nk * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
+        keep = nk;
+        tol = 1e-12; abs_floor = 0.0;                          // second pass only polishes
+    }
+    return keep;
+}
+
+// Z = S X  (X: n x b):  W0 = beta A X ; Z <- W0 + beta A Z, `terms` times  => sum_{t=1..terms+1} (beta A)^t X.
+// W0, T0, T1: scratch n x b with leading dimension ldt.
+void apply_S(Hope &H, const float *X, int ldx, int b, int terms, float *T0, float *T1, float *W0, int ldt, float *Out, int ldo)
+{
+    spmm(H, false, H.beta, X, ldx, nullptr, 0, W0, ldt, b);
+    if (terms == 0) {
+        HOPE_TRY(H, hipMemcpy2DAsync(Out, (size_t)ldo * sizeof(float), W0, (size_t)ldt * sizeof(float), (size_t)b * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
+        return;
+    }
+    const float *zin = W0;
+    int ldin = ldt;
+    for (int t = 0; t < terms; ++t) {
+        const bool last = (t == terms - 1);
+        float *zout = last ? Out : ((t & 1) ? T1 : T0);
+        const int ldout = last ? ldo : ldt;
+        spmm(H, false, H.beta, zin, ldin, W0, ldt, zout, ldout, b);
+        zin = zout; ldin = ldout;
+    }
+}
+
+// Z = S^T Y = beta A^T (I - beta A^T)^-1 Y :  R <- Y + beta A^T R, then Z = beta A^T R.
+void apply_ST(Hope &H, const float *Y, int ldy, int b, int terms, float *T0, float *T1, int ldt, float *Out, int ldo)
+{
+    const float *rin = Y; int ldr = ldy;
+    for (int t = 0; t < terms; ++t) {
+        float *rout = (t & 1) ? T1 : T0;
+        spmm(H, true, H.beta, rin, ldr, Y, ldy, rout, ldt, b);
+        rin = rout; ldr = ldt;
+    }
+    spmm(H, true, H.beta, rin, ldr, nullptr, 0, Out, ldo, b);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------- host API
+extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
+                           int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS,
+                           float *V_sqrtS, float *sigma, double *stats)
+{
+    GEMHIP_REQUIRE(n >= 2 && nnz >= 0 && row_ptr && (nnz == 0 || col), "hope: bad CSR arguments");
+    GEMHIP_REQUIRE(k >= 1 && k < n, "hope: k=%d must satisfy 1 <= k < n=%lld (svds requirement)", k, (long long)n);
+    GEMHIP_REQUIRE(U_sqrtS && V_sqrtS && sigma, "hope: output pointers are NULL");
+    GEMHIP_REQUIRE(oversample >= 0 && krylov_steps >= 1 && max_restarts >= 0, "hope: need oversample >= 0, krylov_steps >= 1, max_restarts >= 0");
+    GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "hope: row_ptr inconsistent with nnz");
+    Hope H;
+    H.n = n; H.nnz = nnz; H.beta = beta;
+    // transpose on the host (counting sort), values default to 1
+    std::vector<int64_t> rpT(n + 1, 0);
+    std::vector<int32_t> ciT(std::max<int64_t>(nnz, 1));
+    std::vector<float> va(std::max<int64_t>(nnz, 1)), vaT(std::max<int64_t>(nnz, 1));
+    for (int64_t e = 0; e < nnz; ++e) {
+        GEMHIP_REQUIRE(col[e] >= 0 && col[e] < n, "hope: column %d outside [0,%lld)", col[e], (long long)n);
+        va[e] = w ? w[e] : 1.0f;
+        ++rpT[col[e] + 1];
+    }
+    for (int64_t i = 0; i < n; ++i) rpT[i + 1] += rpT[i];
+    {
+        std::vector<int64_t> at(rpT.begin(), rpT.end() - 1);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { const int64_t q = at[col[e]]++; ciT[q] = (int32_t)i; vaT[q] = va[e]; }
+    }
+    // Neumann terms from a power-iteration estimate of rho(A): bound by the max absolute row/col sum too
+    double rs_max = 0.0, cs_max = 0.0;
+    {
+        std::vector<double> cs(n, 0.0);
+        for (int64_t i = 0; i < n; ++i) {
+            double rs = 0.0;
+            for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { rs += std::fabs(va[e]); cs[col[e]] += std::fabs(va[e]); }
+            rs_max = std::max(rs_max, rs);
+        }
+        for (int64_t i = 0; i < n; ++i) cs_max = std::max(cs_max, cs[i]);
+    }
+    double rho = 0.0;
+    {   // power iteration on A^T A (host, 40 steps): sigma_max(A) >= rho(A); converges from below, hence the margin
+        std::vector<double> x(n), y(n), z(n);
+        for (int64_t i = 0; i < n; ++i) x[i] = 1.0 + 0.37 * std::sin(12.9898 * (double)(i + 1));
+        for (int it = 0; it < 40; ++it) {
+            for (int64_t i = 0; i < n; ++i) {
+                double sacc = 0.0;
+                for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) sacc += va[e] * x[col[e]];
+                y[i] = sacc;
+            }
+            std::fill(z.begin(), z.end(), 0.0);
+            for (int64_t i = 0; i < n; ++i)
+                for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) z[col[e]] += va[e] * y[i];
+            double nx = 0.0, nz = 0.0;
+            for (int64_t i = 0; i < n; ++i) { nx += x[i] * x[i]; nz += z[i] * z[i]; }
+            if (nz == 0.0 || nx == 0.0) break;
+            rho = std::sqrt(std::sqrt(nz / nx));
+            const double inv = 1.0 / std::sqrt(nz);
+            for (int64_t i = 0; i < n; ++i) x[i] = z[i] * inv;
+        }
+        rho = std::min(std::max(rho * 1.1, 1e-30), std::sqrt(rs_max * cs_max));
+    }
+    const double br = std::fabs((double)beta) * rho;
+    if (!(br < 0.95))
+        return fail(GEMHIP_E_NOTCONVERGED, "hope: beta*rho(A) ~ %.3f >= 0.95: the Katz series (I - beta A)^-1 = sum (beta A)^t does not converge fast "
+                                           "enough on this graph (the reference forms the dense inverse); lower beta", br);
+    int terms = (br <= 0.0) ? 0 : (int)std::ceil(std::log(1e-8) / std::log(br));
+    terms = std::max(1, std::min(terms, 400));
+
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "hope: no HIP device");
+    auto up = [&](void **dp, const void *hp, size_t bytes) { HOPE_TRY(H, hipMalloc(dp, std::max<size_t>(bytes, 16))); if (!H.err && bytes) HOPE_TRY(H, hipMemcpy(*dp, hp, bytes, hipMemcpyHostToDevice)); };
+    up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
+    up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
+    if (H.err) return H.err;
+
+    // ---- block Krylov on S^T S ------------------------------------------------------------
+    const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
+    const int mmax = (int)std::min<int64_t>(std::min<int64_t>((int64_t)b * (krylov_steps + 1), n), 512);
+    GEMHIP_REQUIRE(b <= 512 && k <= mmax, "hope: k + oversample = %d too large (max 512)", b);
+    const int ldm = (mmax + 31) / 32 * 32, ldb = (b + 31) / 32 * 32;
+    float *Vall = nullptr, *Ball = nullptr, *Wk = nullptr, *T0 = nullptr, *T1 = nullptr, *W0 = nullptr, *Tmp = nullptr;
+    auto dalloc = [&](float **p, size_t cols) { HOPE_TRY(H, hipMalloc((void **)p, (size_t)n * cols * sizeof(float))); if (!H.err) HOPE_TRY(H, hipMemset(*p, 0, (size_t)n * cols * sizeof(float))); };
+    dalloc(&Vall, ldm); dalloc(&Ball, ldm); dalloc(&Wk, ldb); dalloc(&T0, ldb); dalloc(&T1, ldb); dalloc(&W0, ldb); dalloc(&Tmp, ldm);
+    auto cleanup = [&]() { hipFree(Vall); hipFree(Ball); hipFree(Wk); hipFree(T0); hipFree(T1); hipFree(W0); hipFree(Tmp); };
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (!H.err) { HOPE_TRY(H, hipEventCreate(&ev0)); HOPE_TRY(H, hipEventCreate(&ev1)); }
+    if (H.err) { cleanup(); return H.err; }
+    hipEventRecord(ev0, H.s);
+
+    const int64_t threads = (n * (int64_t)b + 3) / 4;
+    hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, H.s, Vall, n, b, ldm, seed);
+    int m0 = orth(H, Vall, ldm, b, Tmp, ldm, 1e-10);
+
+    std::vector<double> sig_old(k, 0.0), sig(k, 0.0), Wv, ev;
+    int mc = 0, restarts_done = 0;
+    double last_change = 1.0;
+    bool exact = false;
+    for (int rs = 0; rs <= max_restarts && !H.err; ++rs) {
+        mc = m0;
+        int prev_off = 0, prev_b = m0;
+        for (int j = 1; j <= krylov_steps && mc < mmax && !H.err; ++j) {
+            // W = S^T S V_{j-1}
+            apply_S(H, Vall + prev_off, ldm, prev_b, terms, T0, T1, W0, ldb, Wk, ldb);
+            apply_ST(H, Wk, ldb, prev_b, terms, T0, T1, ldb, W0, ldb);
+            // energy of the new block before projection: what is left after projecting out the basis is only
+            // kept if it stands above fp32 rounding noise relative to this
+            double ref_energy = 0.0;
+            {
+                std::vector<double> D;
+                gram(H, W0, ldb, prev_b, W0, ldb, prev_b, D);
+                for (int c = 0; c < prev_b && !H.err; ++c) ref_energy = std::max(ref_energy, D[(size_t)c * prev_b + c]);
+            }
+            // full re-orthogonalisation against the basis so far, normalise, then repeat on the normalised block:
+            // a direction that survives the rank filter with small amplitude carries rounding noise that lies
+            // INSIDE span(Vall); after normalisation that noise is O(eps / amplitude), so project again.
+            auto project = [&](int cols) {
+                std::vector<double> C;
+                gram(H, Vall, ldm, mc, W0, ldb, cols, C);
+                tsgemm(H, Vall, ldm, mc, C, cols, -1.0f, W0, ldb, W0, ldb);
+            };
+            project(prev_b);
+            project(prev_b);
+            int nb = orth(H, W0, ldb, prev_b, Tmp, ldm, 1e-9, 1e-8 * ref_energy);
+            if (nb > 0) {
+                project(nb);
+                nb = orth(H, W0, ldb, nb, Tmp, ldm, 1e-9, 0.25);      // unit columns: drop what lost half its norm
+            }
+            nb = std::min(nb, mmax - mc);
+            if (nb <= 0) break;
+            HOPE_TRY(H, hipMemcpy2DAsync(Vall + mc, (size_t)ldm * sizeof(float), W0, (size_t)ldb * sizeof(float), (size_t)nb * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
+            prev_off = mc; prev_b = nb; mc += nb;
+        }
+        // B = S Vall, block by block
+        for (int off = 0; off < mc && !H.err; off += b) {
+            const int bb = std::min(b, mc - off);
+            apply_S(H, Vall + off, ldm, bb, terms, T0, T1, W0, ldb, Ball + off, ldm);
+        }
+        // Rayleigh-Ritz: B^T B = Wv diag(ev) Wv^T
+        gram(H, Ball, ldm, mc, Ball, ldm, mc, Wv);
+        if (H.err) break;
+        sym_eig(mc, Wv, ev);
+        GEMHIP_REQUIRE(mc >= k || (cleanup(), false), "hope: Krylov space collapsed to %d < k=%d columns (rank-deficient S?)", mc, k);
+        for (int j = 0; j < k; ++j) sig[j] = std::sqrt(std::max(ev[mc - 1 - j], 0.0));          // descending
+        double change = 0.0;
+        for (int j = 0; j < k; ++j) change = std::max(change, std::fabs(sig[j] - sig_old[j]));
+        last_change = sig[0] > 0 ? change / sig[0] : 0.0;
+        sig_old = sig;
+        restarts_done = rs;
+        exact = (mc >= n) || (krylov_steps == 0 && false);
+        const bool done = exact || (rs > 0 && last_change < tol) || rs == max_restarts;
+        if (done) break;
+        // restart from the best b right Ritz vectors:  V0 <- Vall Wv[:, top b]
+        const int nb = std::min(b, mc);
+        std::vector<double> C((size_t)mc * nb);
+        for (int i = 0; i < mc; ++i)
+            for (int j = 0; j < nb; ++j) C[(size_t)i * nb + j] = Wv[(size_t)i * mc + (mc - 1 - j)];
+        tsgemm(H, Vall, ldm, mc, C, nb, 1.0f, nullptr, 0, Tmp, ldm);
+        HOPE_TRY(H, hipMemcpy2DAsync(Vall, (size_t)ldm * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)nb * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
+        m0 = orth(H, Vall, ldm, nb, Tmp, ldm, 1e-10);
+    }
+    if (!H.err) {
+        // U sqrt(S) = B Wv S^-1/2 ,  V sqrt(S) = Vall Wv S^1/2 ; columns in ASCENDING sigma (svds order, hope.py:33)
+        std::vector<double> Cu((size_t)mc * k), Cv((size_t)mc * k);
+        for (int j = 0; j < k; ++j) {
+            const int src = mc - k + j;                      // ascending eigenvalue index
+            const double s = std::sqrt(std::max(ev[src], 0.0));
+            sigma[j] = (float)s;
+            const double su = s > 0 ? 1.0 / std::sqrt(s) : 0.0, sv = std::sqrt(s);
+            for (int i = 0; i < mc; ++i) { Cu[(size_t)i * k + j] = Wv[(size_t)i * mc + src] * su; Cv[(size_t)i * k + j] = Wv[(size_t)i * mc + src] * sv; }
+        }
+        tsgemm(H, Ball, ldm, mc, Cu, k, 1.0f, nullptr, 0, Tmp, ldm);
+        HOPE_TRY(H, hipMemcpy2D(U_sqrtS, (size_t)k * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)k * sizeof(float), n, hipMemcpyDeviceToHost));
+        tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, ldm);
+        HOPE_TRY(H, hipMemcpy2D(V_sqrtS, (size_t)k * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)k * sizeof(float), n, hipMemcpyDeviceToHost));
+        // deterministic sign: largest-magnitude entry of each left vector positive (svds signs are arbitrary)
+        for (int j = 0; j < k; ++j) {
+            int64_t arg = 0; float best = 0.f;
+            for (int64_t i = 0; i < n; ++i) { const float a = std::fabs(U_sqrtS[i * k + j]); if (a > best) { best = a; arg = i; } }
+            if (U_sqrtS[arg * k + j] < 0.f)
+                for (int64_t i = 0; i < n; ++i) { U_sqrtS[i * k + j] = -U_sqrtS[i * k + j]; V_sqrtS[i * k + j] = -V_sqrtS[i * k + j]; }
+        }
+    }
+    float ms = 0.f;
+    if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
+    if (stats && !H.err) {
+        stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = terms; stats[4] = mc; stats[5] = restarts_done;
+        stats[6] = last_change; stats[7] = br;
+    }
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
+    cleanup();
+    return H.err;
+}
+
+
+// ------------------------------------------------------------------ building blocks, exposed for kernel-level parity tests
+extern "C" int gemhip_sym_eig(int32_t n, double *A_inout, double *w_out)
+{
+    GEMHIP_REQUIRE(n >= 1 && A_inout && w_out, "sym_eig: bad arguments");
+    std::vector<double> V(A_inout, A_inout + (size_t)n * n), w;
+    sym_eig(n, V, w);
+    std::copy(V.begin(), V.end(), A_inout);
+    std::copy(w.begin(), w.end(), w_out);
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_hope_spmm(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float alpha, int32_t b,
+                                const float *X_host, const float *Wadd_host, float *Y_host)
+{
+    GEMHIP_REQUIRE(n >= 1 && row_ptr && X_host && Y_host && b >= 1 && b <= 512, "hope_spmm: bad arguments");
+    Hope H; H.n = n; H.nnz = nnz;
+    std::vector<float> va(std::max<int64_t>(nnz, 1), 1.0f);
+    if (w) std::copy(w, w + nnz, va.begin());
+    float *dX = nullptr, *dW = nullptr, *dY = nullptr;
+    HOPE_TRY(H, hipMalloc((void **)&H.rp, (n + 1) * 8)); HOPE_TRY(H, hipMalloc((void **)&H.ci, std::max<int64_t>(nnz, 1) * 4)); HOPE_TRY(H, hipMalloc((void **)&H.va, std::max<int64_t>(nnz, 1) * 4));
+    HOPE_TRY(H, hipMalloc((void **)&dX, (size_t)n * b * 4)); HOPE_TRY(H, hipMalloc((void **)&dW, (size_t)n * b * 4)); HOPE_TRY(H, hipMalloc((void **)&dY, (size_t)n * b * 4));
+    HOPE_TRY(H, hipMemcpy(H.rp, row_ptr, (n + 1) * 8, hipMemcpyHostToDevice));
+    if (nnz) { HOPE_TRY(H, hipMemcpy(H.ci, col, nnz * 4, hipMemcpyHostToDevice)); HOPE_TRY(H, hipMemcpy(H.va, va.data(), nnz * 4, hipMemcpyHostToDevice)); }
+    HOPE_TRY(H, hipMemcpy(dX, X_host, (size_t)n * b * 4, hipMemcpyHostToDevice));
+    if (Wadd_host) HOPE_TRY(H, hipMemcpy(dW, Wadd_host, (size_t)n * b * 4, hipMemcpyHostToDevice));
+    spmm(H, false, alpha, dX, b, Wadd_host ? dW : nullptr, b, dY, b, b);
+    HOPE_TRY(H, hipMemcpy(Y_host, dY, (size_t)n * b * 4, hipMemcpyDeviceToHost));
+    hipFree(dX); hipFree(dW); hipFree(dY);
+    return H.err;
+}
+
+extern "C" int gemhip_hope_gram(int64_t n, int32_t m1, int32_t m2, const float *X_host, const float *Y_host, double *G_host)
+{
+    GEMHIP_REQUIRE(n >= 1 && m1 >= 1 && m2 >= 1 && X_host && Y_host && G_host, "hope_gram: bad arguments");
+    Hope H; H.n = n;
+    float *dX = nullptr, *dY = nullptr;
+    HOPE_TRY(H, hipMalloc((void **)&dX, (size_t)n * m1 * 4)); HOPE_TRY(H, hipMalloc((void **)&dY, (size_t)n * m2 * 4));
+    HOPE_TRY(H, hipMemcpy(dX, X_host, (size_t)n * m1 * 4, hipMemcpyHostToDevice)); HOPE_TRY(H, hipMemcpy(dY, Y_host, (size_t)n * m2 * 4, hipMemcpyHostToDevice));
+    std::vector<double> G;
+    gram(H, dX, m1, m1, dY, m2, m2, G);
+    if (!H.err) std::copy(G.begin(), G.end(), G_host);
+    hipFree(dX); hipFree(dY);
+    return H.err;
+}
+
+extern "C" int gemhip_hope_tsgemm(int64_t n, int32_t m, int32_t b2, const float *X_host, const double *C_host, float alpha, const float *Src_host,
+                                  float *Out_host)
+{
+    GEMHIP_REQUIRE(n >= 1 && m >= 1 && b2 >= 1 && X_host && C_host && Out_host, "hope_tsgemm: bad arguments");
+    Hope H; H.n = n;
+    float *dX = nullptr, *dS = nullptr, *dO = nullptr;
+    HOPE_TRY(H, hipMalloc((void **)&dX, (size_t)n * m * 4)); HOPE_TRY(H, hipMalloc((void **)&dS, (size_t)n * b2 * 4)); HOPE_TRY(H, hipMalloc((void **)&dO, (size_t)n * b2 * 4));
+    HOPE_TRY(H, hipMemcpy(dX, X_host, (size_t)n * m * 4, hipMemcpyHostToDevice));
+    if (Src_host) HOPE_TRY(H, hipMemcpy(dS, Src_host, (size_t)n * b2 * 4, hipMemcpyHostToDevice));
+    std::vector<double> C(C_host, C_host + (size_t)m * b2);
+    tsgemm(H, dX, m, m, C, b2, alpha, Src_host ? dS : nullptr, b2, dO, b2);
+    HOPE_TRY(H, hipMemcpy(Out_host, dO, (size_t)n * b2 * 4, hipMemcpyDeviceToHost));
+    hipFree(dX); hipFree(dS); hipFree(dO);
+    return H.err;
+}

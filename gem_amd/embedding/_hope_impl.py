@@ -1,0 +1,35 @@
+"""Host side of HOPE.learn_embedding: nx graph -> CSR in graph.nodes order -> libgem_hip.so."""
+import ctypes as C
+
+import numpy as np
+
+from gem_amd import _hip
+from gem_amd.graph import edge_arrays, to_csr
+
+
+def learn(model, graph):
+    n, src, dst, w, order = edge_arrays(graph)
+    if order is not None:
+        # hope.py:28 builds A with nx.to_numpy_matrix(graph): row/column index = position in graph.nodes,
+        # NOT the node id.  Row r of the returned X belongs to the r-th inserted node.
+        pos = np.empty(n, dtype=np.int64)
+        pos[order] = np.arange(n)
+        src, dst = pos[src].astype(np.int32), pos[dst].astype(np.int32)
+    row_ptr, col, ww = to_csr(n, src, dst, w)
+    d = int(model._d)
+    k = d // 2
+    if k < 1 or k >= n:
+        raise ValueError('HOPE needs 1 <= d//2 < n (scipy svds: k must satisfy 0 < k < min(shape))')
+    _hip.require_device()
+    U = np.empty((n, k), dtype=np.float32); V = np.empty((n, k), dtype=np.float32); sig = np.empty(k, dtype=np.float32)
+    stats = (C.c_double * 8)()
+    _hip.check(_hip.lib().gemhip_hope(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), _hip.ptr(ww, C.c_float),
+                                      float(model._beta), k, int(getattr(model, '_oversample', 16)),
+                                      int(getattr(model, '_krylov_steps', 3)), int(getattr(model, '_max_restarts', 20)),
+                                      float(getattr(model, '_tol', 1e-5)), int(getattr(model, '_seed', 20260923)),
+                                      _hip.ptr(U, C.c_float), _hip.ptr(V, C.c_float), _hip.ptr(sig, C.c_float), stats))
+    model._sigma = sig.astype(np.float64)
+    model._stats = dict(zip(('device_seconds', 'spmm_launches', 'spmm_columns', 'katz_terms', 'basis_columns', 'restarts',
+                             'last_sigma_change', 'beta_sigma_max'), list(stats)))
+    model._node_num = n
+    return np.concatenate((U, V), axis=1).astype(np.float64)

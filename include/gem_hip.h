@@ -182,6 +182,38 @@ int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0,
                       int64_t tokens_total, int64_t token_offset, uint64_t seed,
                       int32_t flags, void *stream);
 
+/* ---------------------------------------------------------------------- HOPE
+ * Replaces: gem/embedding/hope.py:23-41 (HOPE.learn_embedding): S = inv(I - beta A) (beta A)
+ * as dense numpy matrices (:28-31) and u, s, vt = scipy.sparse.linalg.svds(S, k=d//2) (:33).
+ *
+ * Graph: CSR of A with rows AND columns indexed in graph.nodes order (hope.py:28 uses
+ * nx.to_numpy_matrix, whose index is insertion order).  Outputs, all caller-owned float32:
+ *   U_sqrtS [n][k] = u * sqrt(s),  V_sqrtS [n][k] = vt.T * sqrt(s)   (hope.py:34-35; X = [U | V]),
+ *   sigma [k] ASCENDING like svds (hope.py:33).  Column signs: largest |entry| of each u positive.
+ * Solver knobs: oversample (block = k + oversample columns), krylov_steps (blocks per cycle),
+ * max_restarts, tol (max relative change of the k singular values between cycles).
+ * stats (optional, 8 doubles): {device_seconds, spmm_launches, spmm_columns_total, katz_terms,
+ * basis_columns, restarts_done, last_sigma_change, beta*sigma_max(A) estimate}.
+ * Returns GEMHIP_E_NOTCONVERGED when beta*sigma_max(A) >= 0.95 (Katz series too slow). */
+int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
+                float beta, int32_t k, int32_t oversample, int32_t krylov_steps,
+                int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS, float *V_sqrtS,
+                float *sigma, double *stats);
+
+/* HOPE building blocks, exposed so each kernel can be parity-tested on its own (host buffers in,
+ * host buffers out, blocking).  Dense blocks are row-major with leading dimension = column count.
+ *   sym_eig : host fp64 symmetric eigensolver used for the projected problems (A overwritten by
+ *             eigenvectors in columns, w ascending) -- pure host code, callable without a GPU;
+ *   spmm    : Y[n][b] = alpha * A X (+ Wadd)        gram : G[m1][m2] = X^T Y  (fp64 out, MFMA fp32)
+ *   tsgemm  : Out[n][b2] = (Src or 0) + alpha * X[n][m] C[m][b2]   (C given in fp64, MFMA fp32). */
+int gemhip_sym_eig(int32_t n, double *A_inout, double *w_out);
+int gemhip_hope_spmm(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
+                     float alpha, int32_t b, const float *X_host, const float *Wadd_host, float *Y_host);
+int gemhip_hope_gram(int64_t n, int32_t m1, int32_t m2, const float *X_host, const float *Y_host,
+                     double *G_host);
+int gemhip_hope_tsgemm(int64_t n, int32_t m, int32_t b2, const float *X_host, const double *C_host,
+                       float alpha, const float *Src_host, float *Out_host);
+
 #ifdef __cplusplus
 }
 #endif

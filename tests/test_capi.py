@@ -52,3 +52,20 @@ def test_product_never_imports_oracle():
                 if re.search(r'^\s*(import|from)\s+oracle\b', t, flags=re.M) or 'liboracle' in t or '_ref/' in t:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_host_symmetric_eigensolver():
+    """gemhip_sym_eig is host code (tred2/tql2) -- the projected eigenproblems of HOPE run through it."""
+    import numpy as np
+    L = _hip.lib()
+    rng = np.random.RandomState(0)
+    for n in (1, 2, 7, 34, 96, 257):
+        M = rng.randn(n, n)
+        A = (M + M.T) / 2 if n != 34 else M[:, :10] @ M[:, :10].T          # n=34: rank 10
+        V = A.copy(); w = np.zeros(n)
+        _hip.check(L.gemhip_sym_eig(n, _hip.ptr(V, ctypes.c_double), _hip.ptr(w, ctypes.c_double)))
+        scale = max(np.abs(A).max(), 1.0)
+        assert np.all(np.diff(w) >= 0)
+        assert np.abs(w - np.linalg.eigvalsh(A)).max() < 1e-11 * scale * n
+        assert np.abs(V @ np.diag(w) @ V.T - A).max() < 1e-11 * scale * n
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12 * n

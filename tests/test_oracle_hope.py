@@ -1,0 +1,33 @@
+"""CPU tests: the HOPE oracle against the reference's golden vector and against vectors produced by
+running gem/embedding/hope.py itself (scripts/make_golden.py)."""
+import numpy as np
+
+from oracle import hope_oracle
+from gem_amd.graph import edge_arrays
+from conftest import golden_path
+
+
+def test_dense_oracle_reproduces_reference_golden(karate):
+    n, src, dst, w, order = edge_arrays(karate)
+    assert order is not None and list(order[:4]) == [0, 31, 21, 19]          # insertion order quirk
+    A = hope_oracle.adjacency(n, src, dst, w, order)
+    X, s = hope_oracle.hope_dense(A, 0.01, 4)
+    gold = np.loadtxt(golden_path('ref_karate_HOPE.txt'))                    # tests/karate_res/HOPE.txt
+    assert np.allclose(np.abs(X), np.abs(gold))                              # allclose as tests/test_karate.py:76, mod ARPACK signs
+    assert np.allclose(hope_oracle.align_signs(X, gold, 4), gold)
+    fresh = np.load(golden_path('hope_karate_d4.npz'))['X']
+    assert np.allclose(hope_oracle.align_signs(X, fresh, 4), fresh)
+
+
+def test_dense_and_operator_oracles_reproduce_reference_on_sbm(sbm1024):
+    n, src, dst, w, order = edge_arrays(sbm1024)
+    assert order is None
+    A = hope_oracle.adjacency(n, src, dst, w)
+    gold = np.load(golden_path('hope_sbm1024_d32.npz'))['X']
+    sv = np.load(golden_path('hope_sbm1024_sigma.npy'))
+    X, s = hope_oracle.hope_dense(A, 0.01, 32)
+    assert np.allclose(s[::-1], sv[:16], rtol=1e-10)
+    assert np.allclose(hope_oracle.align_signs(X, gold, 32), gold, atol=1e-6)
+    Xo, so = hope_oracle.hope_operator(A, 0.01, 32)
+    assert np.allclose(so, s, rtol=1e-9)
+    assert np.allclose(hope_oracle.align_signs(Xo, gold, 32), gold, atol=1e-6)
