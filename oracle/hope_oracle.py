@@ -59,6 +59,40 @@ def hope_operator(A, beta, d, tol=0, ncv=None):
     return np.concatenate((u * np.sqrt(s), vt.T * np.sqrt(s)), axis=1), s
 
 
+def hope_operator_series(A, beta, d, tol=0, ncv=None, series_tol=1e-15):
+    """Same SVD, S applied through its Katz series S x = sum_{t>=1} (beta A)^t x (converges when
+    beta*rho(A) < 1), i.e. sparse mat-vecs only: the practical CPU baseline at n >= 1e4, where the sparse LU
+    of (I - beta A) fills in almost completely for these random graphs."""
+    A = sp.csr_matrix(A, dtype=np.float64)
+    n = A.shape[0]
+    At = A.T.tocsr()
+    x = np.ones(n) / np.sqrt(n)
+    for _ in range(50):
+        x = At @ (A @ x); nx = np.linalg.norm(x); x /= nx
+    br = beta * np.sqrt(nx) * 1.05
+    if not br < 1:
+        raise ValueError('Katz series diverges: beta*sigma_max(A) = %.3f' % br)
+    terms = int(np.ceil(np.log(series_tol) / np.log(br)))
+
+    def mv(x):
+        w = beta * (A @ x); z = w
+        for _ in range(terms):
+            z = w + beta * (A @ z)
+        return z
+
+    def rmv(y):
+        r = y
+        for _ in range(terms):
+            r = y + beta * (At @ r)
+        return beta * (At @ r)
+    op = sla.LinearOperator((n, n), matvec=mv, rmatvec=rmv, dtype=np.float64)
+    k = d // 2
+    u, s, vt = sla.svds(op, k=k, tol=tol, ncv=ncv)
+    order = np.argsort(s)
+    u, s, vt = u[:, order], s[order], vt[order]
+    return np.concatenate((u * np.sqrt(s), vt.T * np.sqrt(s)), axis=1), s
+
+
 def align_signs(X, Xref, d):
     """Flip singular-vector pairs of X to the signs of Xref (pair j = columns j and k+j)."""
     k = d // 2
