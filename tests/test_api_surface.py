@@ -48,3 +48,30 @@ def test_reconstructed_adj_sets_embedding_and_zero_diagonal():
     assert A[0, 2] == pytest.approx(np.dot(X[0, :2], X[2, 2:]))
     A2 = m.get_reconstructed_adj(X, node_l=[2, 0])
     assert A2.shape == (2, 2) and A2[0, 1] == pytest.approx(np.dot(X[2, :2], X[0, 2:]))
+
+
+def test_gem_alias_paths():
+    """GEM's own import paths resolve to the HIP-backed classes (examples/run_karate.py:9-17 style imports)."""
+    from gem.embedding.hope import HOPE as H2
+    from gem.embedding.gf import GraphFactorization as G2
+    from gem.embedding.node2vec import node2vec as N2
+    from gem.evaluation import evaluate_graph_reconstruction as gr
+    from gem.utils import graph_util
+    assert (H2, G2, N2) == (HOPE, GraphFactorization, node2vec)
+    assert callable(gr.evaluateStaticGraphReconstruction) and callable(graph_util.loadGraphFromEdgeListTxt)
+
+
+def test_wire_formats_roundtrip(tmp_path, karate):
+    """graph_util.py:129-169: header n/m + '%d %d %f' ; headerless n2v list ; 'n d' + 'id v..' embedding."""
+    from gem_amd.utils import graph_util
+    f = str(tmp_path / 'g.txt')
+    graph_util.saveGraphToEdgeListTxt(karate, f)
+    lines = open(f).read().split('\n')
+    assert lines[0] == '34' and lines[1] == '77' and lines[2] == '0 31 1.000000'
+    graph_util.saveGraphToEdgeListTxtn2v(karate, f)
+    G = graph_util.loadGraphFromEdgeListTxt(f, directed=True)
+    assert sorted(G.edges()) == sorted(karate.edges())
+    with open(f, 'w') as fh:
+        fh.write('3 2\n2 0.5 1.5\n0 1 2\n')
+    X = graph_util.loadEmbedding(f)
+    assert X.shape == (3, 2) and X[2, 1] == 1.5 and X[1, 0] == 0.0

@@ -1,0 +1,131 @@
+"""CPU tests of the N>1 path (gem_amd/multi_gpu.py) with world_size=2 over gloo.  The sharding and
+exchange logic is the production code; the per-rank compute is a stand-in backend built on the CPU
+oracle (tests may use the oracle), so what is verified is: the row/walk partition, the all-gather
+of owned GF row blocks, the vocabulary all-reduce, and the delta-sum exchange of the SGNS tables."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from gem_amd import multi_gpu
+from gem_amd.graph import edge_arrays, sbm_graph
+from conftest import load_sbm1024
+
+SNAP = 11
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+class OracleGF(object):
+    def __init__(self, n, src, dst, d, r0, r1, X0):
+        own = (src >= r0) & (src < r1)
+        self.n, self.d, self.src, self.dst = n, d, src[own], dst[own]
+        self.X = [torch.from_numpy(X0.copy()), torch.from_numpy(X0.copy())]
+        self.cur = 0
+        self.r0, self.r1 = r0, r1
+
+    def sweep(self, eta, regu):
+        old = self.X[self.cur].numpy()
+        new = oracle.gf_train_f32(self.n, self.src, self.dst, None, self.d, eta, regu, 1, old[:self.n])
+        out = self.X[self.cur ^ 1]
+        out.numpy()[:self.n] = new
+        self.cur ^= 1
+        return out
+
+
+class OracleN2V(object):
+    def __init__(self, n, src, dst, d):
+        self.n, self.d = n, d
+        self.row_ptr, self.col, _ = oracle.sorted_csr(n, src, dst, None)
+
+    def walks(self, p, q, num_walks, walk_len, seed, flags, lo, hi):
+        self.w = oracle.n2v_walks(self.row_ptr, self.col, None, None, p, q, num_walks, walk_len, seed, flags, lo, hi)
+        self.lo = lo
+
+    def vocab(self):
+        self.counts = torch.from_numpy(oracle.n2v_vocab(self.n, self.w))
+        return self.counts
+
+    def build_unigram(self):
+        self.UT, self.KT = oracle.unigram_build(self.counts.numpy())
+
+    def init_tables(self, seed):
+        P, N = oracle.sgns_init(self.n, self.d, seed)
+        self.P, self.N = torch.from_numpy(P), torch.from_numpy(N)
+        return self.P, self.N
+
+    def train(self, window, epochs, epoch, lo, hi, tokens_total, token_offset, seed, flags):
+        if hi > lo:
+            oracle.sgns_train(self.w[lo:hi], window, 0.025, epochs, epoch, tokens_total, token_offset + lo * self.w.shape[1],
+                              self.lo + lo, self.UT, self.KT, seed, flags, self.P.numpy(), self.N.numpy())
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    comm = multi_gpu.TorchComm(world)
+    # ---- GF: sharded sweeps == the single-process sequential reference loop
+    g = sbm_graph(1001, 10000, 4, seed=3)               # n not divisible by world: exercises the padding
+    n, src, dst, w, _ = edge_arrays(g)
+    X0 = (0.1 * np.random.RandomState(0).randn(n, 8)).astype(np.float32)
+    n_pad = (n + world - 1) // world * world
+    X0p = np.zeros((n_pad, 8), np.float32); X0p[:n] = X0
+    job = multi_gpu.GFSharded(None, comm, rank, world, n)
+    job.b = OracleGF(n, src, dst, 8, job.r0, job.r1, X0p)
+    for _ in range(3):
+        last = job.sweep(0.05, 0.01)
+    ref = oracle.gf_train_f32(n, src, dst, None, 8, 0.05, 0.01, 3, X0)
+    ok_gf = bool(np.array_equal(last.numpy()[:n], ref))
+    # ---- node2vec: counts all-reduce, identical tables on all ranks, quality preserved
+    G = load_sbm1024()
+    n, src, dst, w, _ = edge_arrays(G)
+    b = OracleN2V(n, src, dst, 16)
+    job = multi_gpu.Node2VecSharded(b, comm, rank, world, n, 10, 80, 10, 1, seed=5, flags=SNAP, sync_chunks=8)
+    P = job.run(1.0, 1.0)
+    full_counts = oracle.n2v_vocab(n, oracle.n2v_walks(b.row_ptr, b.col, None, None, 1.0, 1.0, 10, 80, 5, SNAP))
+    ok_counts = bool(np.array_equal(b.counts.numpy(), full_counts))
+    gathered = [torch.zeros_like(P) for _ in range(world)]
+    dist.all_gather(gathered, P)
+    ok_same = all(bool(torch.equal(gathered[0], t)) for t in gathered)
+    if rank == 0:
+        np.save(out, P.numpy())
+        with open(out + '.flags', 'w') as fh:
+            fh.write('%d %d %d %d %d' % (ok_gf, ok_counts, ok_same, job.lo, job.hi))
+    dist.destroy_process_group()
+
+
+def test_world2_gloo(tmp_path, sbm1024):
+    out = str(tmp_path / 'P.npy')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ok_gf, ok_counts, ok_same, lo, hi = (int(x) for x in open(out + '.flags').read().split())
+    assert ok_gf, 'sharded GF sweeps differ from the sequential reference loop'
+    assert ok_counts, 'vocabulary all-reduce wrong'
+    assert ok_same, 'ranks ended with different tables'
+    assert (lo, hi) == (0, 5120)
+    from gem_amd.embedding.node2vec import node2vec
+    from gem_amd.evaluation import reconstruction as gr
+    P = np.load(out).astype(np.float64)
+    m = node2vec(d=16, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
+    MAP = gr.evaluateStaticGraphReconstruction(sbm1024, m, P, None)[0]
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    Xs, _ = oracle.n2v_train(n, src, dst, w, 16, 80, 10, 10, 1, 1.0, 1.0, 5, SNAP)
+    MAPs = gr.evaluateStaticGraphReconstruction(sbm1024, m, Xs.astype(np.float64), None)[0]
+    assert abs(MAP - MAPs) <= 0.05 * MAPs, (MAP, MAPs)          # delta-sum exchange keeps the sequential quality
+
+
+def test_world1_is_the_plain_pipeline(sbm1024):
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    b = OracleN2V(n, src, dst, 8)
+    job = multi_gpu.Node2VecSharded(b, multi_gpu.TorchComm(1), 0, 1, n, 2, 20, 5, 1, seed=9, flags=SNAP, sync_chunks=8)
+    P = job.run(1.0, 1.0).numpy()
+    ref, _ = oracle.n2v_train(n, src, dst, w, 8, 20, 2, 5, 1, 1.0, 1.0, 9, SNAP)
+    assert np.array_equal(P, ref)
+    assert multi_gpu.shard_range(10, 0, 3) == (0, 3) and multi_gpu.shard_range(10, 2, 3) == (6, 10)
