@@ -39,6 +39,20 @@ from gem_amd.graph import sbm_graph, edge_arrays, to_csr
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
 
 
+def pmc_traffic(kernel, key):
+    """HBM bytes per unit measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/*_pmc_traffic.json,
+    corrected as MI355X_MICROARCH.md prescribes); bench.py scales it to the units one launch processes."""
+    best = None
+    pdir = os.path.join(ROOT, 'profiles')
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith('_pmc_traffic.json'):
+            try:
+                best = json.load(open(os.path.join(pdir, f)))[kernel][key]
+            except (KeyError, ValueError):
+                pass
+    return best
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -85,8 +99,10 @@ class GFWorkload(object):
         algo = self.b.algo_bytes / self.b.levels        # 1548 B x updates
         compulsory = (self.b.rows * 2 * 4 * self.d + self.b.updates * (4 * self.d + 8)) / self.b.levels
         ach = algo / avg_s / 1e9
+        per_upd = pmc_traffic(self.kernel, 'traffic_bytes_per_update')
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': None, 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
+                'traffic': None if per_upd is None else per_upd * self.b.updates / self.b.levels,
+                'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
                 'note': 'algorithmic = 1548 B/update (X_i r+w, X_j r per update); the kernel keeps X_i in registers for a whole row, '
                         'so its compulsory HBM bytes are %.3g per launch = %.0f GB/s' % (compulsory, compulsory / avg_s / 1e9)}
 
@@ -151,8 +167,9 @@ class N2VWorkload(object):
         algo = (14 * 4 * self.args.d + 24) * pairs / launches       # 14*4d B per (centre,context) pair + ids
         ach = algo / avg_s / 1e9
         tokens = (self.job.hi - self.job.lo) * self.args.walk_len
+        per_pair = pmc_traffic(self.kernel, 'traffic_bytes_per_pair')
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': None, 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
+                'traffic': None if per_pair is None else per_pair * pairs / launches, 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
                 'pairs_per_launch': pairs / launches, 'tokens_per_launch': tokens,
                 'sgns_fraction_of_step': ms / dev_ms_total,
                 'note': 'algorithmic = 7168+24 B per (centre,context) pair at d=128 (SynPos r+w, 6 x SynNeg r+w); the kernel keeps the '
@@ -167,7 +184,7 @@ class N2VWorkload(object):
         a = self.args
         n_s = 2048            # SNAP needs ~11 s for 1024 nodes on 8 cores: keep the sample ~20-30 s
         gs = sbm_graph(n_s, n_s * (a.edges // a.nodes), max(1, n_s // (a.nodes // a.blocks)), seed=7)
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 16)    # SNAP's dynamic OpenMP loop gets SLOWER beyond a few threads on small graphs
         if os.path.exists(oracle.REF_N2V):
             tmp = tempfile.mkdtemp()
             gf = os.path.join(tmp, 'g.graph')
