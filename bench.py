@@ -227,7 +227,7 @@ class HopeWorkload(object):
         self.row_ptr, self.col, _ = to_csr(n, src, dst, None)
         self.k = args.d // 2
         self.U = np.empty((n, self.k), np.float32); self.V = np.empty((n, self.k), np.float32); self.sig = np.empty(self.k, np.float32)
-        self.stats = (C.c_double * 8)()
+        self.stats = (C.c_double * 12)()
         self.dev_s, self.spmm, self.spmm_cols, self.calls = 0.0, 0.0, 0.0, 0
 
     def reset_counters(self):

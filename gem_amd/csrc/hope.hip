@@ -21,6 +21,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 
 using namespace gemhip;
 
@@ -193,11 +194,22 @@ __global__ void hope_randn_kernel(float *X, int64_t n, int b, int ld, uint64_t s
 // Householder tridiagonalisation + implicit-shift QL (the classical EISPACK tred2/tql2 pair).
 // A (n x n, row-major, symmetric) is overwritten by the eigenvectors (columns); w gets the
 // eigenvalues in ASCENDING order.
+void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d);
+double g_eig_seconds = 0.0, g_eig_calls = 0.0;
 void sym_eig(int n, std::vector<double> &V, std::vector<double> &d)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    sym_eig_impl(n, V, d);
+    g_eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_eig_calls += 1.0;
+}
+void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
 {
     std::vector<double> e(n, 0.0);
     d.assign(n, 0.0);
-    auto A = [&](int i, int j) -> double & { return V[(size_t)i * n + j]; };
+    // column-major accessor: every O(n^3) loop below runs over the FIRST index, i.e. contiguous memory
+    // (the input is symmetric, so its layout does not matter; the result is transposed back at the end)
+    auto A = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
     for (int j = 0; j < n; ++j) d[j] = A(n - 1, j);
     for (int i = n - 1; i > 0; --i) {
         double scale = 0.0, h = 0.0;
@@ -309,6 +321,8 @@ void sym_eig(int n, std::vector<double> &V, std::vector<double> &d)
             for (int j = 0; j < n; ++j) std::swap(A(j, i), A(j, k));
         }
     }
+    for (int i = 0; i < n; ++i)                              // back to row-major: V[i*n + j] = component i of eigenvector j
+        for (int j = i + 1; j < n; ++j) std::swap(V[(size_t)i * n + j], V[(size_t)j * n + i]);
 }
 
 // ---------------------------------------------------------------------- solver state
@@ -322,7 +336,7 @@ struct Hope {
     double *G = nullptr; size_t G_elems = 0;         // device fp64 Gram
     float *Csmall = nullptr; size_t C_elems = 0;     // device small matrix for tsgemm
     hipStream_t s = nullptr;
-    double spmm_count = 0, spmm_cols = 0;            // statistics
+    double spmm_count = 0, spmm_cols = 0, eig_seconds = 0, eig_calls = 0;   // statistics
     int err = 0;
     ~Hope()
     {
@@ -351,7 +365,11 @@ void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int
     Gh.assign((size_t)m1 * m2, 0.0);
     if (H.err || m1 == 0 || m2 == 0) return;
     const int t1 = (m1 + 31) / 32, t2 = (m2 + 31) / 32, m1p = t1 * 32, m2p = t2 * 32;
-    const int64_t rows_per_slab = 4096;
+    const int ntiles_ = t1 * t2;
+    // aim at ~8192 wavefronts (256 CUs x 32) whatever the tile count: slab partials stay ~32 MB
+    int64_t want_slabs = std::max<int64_t>(1, 8192 / ntiles_);
+    int64_t rows_per_slab = std::max<int64_t>(64, (H.n + want_slabs - 1) / want_slabs);
+    rows_per_slab = (rows_per_slab + 7) / 8 * 8;
     const int nslabs = (int)((H.n + rows_per_slab - 1) / rows_per_slab);
     const size_t need = (size_t)nslabs * m1p * m2p * sizeof(float);
     if (need > H.P_bytes) { hipFree(H.P); H.P = nullptr; H.P_bytes = 0; HOPE_TRY(H, hipMalloc((void **)&H.P, need)); if (!H.err) H.P_bytes = need; }
@@ -381,25 +399,62 @@ void tsgemm(Hope &H, const float *X, int ldx, int m, const std::vector<double> &
                        ldo, ct);
 }
 
-// Orthonormalise the b columns of Y (n x b, ld) into Out via the Gram eigen-decomposition
-// Y <- Y W L^-1/2, dropping directions with relative energy below `tol` (rank revealing), twice.
+// Upper-triangular Cholesky G = R^T R in fp64 with a pivot floor; on success C = R^-1 (so that (Y C)^T (Y C) = I).
+// Returns false when a pivot falls below the floor (rank deficient or ill conditioned block): the caller then
+// takes the rank-revealing eigen path.
+bool chol_inverse(int b, const std::vector<double> &G, double floor, std::vector<double> &C)
+{
+    std::vector<double> R((size_t)b * b, 0.0);
+    for (int j = 0; j < b; ++j) {
+        double djj = G[(size_t)j * b + j];
+        for (int k = 0; k < j; ++k) djj -= R[(size_t)k * b + j] * R[(size_t)k * b + j];
+        if (!(djj > floor)) return false;
+        const double rjj = std::sqrt(djj);
+        R[(size_t)j * b + j] = rjj;
+        for (int i = j + 1; i < b; ++i) {
+            double v = G[(size_t)j * b + i];
+            for (int k = 0; k < j; ++k) v -= R[(size_t)k * b + j] * R[(size_t)k * b + i];
+            R[(size_t)j * b + i] = v / rjj;
+        }
+    }
+    C.assign((size_t)b * b, 0.0);                           // back substitution: R C = I, C upper triangular
+    for (int j = 0; j < b; ++j) {
+        C[(size_t)j * b + j] = 1.0 / R[(size_t)j * b + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double v = 0.0;
+            for (int k = i + 1; k <= j; ++k) v += R[(size_t)i * b + k] * C[(size_t)k * b + j];
+            C[(size_t)i * b + j] = -v / R[(size_t)i * b + i];
+        }
+    }
+    return true;
+}
+
+// Orthonormalise the b columns of Y (n x b, ld) in place (Tmp = scratch).  Well-conditioned blocks take a
+// CholeskyQR step (Y <- Y R^-1); otherwise the Gram eigen-decomposition Y <- Y W L^-1/2 drops directions whose
+// relative energy is below `tol` or whose absolute energy is below `abs_floor` (rank revealing).  Two passes.
 // Returns the number of columns kept.
 int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, double abs_floor = 0.0)
 {
     int keep = b;
     for (int pass = 0; pass < 2 && keep > 0 && !H.err; ++pass) {
-        std::vector<double> G, w;
+        std::vector<double> G, w, C;
         gram(H, Y, ld, keep, Y, ld, keep, G);
         if (H.err) return 0;
-        sym_eig(keep, G, w);                                  // ascending; G columns = eigenvectors
-        const double lmax = std::max(w[keep - 1], 0.0);
-        int first = 0;
-        while (first < keep && !(w[first] > tol * lmax && w[first] > abs_floor && w[first] > 0.0)) ++first;
-        const int nk = keep - first;
-        if (nk == 0) return 0;
-        std::vector<double> C((size_t)keep * nk);
-        for (int i = 0; i < keep; ++i)
-            for (int j = 0; j < nk; ++j) C[(size_t)i * nk + j] = G[(size_t)i * keep + (keep - 1 - j)] / std::sqrt(w[keep - 1 - j]);
+        double dmax = 0.0;
+        for (int i = 0; i < keep; ++i) dmax = std::max(dmax, G[(size_t)i * keep + i]);
+        int nk = keep;
+        // Cholesky pivots are Schur complements: a pivot below 1e-4 * dmax means condition > ~1e4 (or rank loss)
+        if (!chol_inverse(keep, G, std::max(1e-4 * dmax, abs_floor), C)) {
+            sym_eig(keep, G, w);                                  // ascending; G columns = eigenvectors
+            const double lmax = std::max(w[keep - 1], 0.0);
+            int first = 0;
+            while (first < keep && !(w[first] > tol * lmax && w[first] > abs_floor && w[first] > 0.0)) ++first;
+            nk = keep - first;
+            if (nk == 0) return 0;
+            C.assign((size_t)keep * nk, 0.0);
+            for (int i = 0; i < keep; ++i)
+                for (int j = 0; j < nk; ++j) C[(size_t)i * nk + j] = G[(size_t)i * keep + (keep - 1 - j)] / std::sqrt(w[keep - 1 - j]);
+        }
         tsgemm(H, Y, ld, keep, C, nk, 1.0f, nullptr, 0, Tmp, ldt);
         HOPE_TRY(H, hipMemcpy2DAsync(Y, (size_t)ld * sizeof(float), Tmp, (size_t)ldt * sizeof(float), (size_t)nk * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
         keep = nk;
@@ -454,6 +509,7 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "hope: row_ptr inconsistent with nnz");
     Hope H;
     H.n = n; H.nnz = nnz; H.beta = beta;
+    g_eig_seconds = 0.0; g_eig_calls = 0.0;
     // transpose on the host (counting sort), values default to 1
     std::vector<int64_t> rpT(n + 1, 0);
     std::vector<int32_t> ciT(std::max<int64_t>(nnz, 1));
@@ -563,7 +619,7 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
             };
             project(prev_b);
             project(prev_b);
-            int nb = orth(H, W0, ldb, prev_b, Tmp, ldm, 1e-9, 1e-8 * ref_energy);
+            int nb = orth(H, W0, ldb, prev_b, Tmp, ldm, 1e-11, 1e-12 * ref_energy);
             if (nb > 0) {
                 project(nb);
                 nb = orth(H, W0, ldb, nb, Tmp, ldm, 1e-9, 0.25);      // unit columns: drop what lost half its norm
@@ -627,7 +683,7 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
     if (stats && !H.err) {
         stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = terms; stats[4] = mc; stats[5] = restarts_done;
-        stats[6] = last_change; stats[7] = br;
+        stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = 0; stats[11] = 0;
     }
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);

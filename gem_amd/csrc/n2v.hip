@@ -257,6 +257,30 @@ __device__ __forceinline__ void st_row(float *p, int d, int lane, int c, const f
     }
 }
 
+// d == 128 WIDE variant (opt-in, flag 32; measured 15 % SLOWER than the 8-byte path on MI355X, kept for A/B): one embedding row is 512 B = 32 lanes x 16 B.  Lanes 0-31 move the row with ONE
+// 16-byte-per-lane sc1 buffer access (the widest, cheapest coherent access: an 8-byte sc1 store costs ~2.7x
+// per byte, MI355X_MICROARCH.md "stores of each flavour"), and two v_permlane32_swap spread it over the 64 lanes
+// as float2: lane l < 32 holds elements (4l, 4l+1), lane 32+l holds (4l+2, 4l+3).
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void ld_row_wide(__amdgpu_buffer_rsrc_t rs, int64_t row, int lane, float (&v)[2])
+{
+    u32x4v t = {0u, 0u, 0u, 0u};
+    if (lane < 32) t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((uint32_t)row * 512u + (uint32_t)lane * 16u), 0, 16 /* sc1 */);
+    const u32x2v a = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
+    const u32x2v b = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
+    v[0] = __builtin_bit_cast(float, a.x);
+    v[1] = __builtin_bit_cast(float, b.x);
+}
+__device__ __forceinline__ void st_row_wide(__amdgpu_buffer_rsrc_t rs, int64_t row, int lane, const float (&v)[2])
+{
+    const u32x2v a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, v[0]), 0u, false, false);
+    const u32x2v b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, v[1]), 0u, false, false);
+    const u32x4v o = {a.x, b.x, a.y, b.y};
+    if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(o, rs, (int)((uint32_t)row * 512u + (uint32_t)lane * 16u), 0, 16 /* sc1 */);
+}
+
 struct SgnsArgs {
     const int32_t *walks; int64_t walk_lo, walk_hi; int32_t walk_len; int32_t window;
     float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
@@ -277,9 +301,12 @@ __device__ __forceinline__ float sgns_grad(float f, float label, float alpha)
 // stays in registers across all its contexts; per context the context row and the five
 // negative rows are fetched together (6 coalesced 4d-byte reads in flight), reduced with
 // DPP wave sums, and written back.  Hogwild across wavefronts, exactly sequential inside one.
-template <int VEC, int NV>
+template <int VEC, int NV, bool WIDE>
 __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 {
+    static_assert(!WIDE || (VEC == 2 && NV == 1), "wide path is d == 128 only");
+    __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(A.SynPos, 0, WIDE ? (int)((uint32_t)A.n * 512u) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(A.SynNeg, 0, WIDE ? (int)((uint32_t)A.n * 512u) : 0, 0x00020000);
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -326,8 +353,10 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 
             float yp[NV][VEC];                               // SynNeg[word]: positive target of every context of this centre
             float *pp = A.SynNeg + (int64_t)word * d;
+            if constexpr (WIDE) ld_row_wide(rsN, word, lane, yp[0]);
+            else
 #pragma unroll
-            for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
+                for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
 
             for (int a = b; a < 2 * win + 1 - b; ++a) {
                 if (a == win) continue;
@@ -343,13 +372,17 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 
                 float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
                 float *pc = A.SynPos + (int64_t)ctx * d;
+                if constexpr (WIDE) ld_row_wide(rsP, ctx, lane, xc[0]);
+                else
 #pragma unroll
-                for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
+                    for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
 #pragma unroll
                 for (int j = 0; j < SGNS_NEG; ++j) {
                     const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+                    if constexpr (WIDE) ld_row_wide(rsN, tgt[j], lane, yn[j][0]);
+                    else
 #pragma unroll
-                    for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
+                        for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
                 }
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
@@ -391,18 +424,23 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yn[j][c][v]; yn[j][c][v] += g * xc[c][v]; }
                     float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+                    if constexpr (WIDE) st_row_wide(rsN, tgt[j], lane, yn[j][0]);
+                    else
 #pragma unroll
-                    for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+                        for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
                 }
 #pragma unroll
                 for (int c = 0; c < NV; ++c) {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
-                    st_row<VEC>(pc, d, lane, c, xc[c]);
+                    if constexpr (!WIDE) st_row<VEC>(pc, d, lane, c, xc[c]);
                 }
+                if constexpr (WIDE) st_row_wide(rsP, ctx, lane, xc[0]);
             }
+            if constexpr (WIDE) st_row_wide(rsN, word, lane, yp[0]);
+            else
 #pragma unroll
-            for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
+                for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -410,13 +448,14 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 }
 
 using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
-template <int VEC, int NV>
+template <int VEC, int NV, bool WIDE = false>
 void launch_sgns(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
 {
-    hipLaunchKernelGGL((sgns_kernel<VEC, NV>), dim3(blocks), dim3(threads), lds, s, A);
+    hipLaunchKernelGGL((sgns_kernel<VEC, NV, WIDE>), dim3(blocks), dim3(threads), lds, s, A);
 }
-sgns_fn pick_sgns(int d)
+sgns_fn pick_sgns(int d, int64_t n = 0, bool allow_wide = false)
 {
+    if (allow_wide && d == 128 && n > 0 && n * 512 < ((int64_t)1 << 32)) return launch_sgns<2, 1, true>;
     if (d % 2 == 0) {
         const int nv = (d + 127) / 128;
         if (nv <= 1) return launch_sgns<2, 1>;
@@ -756,16 +795,16 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
         // time; when (waves x 7) approaches n, concurrent writers overwrite each other's updates and the
         // embedding degrades (measured: tests/test_n2v_gpu.py).  Cap the number of concurrent
         // wavefronts at n/HOGWILD_ROWS_PER_WAVE; at BASELINE scale (n >= 1M) the cap is the machine
-        // (256 CUs x 32 waves) and never binds.
+        // (256 CUs x 16 waves) and never binds.
         int64_t cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / HOGWILD_ROWS_PER_WAVE);
-        cap = std::min<int64_t>(cap, 256 * 32);
+        cap = std::min<int64_t>(cap, 256 * 16);          // 16 waves/CU already saturate the fabric (scripts/ab_sgns_waves.py)
         const int64_t waves = std::min<int64_t>(cap, walk_hi - walk_lo);
         blocks = (int)((waves + 3) / 4);
         A.nwaves = (int32_t)waves;
     }
     const size_t lds = per_wave * (threads / 64);
     GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window too large for LDS staging (%zu bytes)", lds);
-    pick_sgns(h->d)(A, blocks, threads, lds, (hipStream_t)stream);
+    pick_sgns(h->d, h->n, (flags & 32) != 0)(A, blocks, threads, lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());
     return GEMHIP_OK;
 }

@@ -22,7 +22,7 @@ def learn(model, graph):
         raise ValueError('HOPE needs 1 <= d//2 < n (scipy svds: k must satisfy 0 < k < min(shape))')
     _hip.require_device()
     U = np.empty((n, k), dtype=np.float32); V = np.empty((n, k), dtype=np.float32); sig = np.empty(k, dtype=np.float32)
-    stats = (C.c_double * 8)()
+    stats = (C.c_double * 12)()
     _hip.check(_hip.lib().gemhip_hope(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), _hip.ptr(ww, C.c_float),
                                       float(model._beta), k, int(getattr(model, '_oversample', 16)),
                                       int(getattr(model, '_krylov_steps', 3)), int(getattr(model, '_max_restarts', 20)),
@@ -30,6 +30,6 @@ def learn(model, graph):
                                       _hip.ptr(U, C.c_float), _hip.ptr(V, C.c_float), _hip.ptr(sig, C.c_float), stats))
     model._sigma = sig.astype(np.float64)
     model._stats = dict(zip(('device_seconds', 'spmm_launches', 'spmm_columns', 'katz_terms', 'basis_columns', 'restarts',
-                             'last_sigma_change', 'beta_sigma_max'), list(stats)))
+                             'last_sigma_change', 'beta_sigma_max', 'host_eig_seconds', 'host_eig_calls'), list(stats)))
     model._node_num = n
     return np.concatenate((U, V), axis=1).astype(np.float64)

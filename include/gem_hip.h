@@ -125,6 +125,7 @@ int gemhip_gf_objective(int64_t n, int64_t m, const int32_t *src,
 #define GEMHIP_N2V_DETERMINISTIC 4
 #define GEMHIP_N2V_UNIFORM_FIRST_HOP 8
 #define GEMHIP_N2V_SNAP_COMPAT 11
+#define GEMHIP_N2V_WIDE_ROWS 32 /* A/B switch (d == 128): 16-byte sc1 buffer accesses from half a wave + v_permlane32_swap; measured slower than the default 8-byte path */
 
 typedef struct gemhip_n2v *gemhip_n2v_t;
 
@@ -169,7 +170,7 @@ int gemhip_sgns_init(gemhip_n2v_t h, int32_t d, uint64_t seed, void *dSynPos, vo
 /* (centre, context) pairs trained since creation / the last reset -- the unit of SURVEY 8(d)'s
  * SGNS byte count (14*4d bytes per pair). */
 int gemhip_sgns_pairs(gemhip_n2v_t h, int64_t *pairs, int32_t reset);
-/* Cap on concurrently training wavefronts (Hogwild width).  0 = auto: min(machine, n/128),
+/* Cap on concurrently training wavefronts (Hogwild width).  0 = auto: min(4096, n/128),
  * which keeps lost updates negligible on small graphs and never binds at n >= 1M. */
 int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves);
 int gemhip_sgns_set_tables(gemhip_n2v_t h, const float *SynPos_host, const float *SynNeg_host);
@@ -192,8 +193,9 @@ int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0,
  *   sigma [k] ASCENDING like svds (hope.py:33).  Column signs: largest |entry| of each u positive.
  * Solver knobs: oversample (block = k + oversample columns), krylov_steps (blocks per cycle),
  * max_restarts, tol (max relative change of the k singular values between cycles).
- * stats (optional, 8 doubles): {device_seconds, spmm_launches, spmm_columns_total, katz_terms,
- * basis_columns, restarts_done, last_sigma_change, beta*sigma_max(A) estimate}.
+ * stats (optional, 12 doubles): {device_seconds, spmm_launches, spmm_columns_total, katz_terms,
+ * basis_columns, restarts_done, last_sigma_change, beta*sigma_max(A) estimate, host_eig_seconds,
+ * host_eig_calls, 0, 0}.
  * Returns GEMHIP_E_NOTCONVERGED when beta*sigma_max(A) >= 0.95 (Katz series too slow). */
 int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
                 float beta, int32_t k, int32_t oversample, int32_t krylov_steps,

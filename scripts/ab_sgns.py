@@ -1,0 +1,21 @@
+"""A/B of SGNS kernel variants on SBM 1M/10M d=128 with r walks per node (bench-equivalent, shorter)."""
+import sys, time, ctypes as C
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+from gem_amd import _hip, multi_gpu
+from gem_amd.graph import sbm_graph, edge_arrays, to_csr
+r = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+variants = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [11, 11 | 32]
+g = sbm_graph(1000000, 10000000, 100, seed=20260927)
+n, src, dst, w, _ = edge_arrays(g)
+row_ptr, col, ww = to_csr(n, src, dst, w)
+b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, 128)
+b.walks(1.0, 1.0, r, 80, 1, 11, 0, n * r); b.vocab(); b.build_unigram()
+for rep in range(2):
+    for flags in variants:
+        b.init_tables(1); b.pairs(reset=True)
+        torch.cuda.synchronize(); t = time.time()
+        b.train(10, 1, 0, 0, n * r, n * r * 80, 0, 1, flags)
+        torch.cuda.synchronize(); el = time.time() - t
+        pairs = b.pairs()
+        print('flags', flags, 'sgns %.3f s' % el, 'algorithmic TB/s %.3f' % (pairs * 7192 / el / 1e12), 'absmax', float(b.P.abs().max()), flush=True)

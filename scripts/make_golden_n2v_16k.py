@@ -25,7 +25,14 @@ for thr in ('1', '8'):
                      '-l:%d' % PARAMS['walk_len'], '-r:%d' % PARAMS['num_walks'], '-k:%d' % PARAMS['window'], '-e:1', '-p:1.000000',
                      '-q:1.000000', '-dr', '-w'], stdout=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS=thr))
     el = time.time() - t
-    X = graph_util.loadEmbedding(os.path.join(tmp, 'g.emb'))
+    # isolated nodes never reach the binary: its header counts only the nodes it saw, and GEM's loadEmbedding
+    # (graph_util.py:161-169) would index out of bounds; place rows by id into an (n, d) array instead
+    X = np.zeros((PARAMS['n'], PARAMS['d']))
+    with open(os.path.join(tmp, 'g.emb')) as fh:
+        fh.readline()
+        for line in fh:
+            tok = line.split()
+            X[int(tok[0])] = [float(v) for v in tok[1:]]
     m = node2vec(d=PARAMS['d'], max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
     MAP = gr.evaluateStaticGraphReconstruction(g, m, X, None)[0]
     out['t' + thr] = {'MAP': MAP, 'seconds': el, 'edges_per_s': g.number_of_edges() / el}

@@ -1,0 +1,44 @@
+"""GPU parity on a power-law (R-MAT) graph -- hub rows far longer than a wavefront chunk, the shape of
+BASELINE configs[4] (R-MAT scale-22) at test size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from gem_amd import _hip
+from gem_amd.graph import edge_arrays, rmat_graph
+from test_gf_gpu import hip_train, assert_close
+from test_n2v_gpu import Dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def rmat():
+    g = rmat_graph(13, 160000, seed=20260928)
+    n, src, dst, w, _ = edge_arrays(g)
+    deg = np.bincount(src, minlength=n)
+    assert deg.max() > 500 and (deg == 0).sum() > 100          # hubs and isolated nodes
+    return g
+
+
+def test_gf_on_hub_rows(rmat):
+    n, src, dst, w, _ = edge_arrays(rmat)
+    X0 = 0.05 * np.random.RandomState(1).randn(n, 128)
+    X, stats = hip_train(n, src, dst, w, 128, 0.002, 0.01, 4, X0)
+    assert_close(X, oracle.gf_train_f32(n, src, dst, w, 128, 0.002, 0.01, 4, X0))
+
+
+def test_walks_weighted_second_order_on_hubs(rmat):
+    n, src, dst, _, _ = edge_arrays(rmat)
+    w = (np.random.RandomState(2).rand(len(src)) + 0.25).astype(np.float32)
+    dev = Dev(n, src, dst, w)
+    row_ptr, col, ww = oracle.sorted_csr(n, src, dst, w)
+    U, K = oracle.n2v_alias_rows(row_ptr, ww)
+    for p, q in ((1.0, 1.0), (0.5, 2.0)):
+        got = dev.walks(p, q, 2, 40, 17, 11)
+        assert np.array_equal(got, oracle.n2v_walks(row_ptr, col, U, K, p, q, 2, 40, 17, 11))
+    c, UT, KT = dev.unigram()
+    assert np.array_equal(c, oracle.n2v_vocab(n, got))
+    dev.close()
