@@ -301,11 +301,16 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    local = local % torch.cuda.device_count()      # (lets the N>1 code path be exercised on a 1-GPU box with GEM_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     _hip.check(_hip.lib().gemhip_set_device(local))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        backend = os.environ.get('GEM_BENCH_BACKEND', 'nccl')          # "nccl" is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         log('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world))
 

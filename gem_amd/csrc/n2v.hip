@@ -80,6 +80,10 @@ struct gemhip_n2v {
     bool own_syn = false;
     int32_t max_waves = 0;            // 0 = auto (see gemhip_sgns_train)
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
+    // per-partition unigram tables (multi-GPU episode schedule): partition p = {v : v % parts == p}, local index v / parts
+    int32_t parts = 0;
+    float *d_UTp = nullptr; int32_t *d_KTp = nullptr;
+    std::vector<int64_t> part_off;           // table p occupies [part_off[p], part_off[p+1])
     bool own_counts = true;
 };
 
@@ -470,6 +474,179 @@ sgns_fn pick_sgns(int d, int64_t n = 0, bool allow_wide = false)
     return nullptr;
 }
 
+
+// ------------------------------------------------------------------ partitioned ("episode") SGNS
+// Multi-GPU schedule (gem_amd/multi_gpu.py): nodes are split into `parts` partitions
+// (v -> v % parts, local row v / parts); the (context, word) pairs TrainModel forms are materialised, bucketed
+// by (part(context), part(word)) and trained bucket by bucket so that no two GPUs ever touch the same row.
+
+// One lane per centre token: emit its (context, word) pairs (same window-shrink draw as sgns_kernel) with a
+// wave-aggregated append (one atomic per wavefront).
+__global__ __launch_bounds__(256) void sgns_emit_pairs_kernel(const int32_t *__restrict__ walks, int64_t walk_lo, int64_t walk_hi, int32_t walk_len,
+                                                              int32_t window, int32_t epoch, int64_t walk_id_offset, uint64_t seed,
+                                                              int2 *__restrict__ out, int64_t cap, unsigned long long *__restrict__ cursor)
+{
+    const int lane = lane_id();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ntok = (walk_hi - walk_lo) * walk_len;
+    int cnt = 0, b = 0, pos = 0;
+    const int32_t *walk = nullptr;
+    int32_t word = -1;
+    if (t < ntok) {
+        const int64_t wl = walk_lo + t / walk_len;
+        pos = (int)(t % walk_len);
+        walk = walks + wl * walk_len;
+        word = walk[pos];
+        if (word >= 0) {
+            const int64_t wid = walk_id_offset + wl;
+            const u32x4 rw = philox4x32_10(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)epoch << 8));
+            b = (int)(rw.x % (uint32_t)window);
+            for (int a = b; a < 2 * window + 1 - b; ++a) {
+                const int cp = pos - window + a;
+                if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) ++cnt;
+            }
+        }
+    }
+    // exclusive prefix of cnt over the wavefront
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const int total = __shfl(incl, WAVE - 1);
+    unsigned long long base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(cursor, (unsigned long long)total);
+    base = ((unsigned long long)__shfl((int)(base >> 32), 0) << 32) | (unsigned int)__shfl((int)(base & 0xffffffffu), 0);
+    int64_t at = (int64_t)base + (incl - cnt);
+    if (cnt > 0) {
+        for (int a = b; a < 2 * window + 1 - b; ++a) {
+            const int cp = pos - window + a;
+            if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) {
+                if (at < cap) out[at] = make_int2(walk[cp], word);
+                ++at;
+            }
+        }
+    }
+}
+
+struct PairArgs {
+    const int2 *pairs; int64_t npairs; int32_t parts; int32_t neg_part; int64_t n_local_neg;
+    const float *UTp; const int32_t *KTp; float alpha_begin, alpha_end; uint64_t seed; uint32_t stream_id; int32_t flags; int32_t d;
+    float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs_done;
+};
+
+// One wavefront per pair at a time: context row (local), positive row and five negative rows of the visiting
+// SynNeg partition; same arithmetic, clamps and duplicate forwarding as sgns_kernel.
+template <int VEC, int NV>
+__global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
+{
+    const int lane = lane_id();
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (gw >= A.nwaves) return;
+    const int d = A.d;
+    const bool quirk = (A.flags & 2) != 0;
+    unsigned long long done = 0;
+    for (int64_t i = gw; i < A.npairs; i += A.nwaves) {
+        const int2 pr = A.pairs[i];
+        const int32_t ctx = __builtin_amdgcn_readfirstlane(pr.x), word = __builtin_amdgcn_readfirstlane(pr.y);
+        const int32_t ctx_l = ctx / A.parts, word_l = word / A.parts;
+        const float alpha = A.alpha_begin + (A.alpha_end - A.alpha_begin) * (float)((double)i / (double)(A.npairs > 1 ? A.npairs : 1));
+        int32_t mine = -1;
+        if (lane >= 1 && lane <= SGNS_NEG) {
+            const u32x4 rn = philox4x32_10(A.seed, (uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.stream_id,
+                                           (uint32_t)TAG_NEG | ((uint32_t)lane << 16) | 0x80000000u);
+            const uint32_t slot = mulhi_range(rn.x, (uint32_t)A.n_local_neg);
+            const int32_t X = quirk ? A.KTp[slot] : (int32_t)slot;
+            mine = (u01(rn.y) < A.UTp[X]) ? X : A.KTp[X];
+        }
+        int32_t tgt[SGNS_NEG];
+#pragma unroll
+        for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readlane(mine, j + 1);
+
+        float xc[NV][VEC], neu[NV][VEC], yp[NV][VEC], yn[SGNS_NEG][NV][VEC];
+        float *pc = A.SynPos + (int64_t)ctx_l * d, *pp = A.SynNeg + (int64_t)word_l * d;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) { ld_row<VEC>(pc, d, lane, c, xc[c]); ld_row<VEC>(pp, d, lane, c, yp[c]); }
+#pragma unroll
+        for (int j = 0; j < SGNS_NEG; ++j) {
+            const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) neu[c][v] = 0.f;
+        {
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) part += xc[c][v] * yp[c][v];
+            const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yp[c][v]; yp[c][v] += g * xc[c][v]; }
+#pragma unroll
+            for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
+        }
+#pragma unroll
+        for (int j = 0; j < SGNS_NEG; ++j) {
+            if (tgt[j] == word_l) continue;
+#pragma unroll
+            for (int jp = 0; jp < j; ++jp)
+                if (tgt[jp] == tgt[j] && tgt[jp] != word_l) {
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) yn[j][c][v] = yn[jp][c][v];
+                }
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) part += xc[c][v] * yn[j][c][v];
+            const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yn[j][c][v]; yn[j][c][v] += g * xc[c][v]; }
+            float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
+            st_row<VEC>(pc, d, lane, c, xc[c]);
+        }
+        ++done;
+    }
+    if (lane == 0 && A.pairs_done) atomicAdd(A.pairs_done, done);
+}
+
+using pairs_fn = void (*)(const PairArgs &, int blocks, int threads, hipStream_t);
+template <int VEC, int NV>
+void launch_pairs(const PairArgs &A, int blocks, int threads, hipStream_t s)
+{
+    hipLaunchKernelGGL((sgns_pairs_kernel<VEC, NV>), dim3(blocks), dim3(threads), 0, s, A);
+}
+pairs_fn pick_pairs(int d)
+{
+    if (d % 2 == 0) {
+        const int nv = (d + 127) / 128;
+        if (nv <= 1) return launch_pairs<2, 1>;
+        if (nv <= 2) return launch_pairs<2, 2>;
+        if (nv <= 4) return launch_pairs<2, 4>;
+        return nullptr;
+    }
+    const int nv = (d + 63) / 64;
+    if (nv <= 1) return launch_pairs<1, 1>;
+    if (nv <= 2) return launch_pairs<1, 2>;
+    if (nv <= 4) return launch_pairs<1, 4>;
+    return nullptr;
+}
+
 uint32_t half_bits(uint64_t n)
 {
     uint32_t bits = 1;
@@ -536,7 +713,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
     if (!h) return GEMHIP_OK;
     hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks);
     if (h->own_counts) hipFree(h->d_counts);
-    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_pairs);
+    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
     delete h;
     return GEMHIP_OK;
@@ -679,18 +856,16 @@ extern "C" int gemhip_n2v_counts_ptr(gemhip_n2v_t h, void **d_counts)
     return GEMHIP_OK;
 }
 
-// InitUnigramTable (ELF @0x40e520): count^0.75, Vose in fp64, stacks popped from the back.
-extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, float *UT_out, int32_t *KT_out)
+
+// InitUnigramTable (ELF @0x40e520) on a count vector: count^0.75, Vose in fp64, stacks popped from the back.
+static bool vose_unigram(const int32_t *cnt, int64_t n, int64_t stride, std::vector<float> &Uf, std::vector<int32_t> &K)
 {
-    GEMHIP_REQUIRE(h, "n2v_build_unigram: NULL handle");
-    GEMHIP_CHECK(hipDeviceSynchronize());
-    const int64_t n = h->n;
-    std::vector<int32_t> cnt(n), K(n, 0), small, large;
-    GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     std::vector<double> U(n);
+    std::vector<int32_t> small, large;
+    K.assign(n, 0);
     double total = 0.0;
-    for (int64_t i = 0; i < n; ++i) { U[i] = std::pow((double)cnt[i], 0.75); total += U[i]; }
-    GEMHIP_REQUIRE(total > 0.0, "n2v_build_unigram: empty vocabulary (no walks?)");
+    for (int64_t i = 0; i < n; ++i) { U[i] = std::pow((double)cnt[i * stride], 0.75); total += U[i]; }
+    if (!(total > 0.0)) return false;
     for (int64_t i = 0; i < n; ++i) U[i] /= total;
     small.reserve(n); large.reserve(n);
     for (int64_t i = 0; i < n; ++i) {
@@ -706,8 +881,20 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
     }
     for (int32_t s : small) U[s] = 1.0;
     for (int32_t l : large) U[l] = 1.0;
-    std::vector<float> Uf(n);
+    Uf.resize(n);
     for (int64_t i = 0; i < n; ++i) Uf[i] = (float)U[i];
+    return true;
+}
+
+extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, float *UT_out, int32_t *KT_out)
+{
+    GEMHIP_REQUIRE(h, "n2v_build_unigram: NULL handle");
+    GEMHIP_CHECK(hipDeviceSynchronize());
+    const int64_t n = h->n;
+    std::vector<int32_t> cnt(n), K;
+    std::vector<float> Uf;
+    GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    GEMHIP_REQUIRE(vose_unigram(cnt.data(), n, 1, Uf, K), "n2v_build_unigram: empty vocabulary (no walks?)");
     if (!h->d_UT) GEMHIP_CHECK(hipMalloc((void **)&h->d_UT, n * sizeof(float)));
     if (!h->d_KT) GEMHIP_CHECK(hipMalloc((void **)&h->d_KT, n * sizeof(int32_t)));
     GEMHIP_CHECK(hipMemcpy(h->d_UT, Uf.data(), n * sizeof(float), hipMemcpyHostToDevice));
@@ -716,6 +903,79 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
     if (counts_out) std::copy(cnt.begin(), cnt.end(), counts_out);
     if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
     if (KT_out) std::copy(K.begin(), K.end(), KT_out);
+    return GEMHIP_OK;
+}
+
+// One alias table per partition p = {v : v % parts == p} over local indices v / parts (restricted unigram).
+extern "C" int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, float *UT_out, int32_t *KT_out)
+{
+    GEMHIP_REQUIRE(h && parts >= 1 && parts <= h->n, "n2v_build_unigram_parts: bad arguments");
+    GEMHIP_CHECK(hipDeviceSynchronize());
+    const int64_t n = h->n;
+    std::vector<int32_t> cnt(n);
+    GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<float> Uall(n);
+    std::vector<int32_t> Kall(n);
+    h->part_off.assign(parts + 1, 0);
+    for (int32_t p = 0; p < parts; ++p) {
+        const int64_t np = (n - p + parts - 1) / parts;
+        h->part_off[p + 1] = h->part_off[p] + np;
+        std::vector<float> Uf; std::vector<int32_t> K;
+        GEMHIP_REQUIRE(vose_unigram(cnt.data() + p, np, parts, Uf, K), "n2v_build_unigram_parts: partition %d has an empty vocabulary", p);
+        std::copy(Uf.begin(), Uf.end(), Uall.begin() + h->part_off[p]);
+        std::copy(K.begin(), K.end(), Kall.begin() + h->part_off[p]);
+    }
+    hipFree(h->d_UTp); hipFree(h->d_KTp); h->d_UTp = nullptr; h->d_KTp = nullptr;
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_UTp, n * sizeof(float)));
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_KTp, n * sizeof(int32_t)));
+    GEMHIP_CHECK(hipMemcpy(h->d_UTp, Uall.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    GEMHIP_CHECK(hipMemcpy(h->d_KTp, Kall.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->parts = parts;
+    if (UT_out) std::copy(Uall.begin(), Uall.end(), UT_out);
+    if (KT_out) std::copy(Kall.begin(), Kall.end(), KT_out);
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_emit_pairs(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi, uint64_t seed,
+                                      void *d_pairs, int64_t cap, void *d_count, void *stream)
+{
+    GEMHIP_REQUIRE(h && d_pairs && d_count && cap >= 0, "sgns_emit_pairs: bad arguments");
+    GEMHIP_REQUIRE(window >= 1 && window < 16384 && epoch >= 0 && epoch < 256, "sgns_emit_pairs: window=%d epoch=%d", window, epoch);
+    GEMHIP_REQUIRE(0 <= walk_lo && walk_lo <= walk_hi && walk_hi <= h->nwalks, "sgns_emit_pairs: bad local walk range");
+    const int64_t ntok = (walk_hi - walk_lo) * h->walk_len;
+    if (ntok == 0) return GEMHIP_OK;
+    hipLaunchKernelGGL(sgns_emit_pairs_kernel, dim3((unsigned)((ntok + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->d_walks, walk_lo, walk_hi,
+                       h->walk_len, window, epoch, h->walk_id_offset, seed, (int2 *)d_pairs, cap, (unsigned long long *)d_count);
+    GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs, int32_t neg_part, void *dSynPos_part,
+                                       void *dSynNeg_part, int32_t d, float alpha_begin, float alpha_end, uint64_t seed, uint32_t stream_id,
+                                       int32_t flags, void *stream)
+{
+    GEMHIP_REQUIRE(h && h->parts >= 1, "sgns_train_pairs: call n2v_build_unigram_parts first");
+    GEMHIP_REQUIRE(npairs >= 0 && (npairs == 0 || d_pairs) && dSynPos_part && dSynNeg_part, "sgns_train_pairs: bad arguments");
+    GEMHIP_REQUIRE(neg_part >= 0 && neg_part < h->parts, "sgns_train_pairs: neg_part=%d of %d", neg_part, h->parts);
+    GEMHIP_REQUIRE(pick_pairs(d) != nullptr, "sgns_train_pairs: d=%d unsupported", d);
+    if (npairs == 0) return GEMHIP_OK;
+    PairArgs A;
+    A.pairs = (const int2 *)d_pairs; A.npairs = npairs; A.parts = h->parts; A.neg_part = neg_part;
+    A.n_local_neg = h->part_off[neg_part + 1] - h->part_off[neg_part];
+    A.UTp = h->d_UTp + h->part_off[neg_part]; A.KTp = h->d_KTp + h->part_off[neg_part];
+    A.alpha_begin = alpha_begin; A.alpha_end = alpha_end; A.seed = seed; A.stream_id = stream_id; A.flags = flags; A.d = d;
+    A.SynPos = (float *)dSynPos_part; A.SynNeg = (float *)dSynNeg_part; A.pairs_done = h->d_pairs;
+    int blocks, threads;
+    if (flags & 4) { blocks = 1; threads = 64; A.nwaves = 1; }
+    else {
+        // Hogwild width: the rows in play are those of ONE partition pair (n/parts each)
+        int64_t cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, A.n_local_neg / 32);
+        cap = std::min<int64_t>(cap, 256 * 16);
+        const int64_t waves = std::min<int64_t>(cap, npairs);
+        threads = 256; blocks = (int)((waves + 3) / 4); A.nwaves = (int32_t)waves;
+    }
+    pick_pairs(d)(A, blocks, threads, (hipStream_t)stream);
+    GEMHIP_CHECK(hipGetLastError());
     return GEMHIP_OK;
 }
 

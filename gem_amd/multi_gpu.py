@@ -8,10 +8,14 @@ SURVEY 8(e):
     the owned row blocks after each sweep.
   * node2vec walks shard by START NODE (a contiguous range of global walk ids); the graph is
     replicated; no collective while walking.  The vocabulary counts are summed once (all-reduce,
-    4n bytes).  SGNS trains each rank's walks against a local replica of SynPos/SynNeg and, every
-    `sync_chunks`-th of its walks, all ranks exchange the SUM OF THEIR DELTAS since the last exchange
-    (all-reduce on the d-dim tables): every rank's updates are applied once -- Hogwild with a bounded
-    staleness of one chunk -- rather than averaged away.
+    4n bytes).  SGNS (`Node2VecPartitioned`): replicas that all-reduce the tables do NOT work beyond
+    2 ranks -- summed deltas overshoot, averaged deltas under-train (measured) --
+    so the tables are PARTITIONED instead (node v -> partition v % N, the scheme of GraphVite-style
+    systems): the (context, word) pairs of an episode of walks are materialised, routed to the owner of
+    the context row (all-to-all) and trained in N rounds in which rank g holds SynPos partition g and
+    SynNeg partition (g+s) % N, the SynNeg partitions rotating around a ring between rounds.  No two
+    GPUs ever touch the same row; with >= 64 episodes the embedding quality equals the sequential
+    algorithm's.  (`Node2VecSharded`, the delta-sum replica scheme, is kept for N <= 2 and for the record.)
 
 The compute backend is injected: `HipBackend*` (below) drives libgem_hip.so through the C ABI with
 torch tensors as device memory; the CPU tests inject a stand-in so the exchange logic runs under gloo.
@@ -46,6 +50,55 @@ class TorchComm(object):
         """full[r*k:(r+1)*k] <- rank r's `own` (k rows each)."""
         if self.world > 1:
             self.dist.all_gather_into_tensor(full, own)
+        else:
+            full.copy_(own)
+
+    def all_to_all_rows(self, send, send_counts):
+        """send: [m, c] rows grouped by destination rank (send_counts[r] rows for rank r, in rank order).
+        Returns the rows addressed to this rank, grouped by source rank."""
+        if self.world == 1:
+            return send
+        import torch
+        dist = self.dist
+        sc = torch.as_tensor(send_counts, dtype=torch.int64, device=send.device)
+        allc = torch.empty(self.world * self.world, dtype=torch.int64, device=send.device)
+        dist.all_gather_into_tensor(allc, sc)
+        allc = allc.view(self.world, self.world).cpu()
+        rank = dist.get_rank()
+        recv_counts = allc[:, rank].tolist()
+        send_counts = [int(x) for x in send_counts]
+        out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if dist.get_backend() == 'nccl':
+            dist.all_to_all_single(out, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts)
+            return out
+        ops, so, ro = [], 0, 0
+        keep = []
+        for r in range(self.world):
+            a, b = send_counts[r], recv_counts[r]
+            if r == rank:
+                out[ro:ro + b].copy_(send[so:so + a])
+            else:
+                if a:
+                    t = send[so:so + a].contiguous(); keep.append(t)
+                    ops.append(dist.P2POp(dist.isend, t, r))
+                if b:
+                    ops.append(dist.P2POp(dist.irecv, out[ro:ro + b], r))
+            so += a; ro += b
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return out
+
+    def ring_shift(self, buf, tmp):
+        """Every rank sends `buf` to rank-1 and receives rank+1's into `tmp`; returns (tmp, buf) swapped."""
+        if self.world == 1:
+            return buf, tmp
+        dist = self.dist
+        rank = dist.get_rank()
+        ops = [dist.P2POp(dist.isend, buf, (rank - 1) % self.world), dist.P2POp(dist.irecv, tmp, (rank + 1) % self.world)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return tmp, buf
 
 
 # --------------------------------------------------------------------------- GF
@@ -127,6 +180,65 @@ class Node2VecSharded(object):
         return P
 
 
+def assemble_partitions(P_part, comm, world, n):
+    """All-gather equal-size partition buffers and interleave them back into node-id order:
+    row v = partition[v % world][v // world]."""
+    import torch
+    rows, d = P_part.shape
+    full = torch.empty((world * rows, d), dtype=P_part.dtype, device=P_part.device)
+    comm.all_gather_rows(full, P_part.contiguous())
+    return full.view(world, rows, d).permute(1, 0, 2).reshape(-1, d)[:n].contiguous()
+
+
+class Node2VecPartitioned(object):
+    """One full node2vec.learn_embedding pass on N ranks with PARTITIONED tables (module docstring)."""
+
+    def __init__(self, backend, comm, rank, world, n, num_walks, walk_len, window, epochs, seed, flags, episodes=64, alpha0=0.025):
+        self.b, self.comm, self.rank, self.world = backend, comm, rank, world
+        self.n, self.num_walks, self.walk_len, self.window, self.epochs = n, num_walks, walk_len, window, epochs
+        self.seed, self.flags, self.episodes, self.alpha0 = seed, flags, max(1, episodes), alpha0
+        self.lo, self.hi = shard_range(n * num_walks, rank, world)
+        self.pairs_trained = 0
+
+    def _alpha(self, f):
+        return self.alpha0 * max(1.0 - f, 1e-4)
+
+    def run(self, p=1.0, q=1.0):
+        import torch
+        b, comm, W, g = self.b, self.comm, self.world, self.rank
+        b.walks(p, q, self.num_walks, self.walk_len, self.seed, self.flags, self.lo, self.hi)
+        counts = b.vocab()
+        comm.all_reduce_sum(counts)
+        b.build_unigram_parts(W)
+        P_part, N_cur, N_tmp = b.init_part_tables(self.seed, g, W)          # partition g of SynPos / SynNeg (+ a receive buffer)
+        nloc = self.hi - self.lo
+        total_steps = float(self.epochs * self.episodes)
+        self.pairs_trained = 0
+        for ep in range(self.epochs):
+            for e in range(self.episodes):
+                a, z = shard_range(nloc, e, self.episodes)
+                pairs = b.emit_pairs(self.window, ep, a, z, self.seed)       # [np, 2] int32: (context, word)
+                dest = pairs[:, 0] % W
+                order = torch.argsort(dest, stable=True)
+                send = pairs[order]
+                send_counts = torch.bincount(dest, minlength=W).tolist()
+                mine = comm.all_to_all_rows(send, send_counts)               # every pair whose context row I own
+                wpart = mine[:, 1] % W
+                order = torch.argsort(wpart, stable=True)
+                mine = mine[order].contiguous()
+                off = [0] + torch.cumsum(torch.bincount(wpart, minlength=W), 0).tolist()
+                step = ep * self.episodes + e
+                for s in range(W):
+                    j = (g + s) % W                                          # SynNeg partition visiting me this round
+                    bucket = mine[off[j]:off[j + 1]]
+                    f0, f1 = (step + s / W) / total_steps, (step + (s + 1) / W) / total_steps
+                    b.train_pairs(bucket, j, P_part, N_cur, self._alpha(f0), self._alpha(f1), self.seed,
+                                  (step * W + g) * W + j, self.flags)
+                    self.pairs_trained += int(bucket.shape[0])
+                    N_cur, N_tmp = comm.ring_shift(N_cur, N_tmp)             # after W shifts my own partition is back
+        return assemble_partitions(P_part, comm, W, self.n)
+
+
 class HipBackendN2V(object):
     def __init__(self, n, row_ptr, col, w, d):
         import torch
@@ -164,6 +276,42 @@ class HipBackendN2V(object):
     def train(self, window, epochs, epoch, lo, hi, tokens_total, token_offset, seed, flags):
         _hip.check(self.L.gemhip_sgns_train(self.h, window, 5, 0.025, epochs, epoch, lo, hi, tokens_total, token_offset, seed,
                                             flags, self._stream()))
+
+    # ---- partitioned schedule -------------------------------------------------
+    def build_unigram_parts(self, parts):
+        self.torch.cuda.current_stream().synchronize()
+        _hip.check(self.L.gemhip_n2v_build_unigram_parts(self.h, parts, None, None))
+        self.parts = parts
+
+    def init_part_tables(self, seed, rank, world):
+        """Partition `rank` of the SAME initial tables a single GPU would draw (InitPosEmb / InitNegEmb)."""
+        torch = self.torch
+        self.init_tables(seed)
+        torch.cuda.current_stream().synchronize()
+        rows = (self.n + world - 1) // world                       # equal-size buffers so ring shifts are uniform
+        P = torch.zeros((rows, self.d), dtype=torch.float32, device=self.P.device)
+        own = self.P[rank::world]
+        P[:own.shape[0]].copy_(own)
+        N = torch.zeros_like(P)
+        return P, N, torch.zeros_like(P)
+
+    def emit_pairs(self, window, epoch, lo, hi, seed):
+        torch = self.torch
+        nw = C.c_int64(); wl = C.c_int32(); p = C.c_void_p()
+        _hip.check(self.L.gemhip_n2v_walks_ptr(self.h, C.byref(p), C.byref(nw), C.byref(wl)))
+        cap = max((hi - lo) * wl.value * 2 * window, 1)
+        buf = torch.empty((cap, 2), dtype=torch.int32, device=self.P.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.P.device)
+        _hip.check(self.L.gemhip_sgns_emit_pairs(self.h, window, epoch, lo, hi, seed, C.c_void_p(buf.data_ptr()), cap,
+                                                 C.c_void_p(cnt.data_ptr()), self._stream()))
+        return buf[:int(cnt.item())]
+
+    def train_pairs(self, bucket, neg_part, P_part, N_part, a0, a1, seed, stream_id, flags):
+        if bucket.shape[0] == 0:
+            return
+        _hip.check(self.L.gemhip_sgns_train_pairs(self.h, C.c_void_p(bucket.data_ptr()), bucket.shape[0], neg_part,
+                                                  C.c_void_p(P_part.data_ptr()), C.c_void_p(N_part.data_ptr()), self.d, a0, a1, seed,
+                                                  stream_id & 0xffffffff, flags, self._stream()))
 
     def pairs(self, reset=True):
         v = C.c_int64()

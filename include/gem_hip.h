@@ -183,6 +183,20 @@ int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0,
                       int64_t tokens_total, int64_t token_offset, uint64_t seed,
                       int32_t flags, void *stream);
 
+/* Partitioned ("episode") SGNS for N GPUs -- no reference counterpart (the reference is one process); this is the
+ * schedule that lets SGNS shard without two GPUs ever writing the same row:
+ * node v belongs to partition v % parts with local row v / parts; the (context, word) pairs TrainModel forms are
+ * materialised (emit_pairs: int32 pairs {context, word}, appended at an atomic cursor `d_count` the caller zeroes),
+ * bucketed by the caller by (context % parts, word % parts), and each bucket is trained against ONE SynPos
+ * partition and ONE SynNeg partition (train_pairs; negatives come from the unigram table restricted to the word's
+ * partition, built by build_unigram_parts from the global counts). */
+int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, float *UT_out, int32_t *KT_out);
+int gemhip_sgns_emit_pairs(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi,
+                           uint64_t seed, void *d_pairs, int64_t cap, void *d_count, void *stream);
+int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs, int32_t neg_part,
+                            void *dSynPos_part, void *dSynNeg_part, int32_t d, float alpha_begin,
+                            float alpha_end, uint64_t seed, uint32_t stream_id, int32_t flags, void *stream);
+
 /* ---------------------------------------------------------------------- HOPE
  * Replaces: gem/embedding/hope.py:23-41 (HOPE.learn_embedding): S = inv(I - beta A) (beta A)
  * as dense numpy matrices (:28-31) and u, s, vt = scipy.sparse.linalg.svds(S, k=d//2) (:33).

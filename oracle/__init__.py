@@ -56,6 +56,11 @@ def lib():
                                         C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, f32p, i32p, C.c_uint64,
                                         C.c_int32, f32p, f32p]
         L.oracle_sgns_init.argtypes = [C.c_int64, C.c_int32, C.c_uint64, f32p, f32p]
+        L.oracle_sgns_pairs.restype = C.c_int64
+        L.oracle_sgns_pairs.argtypes = [C.c_int64, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, i32p, i32p]
+        L.oracle_sgns_train_pairs.restype = None
+        L.oracle_sgns_train_pairs.argtypes = [C.c_int32, C.c_int64, i32p, i32p, C.c_int32, C.c_int32, C.c_int64, f32p, i32p, C.c_float,
+                                              C.c_float, C.c_uint64, C.c_uint64, C.c_int32, f32p, f32p]
         for f in ('oracle_philox', 'oracle_alias_build_f32', 'oracle_n2v_alias_rows', 'oracle_n2v_walks', 'oracle_n2v_vocab',
                   'oracle_unigram_build', 'oracle_sgns_train', 'oracle_sgns_init'):
             getattr(L, f).restype = None
@@ -174,3 +179,29 @@ def n2v_train(n, src, dst, w, d, walk_len, num_walks, window, epochs, p, q, seed
     for ep in range(epochs):
         sgns_train(walks, window, 0.025, epochs, ep, tot, ep * tot, 0, UT, KT, seed, flags, P, N)
     return P, walks
+
+
+def sgns_pairs(walks, window, epoch, walk_id_offset, seed):
+    """(context, word) pairs TrainModel forms, in walk order: int32 [np, 2]."""
+    walks = np.ascontiguousarray(walks, dtype=np.int32)
+    a = (walks.shape[0], walks.shape[1], _p(walks, C.c_int32), window, epoch, walk_id_offset, seed)
+    npairs = lib().oracle_sgns_pairs(*a, None, None)
+    ctx = np.empty(npairs, np.int32); word = np.empty(npairs, np.int32)
+    lib().oracle_sgns_pairs(*a, _p(ctx, C.c_int32), _p(word, C.c_int32))
+    return np.stack([ctx, word], axis=1)
+
+
+def unigram_build_parts(counts, parts):
+    """Concatenated per-partition tables (partition p = counts[p::parts]); returns (UT, KT, offsets)."""
+    UT, KT, off = [], [], [0]
+    for p in range(parts):
+        u, k = unigram_build(np.ascontiguousarray(counts[p::parts]))
+        UT.append(u); KT.append(k); off.append(off[-1] + len(u))
+    return np.concatenate(UT), np.concatenate(KT), off
+
+
+def sgns_train_pairs_local(pairs_local, UTp, KTp, a0, a1, seed, stream_id, flags, P_part, N_part):
+    """Train a bucket on PARTITION buffers; pairs_local holds local row indices (context // parts, word // parts)."""
+    ctx = np.ascontiguousarray(pairs_local[:, 0], dtype=np.int32); word = np.ascontiguousarray(pairs_local[:, 1], dtype=np.int32)
+    lib().oracle_sgns_train_pairs(P_part.shape[1], len(ctx), _p(ctx, C.c_int32), _p(word, C.c_int32), 1, 0, len(UTp), _p(UTp, C.c_float),
+                                  _p(KTp, C.c_int32), a0, a1, seed, stream_id, flags, _p(P_part, C.c_float), _p(N_part, C.c_float))

@@ -129,3 +129,79 @@ def test_world1_is_the_plain_pipeline(sbm1024):
     ref, _ = oracle.n2v_train(n, src, dst, w, 8, 20, 2, 5, 1, 1.0, 1.0, 9, SNAP)
     assert np.array_equal(P, ref)
     assert multi_gpu.shard_range(10, 0, 3) == (0, 3) and multi_gpu.shard_range(10, 2, 3) == (6, 10)
+
+
+# ------------------------------------------------------------------ partitioned (episode) schedule
+class OraclePart(OracleN2V):
+    """Stand-in backend for Node2VecPartitioned built on the CPU oracle (partition buffers, local row indices)."""
+
+    def build_unigram_parts(self, parts):
+        self.parts = parts
+        self.UTp, self.KTp, self.off = oracle.unigram_build_parts(self.counts.numpy(), parts)
+
+    def init_part_tables(self, seed, rank, world):
+        P, N = oracle.sgns_init(self.n, self.d, seed)
+        rows = (self.n + world - 1) // world
+        Pp = np.zeros((rows, self.d), np.float32)
+        own = P[rank::world]
+        Pp[:len(own)] = own
+        return torch.from_numpy(Pp), torch.zeros(rows, self.d), torch.zeros(rows, self.d)
+
+    def emit_pairs(self, window, epoch, lo, hi, seed):
+        return torch.from_numpy(oracle.sgns_pairs(self.w[lo:hi], window, epoch, self.lo + lo, seed))
+
+    def train_pairs(self, bucket, neg_part, P_part, N_part, a0, a1, seed, stream_id, flags):
+        if bucket.shape[0] == 0:
+            return
+        local = (bucket // self.parts).numpy()
+        j0, j1 = self.off[neg_part], self.off[neg_part + 1]
+        oracle.sgns_train_pairs_local(local, self.UTp[j0:j1], self.KTp[j0:j1], a0, a1, seed, stream_id & 0xffffffff, flags,
+                                      P_part.numpy(), N_part.numpy())
+
+
+def _worker_part(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    comm = multi_gpu.TorchComm(world)
+    G = load_sbm1024()
+    n, src, dst, w, _ = edge_arrays(G)
+    # all_to_all_rows / ring_shift primitives
+    send = torch.arange(6 * 2, dtype=torch.int32).view(6, 2) + 100 * rank
+    counts = [2, 1, 3][:world] if world == 3 else ([4, 2] if rank == 0 else [1, 5])
+    got = comm.all_to_all_rows(send, counts)
+    exp = torch.cat([(torch.arange(12, dtype=torch.int32).view(6, 2) + 100 * r)[sum(c[:rank]):sum(c[:rank + 1])]
+                     for r, c in enumerate(([4, 2], [1, 5]))])
+    ok_a2a = bool(torch.equal(got, exp))
+    buf = torch.full((3,), float(rank)); tmp = torch.zeros(3)
+    buf, tmp = comm.ring_shift(buf, tmp)
+    ok_ring = bool((buf == float((rank + 1) % world)).all())
+    b = OraclePart(n, src, dst, 16)
+    job = multi_gpu.Node2VecPartitioned(b, comm, rank, world, n, 10, 80, 10, 1, seed=5, flags=9, episodes=32)
+    P = job.run(1.0, 1.0)
+    tot = torch.tensor([job.pairs_trained]); dist.all_reduce(tot)
+    gathered = [torch.zeros_like(P) for _ in range(world)]
+    dist.all_gather(gathered, P)
+    ok_same = all(bool(torch.equal(gathered[0], t)) for t in gathered)
+    if rank == 0:
+        np.save(out, P.numpy())
+        with open(out + '.flags', 'w') as fh:
+            fh.write('%d %d %d %d' % (ok_a2a, ok_ring, ok_same, int(tot.item())))
+    dist.destroy_process_group()
+
+
+def test_partitioned_world2_gloo(tmp_path, sbm1024):
+    out = str(tmp_path / 'Pp.npy')
+    mp.spawn(_worker_part, args=(2, _free_port(), out), nprocs=2, join=True)
+    ok_a2a, ok_ring, ok_same, pairs = (int(x) for x in open(out + '.flags').read().split())
+    assert ok_a2a and ok_ring and ok_same
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    rp, col, _ = oracle.sorted_csr(n, src, dst, None)
+    walks = oracle.n2v_walks(rp, col, None, None, 1.0, 1.0, 10, 80, 5, 9)
+    assert pairs == len(oracle.sgns_pairs(walks, 10, 0, 0, 5))             # every pair trained exactly once across ranks/rounds
+    from gem_amd.embedding.node2vec import node2vec
+    from gem_amd.evaluation import reconstruction as gr
+    m = node2vec(d=16, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
+    MAP = gr.evaluateStaticGraphReconstruction(sbm1024, m, np.load(out).astype(np.float64), None)[0]
+    Xs, _ = oracle.n2v_train(n, src, dst, w, 16, 80, 10, 10, 1, 1.0, 1.0, 5, 9)          # sequential, same flags
+    MAPs = gr.evaluateStaticGraphReconstruction(sbm1024, m, Xs.astype(np.float64), None)[0]
+    assert abs(MAP - MAPs) <= 0.03 * MAPs, (MAP, MAPs)
