@@ -11,7 +11,8 @@ that is already resident in HBM when the timed region starts:
               graph.number_of_edges() / wall of the pass.
     gf        one SGD sweep over all edges of the same SBM, d=128; edges/sec = edges x sweeps / wall.
 For N>1 launch with torch.distributed.run (one rank per GPU, RCCL).  Both paths shard by SOURCE /
-START NODE (gem_amd/multi_gpu.py): total work is fixed => "scaling": "strong".
+START NODE (gem_amd/multi_gpu.py; node2vec additionally partitions its tables over the ranks): total work is
+fixed => "scaling": "strong".
 
 `roofline`: for the dominant kernel, algorithmic bytes per launch (SURVEY 8d per-unit figure x units
 the launch processes) / average launch duration measured with HIP events on the launch stream.
@@ -135,8 +136,12 @@ class N2VWorkload(object):
         n, src, dst, w, _ = edge_arrays(g)
         row_ptr, col, ww = to_csr(n, src, dst, w)
         self.b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, args.d)
-        self.job = multi_gpu.Node2VecSharded(self.b, comm, rank, world, n, args.num_walks, args.walk_len, args.window, 1,
-                                             seed=20260923, flags=_hip.N2V_SNAP_COMPAT, sync_chunks=args.sync_chunks)
+        if world == 1:
+            self.job = multi_gpu.Node2VecSharded(self.b, comm, rank, world, n, args.num_walks, args.walk_len, args.window, 1,
+                                                 seed=20260923, flags=_hip.N2V_SNAP_COMPAT)
+        else:       # N GPUs: partitioned tables, episode schedule (gem_amd/multi_gpu.py)
+            self.job = multi_gpu.Node2VecPartitioned(self.b, comm, rank, world, n, args.num_walks, args.walk_len, args.window, 1,
+                                                     seed=20260923, flags=_hip.N2V_SNAP_COMPAT, episodes=args.episodes)
         self.sgns_ms, self.sgns_launches, self.pairs = 0.0, 0, 0
         self._orig_train = self.b.train
         self.b.train = self._timed_train
@@ -292,7 +297,7 @@ def main():
     ap.add_argument('--num-walks', type=int, default=10)
     ap.add_argument('--walk-len', type=int, default=80)
     ap.add_argument('--window', type=int, default=10)
-    ap.add_argument('--sync-chunks', type=int, default=16)
+    ap.add_argument('--episodes', type=int, default=64, help='N>1 node2vec: episodes of the partitioned schedule')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

@@ -544,7 +544,11 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
     const int d = A.d;
     const bool quirk = (A.flags & 2) != 0;
     unsigned long long done = 0;
-    for (int64_t i = gw; i < A.npairs; i += A.nwaves) {
+    // each wavefront takes a CONTIGUOUS chunk of the bucket: neighbouring pairs come from the same centre word /
+    // the same walk, so interleaving them over wavefronts would make concurrent waves fight over the same rows
+    const int64_t chunk = (A.npairs + A.nwaves - 1) / A.nwaves;
+    const int64_t i_end = (gw + 1) * chunk < A.npairs ? (gw + 1) * chunk : A.npairs;
+    for (int64_t i = gw * chunk; i < i_end; ++i) {
         const int2 pr = A.pairs[i];
         const int32_t ctx = __builtin_amdgcn_readfirstlane(pr.x), word = __builtin_amdgcn_readfirstlane(pr.y);
         const int32_t ctx_l = ctx / A.parts, word_l = word / A.parts;
