@@ -50,6 +50,8 @@ _SIGS = {
     'gemhip_hope': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_float, C.c_uint64, f32p, f32p, f32p, f64p]),
     'gemhip_sym_eig': (C.c_int, [C.c_int32, f64p, f64p]),
+    'gemhip_sym_eig_builtin': (C.c_int, [C.c_int32, f64p, f64p]),
+    'gemhip_set_sym_eig_callback': (C.c_int, [C.c_void_p]),
     'gemhip_hope_spmm': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, f32p, f32p, f32p]),
     'gemhip_hope_gram': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, f32p, f32p, f64p]),
     'gemhip_hope_tsgemm': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, f32p, f64p, C.c_float, f32p, f32p]),
@@ -101,7 +103,32 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        if os.environ.get('GEM_HIP_LAPACK_EIG') == '1':
+            _register_lapack(L)
     return _lib
+
+
+_EIG_CB_TYPE = C.CFUNCTYPE(C.c_int, C.c_int32, f64p, f64p)
+_eig_cb_keepalive = None
+
+
+def _register_lapack(L):
+    """Hand numpy's LAPACK symmetric eigensolver to the library for HOPE's projected (<= 512 x 512) problems.
+    OFF by default: on the 256-core GPU host OpenBLAS spins up every core for a 200 x 200 problem and is 1.4x
+    SLOWER than the built-in single-threaded Householder/QL (measured: 20 ms vs 15 ms per solve).  GEM_HIP_LAPACK_EIG=1."""
+    global _eig_cb_keepalive
+
+    def _eigh(n, a_ptr, w_ptr):
+        try:
+            A = np.ctypeslib.as_array(a_ptr, shape=(n, n))
+            w, V = np.linalg.eigh(A)
+            A[:, :] = V
+            np.ctypeslib.as_array(w_ptr, shape=(n,))[:] = w
+            return 0
+        except Exception:           # fall back to the built-in solver
+            return 1
+    _eig_cb_keepalive = _EIG_CB_TYPE(_eigh)
+    L.gemhip_set_sym_eig_callback(C.cast(_eig_cb_keepalive, C.c_void_p))
 
 
 def check(rc):

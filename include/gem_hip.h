@@ -223,6 +223,11 @@ int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *c
  *   spmm    : Y[n][b] = alpha * A X (+ Wadd)        gram : G[m1][m2] = X^T Y  (fp64 out, MFMA fp32)
  *   tsgemm  : Out[n][b2] = (Src or 0) + alpha * X[n][m] C[m][b2]   (C given in fp64, MFMA fp32). */
 int gemhip_sym_eig(int32_t n, double *A_inout, double *w_out);
+int gemhip_sym_eig_builtin(int32_t n, double *A_inout, double *w_out);
+/* Optional: let the host supply a faster symmetric eigensolver for the projected problems (same contract as
+ * gemhip_sym_eig: row-major symmetric A overwritten by eigenvectors in columns, w ascending, return 0).  The Python
+ * layer registers numpy's LAPACK (dsyevd) here; NULL restores the built-in Householder/QL solver. */
+int gemhip_set_sym_eig_callback(int (*fn)(int32_t n, double *A_inout, double *w_out));
 int gemhip_hope_spmm(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
                      float alpha, int32_t b, const float *X_host, const float *Wadd_host, float *Y_host);
 int gemhip_hope_gram(int64_t n, int32_t m1, int32_t m2, const float *X_host, const float *Y_host,

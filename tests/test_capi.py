@@ -58,14 +58,17 @@ def test_host_symmetric_eigensolver():
     """gemhip_sym_eig is host code (tred2/tql2) -- the projected eigenproblems of HOPE run through it."""
     import numpy as np
     L = _hip.lib()
+    _hip._register_lapack(L)                       # exercise the optional host-eigensolver hook too
     rng = np.random.RandomState(0)
-    for n in (1, 2, 7, 34, 96, 257):
+    for n in (1, 2, 7, 34, 96, 128, 257):
         M = rng.randn(n, n)
         A = (M + M.T) / 2 if n != 34 else M[:, :10] @ M[:, :10].T          # n=34: rank 10
         V = A.copy(); w = np.zeros(n)
-        _hip.check(L.gemhip_sym_eig(n, _hip.ptr(V, ctypes.c_double), _hip.ptr(w, ctypes.c_double)))
+        fn = L.gemhip_sym_eig_builtin if n % 2 else L.gemhip_sym_eig      # built-in QL and the LAPACK callback route
+        _hip.check(fn(n, _hip.ptr(V, ctypes.c_double), _hip.ptr(w, ctypes.c_double)))
         scale = max(np.abs(A).max(), 1.0)
         assert np.all(np.diff(w) >= 0)
         assert np.abs(w - np.linalg.eigvalsh(A)).max() < 1e-11 * scale * n
         assert np.abs(V @ np.diag(w) @ V.T - A).max() < 1e-11 * scale * n
         assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12 * n
+    L.gemhip_set_sym_eig_callback(None)
