@@ -214,6 +214,15 @@ class N2VWorkload(object):
         assert bool(torch.isfinite(self.P).all()), 'non-finite embedding'
         assert float(self.P.abs().max()) > 1e-3
 
+    def quality(self, nsample=256):
+        """Outside the timed region: graph-reconstruction MAP of the learned table over a node sample, with the reference
+        evaluator's semantics (gem_amd/csrc/eval.hip) -- shows the timed pass really trained the embedding."""
+        from gem_amd.evaluation import reconstruction as gr
+        rng = np.random.RandomState(0)
+        nodes = rng.choice(self.g.n, size=min(nsample, self.g.n), replace=False)
+        ap = gr.sampled_ap_gpu(self.g, None, self.P.cpu().numpy(), nodes)
+        return {'sampled_map': float(ap.mean()), 'nodes_sampled': int(len(nodes)), 'evaluator': 'metrics.computeMAP semantics on the GPU'}
+
 
 class HopeWorkload(object):
     """BASELINE configs[2]: SBM 100k nodes / 1M edges, HOPE d=128 (k=64), beta=0.01; embeddings/sec = n / wall."""
@@ -359,6 +368,8 @@ def main():
             'config': {'workload': wl.name, 'nodes': args.nodes, 'directed_edges': wl.n_edges, 'd': args.d,
                        'sharding': 'source-node x%d' % world},
         }
+        if hasattr(wl, 'quality'):
+            out['quality'] = wl.quality()
         if world == 1:
             out['roofline'] = wl.roofline(dev_ms, K)
             if not args.no_cpu_baseline:

@@ -55,6 +55,7 @@ _SIGS = {
     'gemhip_hope_spmm': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, f32p, f32p, f32p]),
     'gemhip_hope_gram': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, f32p, f32p, f64p]),
     'gemhip_hope_tsgemm': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, f32p, f64p, C.c_float, f32p, f32p]),
+    'gemhip_eval_sampled_ap': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, f32p, f32p, i64p, i32p, C.c_int32, C.c_int64, i32p, f64p]),
     'gemhip_n2v_train': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_float, C.c_float, C.c_uint64, C.c_int32, f32p, f64p]),
     'gemhip_n2v_create': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.POINTER(C.c_void_p)]),

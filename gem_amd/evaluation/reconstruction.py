@@ -124,3 +124,29 @@ def sampled_map(graph, pair_score, nodes, undirected=True):
         prec = np.cumsum(hit) / np.arange(1, hit.size + 1)
         aps.append(prec[hit].sum() / hit.sum())
     return float(np.mean(aps)) if aps else 0.0
+
+
+def sampled_ap_gpu(graph, graph_embedding, X, nodes, is_undirected=True):
+    """Per-node AP of graph reconstruction for `nodes`, computed on the GPU (gem_amd/csrc/eval.hip) with the same
+    semantics as average_precision_rows / metrics.computeMAP -- no n x n matrix, so it works at 1M nodes.
+    mean() of the result over ALL nodes equals evaluateStaticGraphReconstruction's MAP (tests/test_eval_gpu.py)."""
+    import ctypes as C
+    from gem_amd import _hip
+    from gem_amd.graph import edge_arrays, to_csr
+    n, src, dst, w, _ = edge_arrays(graph)
+    row_ptr, col, _ = to_csr(n, src, dst, None)
+    X = np.asarray(X)
+    d = X.shape[1]
+    name = graph_embedding.get_method_name() if graph_embedding is not None else ''
+    if name == 'hope_gsvd':                                   # hope.py:43-44: X[i, :k] . X[j, k:]
+        k = d // 2
+        A = np.ascontiguousarray(X[:, :k], dtype=np.float32); B = np.ascontiguousarray(X[:, k:2 * k], dtype=np.float32)
+    else:                                                     # gf.py:103-104 / node2vec.py:56-57: X[i] . X[j]
+        A = np.ascontiguousarray(X, dtype=np.float32); B = None
+    nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+    ap = np.zeros(len(nodes))
+    _hip.require_device()
+    _hip.check(_hip.lib().gemhip_eval_sampled_ap(n, A.shape[1], A.shape[1], _hip.ptr(A, C.c_float), _hip.ptr(B, C.c_float),
+                                                 _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), 1 if is_undirected else 0,
+                                                 len(nodes), _hip.ptr(nodes, C.c_int32), _hip.ptr(ap, C.c_double)))
+    return ap

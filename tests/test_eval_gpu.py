@@ -1,0 +1,42 @@
+"""GPU evaluation kernel (sampled AP) equals the reference-semantics evaluator, node by node."""
+import json
+
+import numpy as np
+import pytest
+
+from gem_amd.embedding.gf import GraphFactorization
+from gem_amd.embedding.hope import HOPE
+from gem_amd.embedding.node2vec import node2vec
+from gem_amd.evaluation import reconstruction as gr
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+def check(G, model, X, undirected=True):
+    n = len(G.nodes)
+    X32 = X.astype(np.float32).astype(np.float64)                    # the kernel sees fp32 inputs
+    est = model.get_reconstructed_adj(X32)
+    ap_ref = gr.average_precision_rows(est, gr._adjacency_bool(G, n), undirected=undirected)
+    ap = gr.sampled_ap_gpu(G, model, X32, np.arange(n), is_undirected=undirected)
+    assert np.abs(ap - ap_ref).max() < 1e-9, np.abs(ap - ap_ref).max()
+    return ap.mean()
+
+
+def test_matches_evaluator_on_reference_goldens(karate, sbm1024):
+    ref = json.load(open(golden_path('map_ref.json')))
+    m = GraphFactorization(d=32, max_iter=1, eta=0.02, regu=0.01)
+    MAP = check(sbm1024, m, np.load(golden_path('gf_sbm1024_d32.npz'))['X'])
+    assert MAP == pytest.approx(ref['sbm1024_gf_d32_5sweeps'], abs=2e-4)           # fp32-rounded inputs
+    m = HOPE(d=32, beta=0.01)
+    MAP = check(sbm1024, m, np.load(golden_path('hope_sbm1024_d32.npz'))['X'])
+    assert MAP == pytest.approx(ref['sbm1024_hope_d32'], abs=2e-4)
+    m = node2vec(d=2, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
+    check(karate, m, np.loadtxt(golden_path('ref_karate_node2vec.txt')))
+    m = GraphFactorization(d=128, max_iter=1, eta=1e-4, regu=1.0)
+    check(sbm1024, m, np.load(golden_path('ref_sbm_GraphFactorization.npz'))['X'].astype(np.float64), undirected=False)
+
+
+def test_ties_follow_the_stable_sort_rule(sbm1024):
+    X = np.round(np.random.RandomState(0).randn(1024, 4) * 2) / 2                   # coarse grid -> many exact ties
+    check(sbm1024, GraphFactorization(d=4, max_iter=1, eta=0.1, regu=0.1), X)
