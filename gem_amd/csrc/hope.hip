@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstring>
 #include <chrono>
+#include <cstdlib>
 
 using namespace gemhip;
 
@@ -120,13 +121,24 @@ __global__ __launch_bounds__(256) void hope_gram_kernel(int64_t n, const float *
     }
 }
 
-__global__ void hope_reduce_kernel(const float *__restrict__ P, int nslabs, int64_t stride, int m1, int m2, int m2p, double *__restrict__ G)
+// Deterministic two-pass fp64 reduction of the slab partials (coalesced over the output index):
+// pass 1: part[c][idx] = sum of slabs k = c, c+C, c+2C, ...   pass 2: G[idx] = sum_c part[c][idx].
+__global__ void hope_reduce1_kernel(const float *__restrict__ P, int nslabs, int64_t stride, int m1, int m2, int m2p, int C, double *__restrict__ part)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
     if (idx >= m1 * m2) return;
     const int i = idx / m2, j = idx - i * m2;
     double s = 0.0;
-    for (int k = 0; k < nslabs; ++k) s += (double)P[k * stride + (int64_t)i * m2p + j];
+    for (int k = c; k < nslabs; k += C) s += (double)P[k * stride + (int64_t)i * m2p + j];
+    part[(int64_t)c * m1 * m2 + idx] = s;
+}
+__global__ void hope_reduce2_kernel(const double *__restrict__ part, int C, int total, double *__restrict__ G)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) s += part[(int64_t)c * total + idx];
     G[idx] = s;
 }
 
@@ -380,13 +392,14 @@ struct Hope {
     float *va = nullptr, *vaT = nullptr;
     float *P = nullptr; size_t P_bytes = 0;          // Gram slab partials
     double *G = nullptr; size_t G_elems = 0;         // device fp64 Gram
+    double *Gpart = nullptr; size_t Gpart_elems = 0; // reduction scratch
     float *Csmall = nullptr; size_t C_elems = 0;     // device small matrix for tsgemm
     hipStream_t s = nullptr;
     double spmm_count = 0, spmm_cols = 0, eig_seconds = 0, eig_calls = 0;   // statistics
     int err = 0;
     ~Hope()
     {
-        hipFree(rp); hipFree(rpT); hipFree(ci); hipFree(ciT); hipFree(va); hipFree(vaT); hipFree(P); hipFree(G); hipFree(Csmall);
+        hipFree(rp); hipFree(rpT); hipFree(ci); hipFree(ciT); hipFree(va); hipFree(vaT); hipFree(P); hipFree(G); hipFree(Gpart); hipFree(Csmall);
     }
 };
 
@@ -424,7 +437,11 @@ void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int
     const int ntiles = t1 * t2;
     hipLaunchKernelGGL(hope_gram_kernel, dim3((ntiles + 3) / 4, nslabs), dim3(256), 0, H.s, H.n, X, ldx, m1, Y, ldy, m2, rows_per_slab, t2, ntiles,
                        H.P, m1p, m2p);
-    hipLaunchKernelGGL(hope_reduce_kernel, dim3((m1 * m2 + 255) / 256), dim3(256), 0, H.s, H.P, nslabs, (int64_t)m1p * m2p, m1, m2, m2p, H.G);
+    const int Cr = std::min(nslabs, 64);
+    if ((size_t)Cr * m1 * m2 > H.Gpart_elems) { hipFree(H.Gpart); H.Gpart = nullptr; H.Gpart_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.Gpart, (size_t)Cr * m1 * m2 * sizeof(double))); if (!H.err) H.Gpart_elems = (size_t)Cr * m1 * m2; }
+    if (H.err) return;
+    hipLaunchKernelGGL(hope_reduce1_kernel, dim3((m1 * m2 + 255) / 256, Cr), dim3(256), 0, H.s, H.P, nslabs, (int64_t)m1p * m2p, m1, m2, m2p, Cr, H.Gpart);
+    hipLaunchKernelGGL(hope_reduce2_kernel, dim3((m1 * m2 + 255) / 256), dim3(256), 0, H.s, H.Gpart, Cr, m1 * m2, H.G);
     HOPE_TRY(H, hipMemcpyAsync(Gh.data(), H.G, (size_t)m1 * m2 * sizeof(double), hipMemcpyDeviceToHost, H.s));
     HOPE_TRY(H, hipStreamSynchronize(H.s));
 }
@@ -638,8 +655,9 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
 
     std::vector<double> sig_old(k, 0.0), sig(k, 0.0), Wv, ev;
     int mc = 0, restarts_done = 0;
-    double last_change = 1.0;
+    double last_change = 1.0, last_residual = 1.0;
     bool exact = false;
+    const bool debug = getenv("GEMHIP_HOPE_DEBUG") != nullptr;
     for (int rs = 0; rs <= max_restarts && !H.err; ++rs) {
         mc = m0;
         int prev_off = 0, prev_b = m0;
@@ -665,6 +683,15 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
             };
             project(prev_b);
             project(prev_b);
+            if (j == 1 && rs > 0 && sig_old[0] > 0) {
+                // V_0 holds the Ritz vectors of the previous cycle (descending sigma): what is left of S^T S v_c after
+                // projecting out span(V_0) is exactly the residual  ||S^T S v_c - sigma_c^2 v_c||  of Ritz pair c
+                std::vector<double> D;
+                gram(H, W0, ldb, prev_b, W0, ldb, prev_b, D);
+                double r2 = 0.0;
+                for (int c = 0; c < std::min(k, prev_b) && !H.err; ++c) r2 = std::max(r2, D[(size_t)c * prev_b + c]);
+                last_residual = std::sqrt(r2) / (sig_old[0] * sig_old[0]);
+            }
             int nb = orth(H, W0, ldb, prev_b, Tmp, ldm, 1e-11, 1e-12 * ref_energy);
             if (nb > 0) {
                 project(nb);
@@ -691,6 +718,7 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
         last_change = sig[0] > 0 ? change / sig[0] : 0.0;
         sig_old = sig;
         restarts_done = rs;
+        if (debug) fprintf(stderr, "[hope] cycle %d basis %d sigma_k %.6g sigma_1 %.6g change %.3e residual(prev cycle) %.3e\n", rs, mc, sig[k - 1], sig[0], last_change, last_residual);
         exact = (mc >= n) || (krylov_steps == 0 && false);
         const bool done = exact || (rs > 0 && last_change < tol) || rs == max_restarts;
         if (done) break;
@@ -729,7 +757,7 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
     if (stats && !H.err) {
         stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = terms; stats[4] = mc; stats[5] = restarts_done;
-        stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = 0; stats[11] = 0;
+        stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual; stats[11] = 0;
     }
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
