@@ -247,12 +247,14 @@ class HopeWorkload(object):
 
     def reset_counters(self):
         self.dev_s, self.spmm, self.spmm_cols, self.calls = 0.0, 0.0, 0.0, 0
+        self.spmm_s, self.eig_s = 0.0, 0.0
 
     def step(self):
         _hip.check(_hip.lib().gemhip_hope(self.n, len(self.col), _hip.ptr(self.row_ptr, C.c_int64), _hip.ptr(self.col, C.c_int32), None,
                                           0.01, self.k, 16, 3, 20, 1e-5, 20260923, _hip.ptr(self.U, C.c_float), _hip.ptr(self.V, C.c_float),
                                           _hip.ptr(self.sig, C.c_float), self.stats))
         self.dev_s += self.stats[0]; self.spmm += self.stats[1]; self.spmm_cols += self.stats[2]; self.calls += 1
+        self.spmm_s = getattr(self, 'spmm_s', 0.0) + self.stats[11]; self.eig_s = getattr(self, 'eig_s', 0.0) + self.stats[8]
 
     def units_per_step(self):
         return self.n * self.world
@@ -262,11 +264,16 @@ class HopeWorkload(object):
         launches = self.spmm
         bavg = self.spmm_cols / launches
         algo = 8.0 * self.n_edges + 4.0 * (self.n + 1) + 8.0 * self.n * bavg
-        return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
-                'algorithmic_bytes_per_launch': algo, 'spmm_launches_per_step': launches / self.calls, 'avg_block_columns': bavg,
-                'device_seconds_per_step': self.dev_s / self.calls, 'restarts': self.stats[5], 'katz_terms': self.stats[3],
-                'note': 'per-kernel launch time comes from the rocprofv3 summary in profiles/ (the solver interleaves SpMM, MFMA Gram/GEMM '
-                        'and host eigensolves inside one blocking C call)'}
+        avg_s = self.spmm_s / launches
+        ach = algo / avg_s / 1e9
+        gather = (4.0 * bavg + 8.0) * self.n_edges + 8.0 * self.n * bavg
+        return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6, 'spmm_launches_per_step': launches / self.calls,
+                'avg_block_columns': bavg, 'device_seconds_per_step': self.dev_s / self.calls, 'spmm_seconds_per_step': self.spmm_s / self.calls,
+                'host_eig_seconds_per_step': self.eig_s / self.calls, 'restarts': self.stats[5], 'katz_terms': self.stats[3],
+                'note': 'algorithmic = SURVEY 8d compulsory bytes of one SpMM (8 nnz + 4(n+1) + 8 n b: the dense block is read once); the row '
+                        'gathers themselves move %.3g B per launch = %.0f GB/s out of L2 / Infinity Cache (the %d MB block fits on chip); launch '
+                        'time = HIP events around the back-to-back SpMM runs inside the solver' % (gather, gather / avg_s / 1e9, int(4 * self.n * bavg / 1e6))}
 
     def cpu_baseline(self, budget_s=30.0):
         """hope.py:28-36 cannot form its dense S at n=100k (three 80 GB matrices), and scipy svds with sparse-LU solves

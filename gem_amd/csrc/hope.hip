@@ -396,6 +396,7 @@ struct Hope {
     float *Csmall = nullptr; size_t C_elems = 0;     // device small matrix for tsgemm
     hipStream_t s = nullptr;
     double spmm_count = 0, spmm_cols = 0, eig_seconds = 0, eig_calls = 0;   // statistics
+    hipEvent_t sp0 = nullptr, sp1 = nullptr; double spmm_ms = 0; bool time_spmm = false;
     int err = 0;
     ~Hope()
     {
@@ -528,8 +529,21 @@ int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, doub
 
 // Z = S X  (X: n x b):  W0 = beta A X ; Z <- W0 + beta A Z, `terms` times  => sum_{t=1..terms+1} (beta A)^t X.
 // W0, T0, T1: scratch n x b with leading dimension ldt.
+struct SpmmTimer {           // HIP events around a run of back-to-back SpMM launches (nothing else is enqueued in between)
+    Hope &H;
+    explicit SpmmTimer(Hope &h) : H(h) { if (H.time_spmm && !H.err) hipEventRecord(H.sp0, H.s); }
+    ~SpmmTimer()
+    {
+        if (H.time_spmm && !H.err) {
+            hipEventRecord(H.sp1, H.s); hipEventSynchronize(H.sp1);
+            float ms = 0.f; hipEventElapsedTime(&ms, H.sp0, H.sp1); H.spmm_ms += ms;
+        }
+    }
+};
+
 void apply_S(Hope &H, const float *X, int ldx, int b, int terms, float *T0, float *T1, float *W0, int ldt, float *Out, int ldo)
 {
+    SpmmTimer timer(H);
     spmm(H, false, H.beta, X, ldx, nullptr, 0, W0, ldt, b);
     if (terms == 0) {
         HOPE_TRY(H, hipMemcpy2DAsync(Out, (size_t)ldo * sizeof(float), W0, (size_t)ldt * sizeof(float), (size_t)b * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
@@ -549,6 +563,7 @@ void apply_S(Hope &H, const float *X, int ldx, int b, int terms, float *T0, floa
 // Z = S^T Y = beta A^T (I - beta A^T)^-1 Y :  R <- Y + beta A^T R, then Z = beta A^T R.
 void apply_ST(Hope &H, const float *Y, int ldy, int b, int terms, float *T0, float *T1, int ldt, float *Out, int ldo)
 {
+    SpmmTimer timer(H);
     const float *rin = Y; int ldr = ldy;
     for (int t = 0; t < terms; ++t) {
         float *rout = (t & 1) ? T1 : T0;
@@ -645,7 +660,7 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     dalloc(&Vall, ldm); dalloc(&Ball, ldm); dalloc(&Wk, ldb); dalloc(&T0, ldb); dalloc(&T1, ldb); dalloc(&W0, ldb); dalloc(&Tmp, ldm);
     auto cleanup = [&]() { hipFree(Vall); hipFree(Ball); hipFree(Wk); hipFree(T0); hipFree(T1); hipFree(W0); hipFree(Tmp); };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (!H.err) { HOPE_TRY(H, hipEventCreate(&ev0)); HOPE_TRY(H, hipEventCreate(&ev1)); }
+    if (!H.err) { HOPE_TRY(H, hipEventCreate(&ev0)); HOPE_TRY(H, hipEventCreate(&ev1)); HOPE_TRY(H, hipEventCreate(&H.sp0)); HOPE_TRY(H, hipEventCreate(&H.sp1)); H.time_spmm = (stats != nullptr); }
     if (H.err) { cleanup(); return H.err; }
     hipEventRecord(ev0, H.s);
 
@@ -757,10 +772,12 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
     if (stats && !H.err) {
         stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = terms; stats[4] = mc; stats[5] = restarts_done;
-        stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual; stats[11] = 0;
+        stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual; stats[11] = H.spmm_ms * 1e-3;
     }
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
+    if (H.sp0) hipEventDestroy(H.sp0);
+    if (H.sp1) hipEventDestroy(H.sp1);
     cleanup();
     return H.err;
 }

@@ -30,6 +30,6 @@ def learn(model, graph):
                                       _hip.ptr(U, C.c_float), _hip.ptr(V, C.c_float), _hip.ptr(sig, C.c_float), stats))
     model._sigma = sig.astype(np.float64)
     model._stats = dict(zip(('device_seconds', 'spmm_launches', 'spmm_columns', 'katz_terms', 'basis_columns', 'restarts',
-                             'last_sigma_change', 'beta_sigma_max', 'host_eig_seconds', 'host_eig_calls'), list(stats)))
+                             'last_sigma_change', 'beta_sigma_max', 'host_eig_seconds', 'host_eig_calls', 'ritz_residual', 'spmm_seconds'), list(stats)))
     model._node_num = n
     return np.concatenate((U, V), axis=1).astype(np.float64)

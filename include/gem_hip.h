@@ -209,7 +209,8 @@ int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs,
  * max_restarts, tol (max relative change of the k singular values between cycles).
  * stats (optional, 12 doubles): {device_seconds, spmm_launches, spmm_columns_total, katz_terms,
  * basis_columns, restarts_done, last_sigma_change, beta*sigma_max(A) estimate, host_eig_seconds,
- * host_eig_calls, max relative Ritz residual of the previous cycle, 0}.
+ * host_eig_calls, max relative Ritz residual of the previous cycle,
+ * seconds inside SpMM launches (HIP events)}.
  * Returns GEMHIP_E_NOTCONVERGED when beta*sigma_max(A) >= 0.95 (Katz series too slow). */
 int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
                 float beta, int32_t k, int32_t oversample, int32_t krylov_steps,
