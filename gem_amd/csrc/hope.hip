@@ -387,6 +387,7 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
 struct Hope {
     int64_t n = 0, nnz = 0;
     float beta = 0.f;
+    int mode = 0;                                    // 0: S = Katz (HOPE); 1: S = I + D^-1/2 A D^-1/2 (symmetric, Laplacian Eigenmaps)
     int64_t *rp = nullptr, *rpT = nullptr;
     int32_t *ci = nullptr, *ciT = nullptr;
     float *va = nullptr, *vaT = nullptr;
@@ -544,6 +545,7 @@ struct SpmmTimer {           // HIP events around a run of back-to-back SpMM lau
 void apply_S(Hope &H, const float *X, int ldx, int b, int terms, float *T0, float *T1, float *W0, int ldt, float *Out, int ldo)
 {
     SpmmTimer timer(H);
+    if (H.mode == 1) { spmm(H, false, 1.0f, X, ldx, X, ldx, Out, ldo, b); return; }          // (I + M) X
     spmm(H, false, H.beta, X, ldx, nullptr, 0, W0, ldt, b);
     if (terms == 0) {
         HOPE_TRY(H, hipMemcpy2DAsync(Out, (size_t)ldo * sizeof(float), W0, (size_t)ldt * sizeof(float), (size_t)b * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
@@ -564,6 +566,7 @@ void apply_S(Hope &H, const float *X, int ldx, int b, int terms, float *T0, floa
 void apply_ST(Hope &H, const float *Y, int ldy, int b, int terms, float *T0, float *T1, int ldt, float *Out, int ldo)
 {
     SpmmTimer timer(H);
+    if (H.mode == 1) { spmm(H, false, 1.0f, Y, ldy, Y, ldy, Out, ldo, b); return; }          // symmetric operator
     const float *rin = Y; int ldr = ldy;
     for (int t = 0; t < terms; ++t) {
         float *rout = (t & 1) ? T1 : T0;
@@ -576,81 +579,11 @@ void apply_ST(Hope &H, const float *Y, int ldy, int b, int terms, float *T0, flo
 }  // namespace
 
 // ------------------------------------------------------------------- host API
-extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
-                           int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS,
-                           float *V_sqrtS, float *sigma, double *stats)
+// Restarted block-Krylov SVD of the operator the Hope state encodes (H.mode).  out_mode 0: U sqrt(S), V sqrt(S) (HOPE);
+// out_mode 1: unit right singular vectors only (symmetric operators: eigenvectors).  sigma ascending.
+static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed,
+                      int terms, double br, int out_mode, float *U_sqrtS, float *V_sqrtS, float *sigma, double *stats)
 {
-    GEMHIP_REQUIRE(n >= 2 && nnz >= 0 && row_ptr && (nnz == 0 || col), "hope: bad CSR arguments");
-    GEMHIP_REQUIRE(k >= 1 && k < n, "hope: k=%d must satisfy 1 <= k < n=%lld (svds requirement)", k, (long long)n);
-    GEMHIP_REQUIRE(U_sqrtS && V_sqrtS && sigma, "hope: output pointers are NULL");
-    GEMHIP_REQUIRE(oversample >= 0 && krylov_steps >= 1 && max_restarts >= 0, "hope: need oversample >= 0, krylov_steps >= 1, max_restarts >= 0");
-    GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "hope: row_ptr inconsistent with nnz");
-    Hope H;
-    H.n = n; H.nnz = nnz; H.beta = beta;
-    g_eig_seconds = 0.0; g_eig_calls = 0.0;
-    // transpose on the host (counting sort), values default to 1
-    std::vector<int64_t> rpT(n + 1, 0);
-    std::vector<int32_t> ciT(std::max<int64_t>(nnz, 1));
-    std::vector<float> va(std::max<int64_t>(nnz, 1)), vaT(std::max<int64_t>(nnz, 1));
-    for (int64_t e = 0; e < nnz; ++e) {
-        GEMHIP_REQUIRE(col[e] >= 0 && col[e] < n, "hope: column %d outside [0,%lld)", col[e], (long long)n);
-        va[e] = w ? w[e] : 1.0f;
-        ++rpT[col[e] + 1];
-    }
-    for (int64_t i = 0; i < n; ++i) rpT[i + 1] += rpT[i];
-    {
-        std::vector<int64_t> at(rpT.begin(), rpT.end() - 1);
-        for (int64_t i = 0; i < n; ++i)
-            for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { const int64_t q = at[col[e]]++; ciT[q] = (int32_t)i; vaT[q] = va[e]; }
-    }
-    // Neumann terms from a power-iteration estimate of rho(A): bound by the max absolute row/col sum too
-    double rs_max = 0.0, cs_max = 0.0;
-    {
-        std::vector<double> cs(n, 0.0);
-        for (int64_t i = 0; i < n; ++i) {
-            double rs = 0.0;
-            for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { rs += std::fabs(va[e]); cs[col[e]] += std::fabs(va[e]); }
-            rs_max = std::max(rs_max, rs);
-        }
-        for (int64_t i = 0; i < n; ++i) cs_max = std::max(cs_max, cs[i]);
-    }
-    double rho = 0.0;
-    {   // power iteration on A^T A (host, 40 steps): sigma_max(A) >= rho(A); converges from below, hence the margin
-        std::vector<double> x(n), y(n), z(n);
-        for (int64_t i = 0; i < n; ++i) x[i] = 1.0 + 0.37 * std::sin(12.9898 * (double)(i + 1));
-        for (int it = 0; it < 40; ++it) {
-            for (int64_t i = 0; i < n; ++i) {
-                double sacc = 0.0;
-                for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) sacc += va[e] * x[col[e]];
-                y[i] = sacc;
-            }
-            std::fill(z.begin(), z.end(), 0.0);
-            for (int64_t i = 0; i < n; ++i)
-                for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) z[col[e]] += va[e] * y[i];
-            double nx = 0.0, nz = 0.0;
-            for (int64_t i = 0; i < n; ++i) { nx += x[i] * x[i]; nz += z[i] * z[i]; }
-            if (nz == 0.0 || nx == 0.0) break;
-            rho = std::sqrt(std::sqrt(nz / nx));
-            const double inv = 1.0 / std::sqrt(nz);
-            for (int64_t i = 0; i < n; ++i) x[i] = z[i] * inv;
-        }
-        rho = std::min(std::max(rho * 1.1, 1e-30), std::sqrt(rs_max * cs_max));
-    }
-    const double br = std::fabs((double)beta) * rho;
-    if (!(br < 0.95))
-        return fail(GEMHIP_E_NOTCONVERGED, "hope: beta*rho(A) ~ %.3f >= 0.95: the Katz series (I - beta A)^-1 = sum (beta A)^t does not converge fast "
-                                           "enough on this graph (the reference forms the dense inverse); lower beta", br);
-    int terms = (br <= 0.0) ? 0 : (int)std::ceil(std::log(1e-8) / std::log(br));
-    terms = std::max(1, std::min(terms, 400));
-
-    int devid = 0;
-    if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "hope: no HIP device");
-    auto up = [&](void **dp, const void *hp, size_t bytes) { HOPE_TRY(H, hipMalloc(dp, std::max<size_t>(bytes, 16))); if (!H.err && bytes) HOPE_TRY(H, hipMemcpy(*dp, hp, bytes, hipMemcpyHostToDevice)); };
-    up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
-    up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
-    if (H.err) return H.err;
-
-    // ---- block Krylov on S^T S ------------------------------------------------------------
     const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
     const int mmax = (int)std::min<int64_t>(std::min<int64_t>((int64_t)b * (krylov_steps + 1), n), 512);
     GEMHIP_REQUIRE(b <= 512 && k <= mmax, "hope: k + oversample = %d too large (max 512)", b);
@@ -753,19 +686,22 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
             const int src = mc - k + j;                      // ascending eigenvalue index
             const double s = std::sqrt(std::max(ev[src], 0.0));
             sigma[j] = (float)s;
-            const double su = s > 0 ? 1.0 / std::sqrt(s) : 0.0, sv = std::sqrt(s);
+            const double su = out_mode == 1 ? (s > 0 ? 1.0 / s : 0.0) : (s > 0 ? 1.0 / std::sqrt(s) : 0.0), sv = out_mode == 1 ? 1.0 : std::sqrt(s);
             for (int i = 0; i < mc; ++i) { Cu[(size_t)i * k + j] = Wv[(size_t)i * mc + src] * su; Cv[(size_t)i * k + j] = Wv[(size_t)i * mc + src] * sv; }
         }
-        tsgemm(H, Ball, ldm, mc, Cu, k, 1.0f, nullptr, 0, Tmp, ldm);
-        HOPE_TRY(H, hipMemcpy2D(U_sqrtS, (size_t)k * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)k * sizeof(float), n, hipMemcpyDeviceToHost));
+        if (U_sqrtS) {
+            tsgemm(H, Ball, ldm, mc, Cu, k, 1.0f, nullptr, 0, Tmp, ldm);
+            HOPE_TRY(H, hipMemcpy2D(U_sqrtS, (size_t)k * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)k * sizeof(float), n, hipMemcpyDeviceToHost));
+        }
         tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, ldm);
         HOPE_TRY(H, hipMemcpy2D(V_sqrtS, (size_t)k * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)k * sizeof(float), n, hipMemcpyDeviceToHost));
         // deterministic sign: largest-magnitude entry of each left vector positive (svds signs are arbitrary)
         for (int j = 0; j < k; ++j) {
+            const float *ref = U_sqrtS ? U_sqrtS : V_sqrtS;
             int64_t arg = 0; float best = 0.f;
-            for (int64_t i = 0; i < n; ++i) { const float a = std::fabs(U_sqrtS[i * k + j]); if (a > best) { best = a; arg = i; } }
-            if (U_sqrtS[arg * k + j] < 0.f)
-                for (int64_t i = 0; i < n; ++i) { U_sqrtS[i * k + j] = -U_sqrtS[i * k + j]; V_sqrtS[i * k + j] = -V_sqrtS[i * k + j]; }
+            for (int64_t i = 0; i < n; ++i) { const float a = std::fabs(ref[i * k + j]); if (a > best) { best = a; arg = i; } }
+            if (ref[arg * k + j] < 0.f)
+                for (int64_t i = 0; i < n; ++i) { if (U_sqrtS) U_sqrtS[i * k + j] = -U_sqrtS[i * k + j]; V_sqrtS[i * k + j] = -V_sqrtS[i * k + j]; }
         }
     }
     float ms = 0.f;
@@ -782,6 +718,126 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     return H.err;
 }
 
+
+extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
+                           int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS,
+                           float *V_sqrtS, float *sigma, double *stats)
+{
+    GEMHIP_REQUIRE(n >= 2 && nnz >= 0 && row_ptr && (nnz == 0 || col), "hope: bad CSR arguments");
+    GEMHIP_REQUIRE(k >= 1 && k < n, "hope: k=%d must satisfy 1 <= k < n=%lld (svds requirement)", k, (long long)n);
+    GEMHIP_REQUIRE(U_sqrtS && V_sqrtS && sigma, "hope: output pointers are NULL");
+    GEMHIP_REQUIRE(oversample >= 0 && krylov_steps >= 1 && max_restarts >= 0, "hope: need oversample >= 0, krylov_steps >= 1, max_restarts >= 0");
+    GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "hope: row_ptr inconsistent with nnz");
+    Hope H;
+    H.n = n; H.nnz = nnz; H.beta = beta;
+    g_eig_seconds = 0.0; g_eig_calls = 0.0;
+    // transpose on the host (counting sort), values default to 1
+    std::vector<int64_t> rpT(n + 1, 0);
+    std::vector<int32_t> ciT(std::max<int64_t>(nnz, 1));
+    std::vector<float> va(std::max<int64_t>(nnz, 1)), vaT(std::max<int64_t>(nnz, 1));
+    for (int64_t e = 0; e < nnz; ++e) {
+        GEMHIP_REQUIRE(col[e] >= 0 && col[e] < n, "hope: column %d outside [0,%lld)", col[e], (long long)n);
+        va[e] = w ? w[e] : 1.0f;
+        ++rpT[col[e] + 1];
+    }
+    for (int64_t i = 0; i < n; ++i) rpT[i + 1] += rpT[i];
+    {
+        std::vector<int64_t> at(rpT.begin(), rpT.end() - 1);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { const int64_t q = at[col[e]]++; ciT[q] = (int32_t)i; vaT[q] = va[e]; }
+    }
+    // Neumann terms from a power-iteration estimate of rho(A): bound by the max absolute row/col sum too
+    double rs_max = 0.0, cs_max = 0.0;
+    {
+        std::vector<double> cs(n, 0.0);
+        for (int64_t i = 0; i < n; ++i) {
+            double rs = 0.0;
+            for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { rs += std::fabs(va[e]); cs[col[e]] += std::fabs(va[e]); }
+            rs_max = std::max(rs_max, rs);
+        }
+        for (int64_t i = 0; i < n; ++i) cs_max = std::max(cs_max, cs[i]);
+    }
+    double rho = 0.0;
+    {   // power iteration on A^T A (host, 40 steps): sigma_max(A) >= rho(A); converges from below, hence the margin
+        std::vector<double> x(n), y(n), z(n);
+        for (int64_t i = 0; i < n; ++i) x[i] = 1.0 + 0.37 * std::sin(12.9898 * (double)(i + 1));
+        for (int it = 0; it < 40; ++it) {
+            for (int64_t i = 0; i < n; ++i) {
+                double sacc = 0.0;
+                for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) sacc += va[e] * x[col[e]];
+                y[i] = sacc;
+            }
+            std::fill(z.begin(), z.end(), 0.0);
+            for (int64_t i = 0; i < n; ++i)
+                for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) z[col[e]] += va[e] * y[i];
+            double nx = 0.0, nz = 0.0;
+            for (int64_t i = 0; i < n; ++i) { nx += x[i] * x[i]; nz += z[i] * z[i]; }
+            if (nz == 0.0 || nx == 0.0) break;
+            rho = std::sqrt(std::sqrt(nz / nx));
+            const double inv = 1.0 / std::sqrt(nz);
+            for (int64_t i = 0; i < n; ++i) x[i] = z[i] * inv;
+        }
+        rho = std::min(std::max(rho * 1.1, 1e-30), std::sqrt(rs_max * cs_max));
+    }
+    const double br = std::fabs((double)beta) * rho;
+    if (!(br < 0.95))
+        return fail(GEMHIP_E_NOTCONVERGED, "hope: beta*rho(A) ~ %.3f >= 0.95: the Katz series (I - beta A)^-1 = sum (beta A)^t does not converge fast "
+                                           "enough on this graph (the reference forms the dense inverse); lower beta", br);
+    int terms = (br <= 0.0) ? 0 : (int)std::ceil(std::log(1e-8) / std::log(br));
+    terms = std::max(1, std::min(terms, 400));
+
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "hope: no HIP device");
+    auto up = [&](void **dp, const void *hp, size_t bytes) { HOPE_TRY(H, hipMalloc(dp, std::max<size_t>(bytes, 16))); if (!H.err && bytes) HOPE_TRY(H, hipMemcpy(*dp, hp, bytes, hipMemcpyHostToDevice)); };
+    up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
+    up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
+    if (H.err) return H.err;
+
+    return krylov_svd(H, n, k, oversample, krylov_steps, max_restarts, tol, seed, terms, br, 0, U_sqrtS, V_sqrtS, sigma, stats);
+}
+
+// ------------------------------------------------------------------ Laplacian Eigenmaps
+// gem/embedding/lap.py:21-37: w, v = eigs(normalized_laplacian(graph.to_undirected()), k=d+1, which='SM'); X = v[:, 1:].
+// The d+1 SMALLEST eigenpairs of L_sym = I - D^-1/2 A D^-1/2 are the d+1 LARGEST of T = I + D^-1/2 A D^-1/2 (symmetric,
+// positive semi-definite, eigenvalue 2 - w): same block-Krylov machinery, one SpMM per operator application.
+// Input: CSR of the SYMMETRIC weighted adjacency; the normalisation is done here.  eigvals: the k smallest eigenvalues of
+// L_sym ascending; V_out [n][k] unit eigenvectors in that order (column 0 = the trivial one lap.py drops).
+extern "C" int gemhip_lap_eigmap(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, int32_t k, int32_t oversample,
+                                 int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed, float *V_out, float *eigvals, double *stats)
+{
+    GEMHIP_REQUIRE(n >= 2 && nnz >= 0 && row_ptr && (nnz == 0 || col), "lap_eigmap: bad CSR arguments");
+    GEMHIP_REQUIRE(k >= 1 && k < n && V_out && eigvals, "lap_eigmap: need 1 <= k < n and output buffers");
+    GEMHIP_REQUIRE(oversample >= 0 && krylov_steps >= 1 && max_restarts >= 0, "lap_eigmap: bad solver parameters");
+    GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "lap_eigmap: row_ptr inconsistent with nnz");
+    Hope H;
+    H.n = n; H.nnz = nnz; H.beta = 1.0f; H.mode = 1;
+    g_eig_seconds = 0.0; g_eig_calls = 0.0;
+    std::vector<double> dinv(n, 0.0);
+    for (int64_t i = 0; i < n; ++i) {
+        double deg = 0.0;
+        for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+            GEMHIP_REQUIRE(col[e] >= 0 && col[e] < n, "lap_eigmap: column %d outside [0,%lld)", col[e], (long long)n);
+            deg += w ? w[e] : 1.0;
+        }
+        dinv[i] = deg > 0.0 ? 1.0 / std::sqrt(deg) : 0.0;       // networkx: isolated nodes get 0
+    }
+    std::vector<float> va(std::max<int64_t>(nnz, 1));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) va[e] = (float)(dinv[i] * (w ? w[e] : 1.0) * dinv[col[e]]);
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "lap_eigmap: no HIP device");
+    auto up = [&](void **dp, const void *hp, size_t bytes) { HOPE_TRY(H, hipMalloc(dp, std::max<size_t>(bytes, 16))); if (!H.err && bytes) HOPE_TRY(H, hipMemcpy(*dp, hp, bytes, hipMemcpyHostToDevice)); };
+    up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
+    if (H.err) return H.err;
+    std::vector<float> sig(k);
+    const int rc = krylov_svd(H, n, k, oversample, krylov_steps, max_restarts, tol, seed, 0, 0.0, 1, nullptr, V_out, sig.data(), stats);
+    if (rc) return rc;
+    // sigma ascending = (2 - w) ascending; lap.py wants w ascending: reverse the columns
+    for (int j = 0; j < k; ++j) eigvals[j] = 2.0f - sig[k - 1 - j];
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < k / 2; ++j) std::swap(V_out[i * k + j], V_out[i * k + (k - 1 - j)]);
+    return GEMHIP_OK;
+}
 
 // ------------------------------------------------------------------ building blocks, exposed for kernel-level parity tests
 extern "C" int gemhip_set_sym_eig_callback(int (*fn)(int32_t, double *, double *))

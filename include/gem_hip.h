@@ -217,6 +217,16 @@ int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *c
                 int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS, float *V_sqrtS,
                 float *sigma, double *stats);
 
+/* ------------------------------------------------ Laplacian Eigenmaps ("next")
+ * Replaces gem/embedding/lap.py:21-37: eigs(nx.normalized_laplacian_matrix(graph.to_undirected()), k=d+1, which='SM').
+ * Input: CSR of the SYMMETRIC weighted adjacency in graph.nodes order (w NULL = unit).  The k smallest eigenpairs of
+ * L_sym = I - D^-1/2 A D^-1/2 are computed as the k largest of I + D^-1/2 A D^-1/2 with the HOPE block-Krylov solver
+ * (one SpMM per operator application).  V_out [n][k]: unit eigenvectors, eigvals[k] ascending (column 0 is the
+ * trivial eigenvector lap.py drops with v[:, 1:]).  stats: as gemhip_hope. */
+int gemhip_lap_eigmap(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
+                      int32_t k, int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol,
+                      uint64_t seed, float *V_out, float *eigvals, double *stats);
+
 /* HOPE building blocks, exposed so each kernel can be parity-tested on its own (host buffers in,
  * host buffers out, blocking).  Dense blocks are row-major with leading dimension = column count.
  *   sym_eig : host fp64 symmetric eigensolver used for the projected problems (A overwritten by

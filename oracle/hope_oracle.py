@@ -101,3 +101,17 @@ def align_signs(X, Xref, d):
         if np.dot(X[:, j], Xref[:, j]) + np.dot(X[:, k + j], Xref[:, k + j]) < 0:
             X[:, j] *= -1; X[:, k + j] *= -1
     return X
+
+
+def lap_eigmap_dense(n, src, dst, w, d):
+    """gem/embedding/lap.py:21-37 with a dense symmetric eigensolver: the d+1 smallest eigenpairs of
+    L_sym = I - D^-1/2 A D^-1/2 (nx.normalized_laplacian_matrix: isolated nodes get D^-1/2 = 0), X = v[:, 1:].
+    src/dst/w: the SYMMETRIC adjacency (both directions listed)."""
+    A = np.zeros((n, n))
+    A[np.asarray(src), np.asarray(dst)] = np.asarray(w, dtype=np.float64)
+    deg = A.sum(axis=1)
+    with np.errstate(divide='ignore'):
+        dinv = np.where(deg > 0, 1.0 / np.sqrt(deg), 0.0)
+    L = np.eye(n) - dinv[:, None] * A * dinv[None, :]
+    wv, v = np.linalg.eigh(L)
+    return v[:, 1:d + 1], wv[:d + 1]

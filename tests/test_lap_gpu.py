@@ -1,0 +1,47 @@
+"""Laplacian Eigenmaps on the GPU vs the reference golden (tests/karate_res/LaplacianEigenmaps.txt,
+asserted with np.allclose in tests/test_karate.py:47-50,76) and the dense oracle."""
+import numpy as np
+import pytest
+
+from oracle import hope_oracle
+from gem_amd.embedding.lap import LaplacianEigenmaps, symmetric_arrays
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+def align(X, ref):
+    X = X.copy()
+    for j in range(X.shape[1]):
+        if np.dot(X[:, j], ref[:, j]) < 0:
+            X[:, j] *= -1
+    return X
+
+
+def test_karate_matches_reference_golden(karate):
+    gold = np.loadtxt(golden_path('ref_karate_LaplacianEigenmaps.txt'))
+    m = LaplacianEigenmaps(d=2)
+    Y = m.learn_embedding(graph=karate, edge_f=None, is_weighted=True, no_python=True)
+    assert Y.shape == (34, 2) and m.get_method_name() == 'lap_eigmap_svd'
+    assert np.allclose(align(Y, gold), gold, atol=2e-5)
+    n, src, dst, w = symmetric_arrays(karate)
+    Xo, wo = hope_oracle.lap_eigmap_dense(n, src, dst, w, 2)
+    assert np.allclose(m._eigvals, wo, atol=2e-6) and abs(m._eigvals[0]) < 2e-6
+    assert m.get_reconstructed_adj(Y)[3, 5] == pytest.approx(m.get_edge_weight(3, 5))
+
+
+def test_sbm1024_matches_dense_oracle(sbm1024):
+    n, src, dst, w = symmetric_arrays(sbm1024)
+    for d in (2, 16):
+        m = LaplacianEigenmaps(d=d)
+        Y = m.learn_embedding(graph=sbm1024)
+        Xo, wo = hope_oracle.lap_eigmap_dense(n, src, dst, w, d)
+        assert np.allclose(m._eigvals, wo, atol=5e-6)
+        # the two community eigenvectors are separated from the bulk: compare them vector by vector
+        Ya = align(Y, Xo)
+        assert np.abs(Ya[:, :2] - Xo[:, :2]).max() < 2e-4
+        # whole subspace: projector distance
+        P = Y @ Y.T; Po = Xo @ Xo.T
+        assert np.linalg.norm(P - Po) <= 2e-2 * np.sqrt(d)
+    with pytest.raises(ValueError):
+        LaplacianEigenmaps(d=2).learn_embedding(graph=None)

@@ -31,3 +31,15 @@ def test_dense_and_operator_oracles_reproduce_reference_on_sbm(sbm1024):
     Xo, so = hope_oracle.hope_operator(A, 0.01, 32)
     assert np.allclose(so, s, rtol=1e-9)
     assert np.allclose(hope_oracle.align_signs(Xo, gold, 32), gold, atol=1e-6)
+
+
+def test_lap_eigmap_oracle_reproduces_reference_golden(karate):
+    """tests/karate_res/LaplacianEigenmaps.txt (np.allclose in tests/test_karate.py:47-50,76), mod eigenvector signs."""
+    from gem_amd.embedding.lap import symmetric_arrays
+    n, src, dst, w = symmetric_arrays(karate)
+    X, wv = hope_oracle.lap_eigmap_dense(n, src, dst, w, 2)
+    gold = np.loadtxt(golden_path('ref_karate_LaplacianEigenmaps.txt'))
+    for j in range(2):
+        if np.dot(X[:, j], gold[:, j]) < 0:
+            X[:, j] *= -1
+    assert np.allclose(X, gold) and abs(wv[0]) < 1e-12
