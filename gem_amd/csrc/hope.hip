@@ -184,6 +184,16 @@ __global__ __launch_bounds__(256) void hope_tsgemm_kernel(int64_t n, const float
     }
 }
 
+// Out[:, :b] = a X + b2 Y + c Z   (row-major blocks with their own leading dimensions)
+__global__ void hope_lincomb_kernel(int64_t n, int b, float a, const float *X, int ldx, float b2, const float *Y, int ldy, float c, const float *Z,
+                                    int ldz, float *Out, int ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * b) return;
+    const int64_t i = t / b; const int j = (int)(t - i * b);
+    Out[i * ldo + j] = a * X[i * ldx + j] + b2 * Y[i * ldy + j] + c * Z[i * ldz + j];
+}
+
 __global__ void hope_randn_kernel(float *X, int64_t n, int b, int ld, uint64_t seed)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,7 +397,8 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
 struct Hope {
     int64_t n = 0, nnz = 0;
     float beta = 0.f;
-    int mode = 0;                                    // 0: S = Katz (HOPE); 1: S = I + D^-1/2 A D^-1/2 (symmetric, Laplacian Eigenmaps)
+    int mode = 0;                                    // 0: S = Katz (HOPE); 1: S = I + D^-1/2 A D^-1/2 (Laplacian Eigenmaps);
+                                                     // 2: S = c I - (I-P)^T (I-P), P = D^-1 A (LLE), c in `beta`
     int64_t *rp = nullptr, *rpT = nullptr;
     int32_t *ci = nullptr, *ciT = nullptr;
     float *va = nullptr, *vaT = nullptr;
@@ -546,6 +557,14 @@ void apply_S(Hope &H, const float *X, int ldx, int b, int terms, float *T0, floa
 {
     SpmmTimer timer(H);
     if (H.mode == 1) { spmm(H, false, 1.0f, X, ldx, X, ldx, Out, ldo, b); return; }          // (I + M) X
+    if (H.mode == 2) {                                                                         // c X - N^T N X,  N = I - P
+        spmm(H, false, -1.0f, X, ldx, X, ldx, W0, ldt, b);                                     // W0 = N X = X - P X
+        spmm(H, true, 1.0f, W0, ldt, nullptr, 0, T0, ldt, b);                                  // T0 = P^T W0
+        if (!H.err)
+            hipLaunchKernelGGL(hope_lincomb_kernel, dim3((unsigned)((H.n * b + 255) / 256)), dim3(256), 0, H.s, H.n, b, H.beta, X, ldx, -1.0f, W0, ldt, 1.0f,
+                               T0, ldt, Out, ldo);                                             // c X - W0 + P^T W0
+        return;
+    }
     spmm(H, false, H.beta, X, ldx, nullptr, 0, W0, ldt, b);
     if (terms == 0) {
         HOPE_TRY(H, hipMemcpy2DAsync(Out, (size_t)ldo * sizeof(float), W0, (size_t)ldt * sizeof(float), (size_t)b * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
@@ -567,6 +586,14 @@ void apply_ST(Hope &H, const float *Y, int ldy, int b, int terms, float *T0, flo
 {
     SpmmTimer timer(H);
     if (H.mode == 1) { spmm(H, false, 1.0f, Y, ldy, Y, ldy, Out, ldo, b); return; }          // symmetric operator
+    if (H.mode == 2) {                                                                         // symmetric: same as apply_S (T0, T1 as scratch)
+        spmm(H, false, -1.0f, Y, ldy, Y, ldy, T1, ldt, b);
+        spmm(H, true, 1.0f, T1, ldt, nullptr, 0, T0, ldt, b);
+        if (!H.err)
+            hipLaunchKernelGGL(hope_lincomb_kernel, dim3((unsigned)((H.n * b + 255) / 256)), dim3(256), 0, H.s, H.n, b, H.beta, Y, ldy, -1.0f, T1, ldt, 1.0f,
+                               T0, ldt, Out, ldo);
+        return;
+    }
     const float *rin = Y; int ldr = ldy;
     for (int t = 0; t < terms; ++t) {
         float *rout = (t & 1) ? T1 : T0;
@@ -834,6 +861,76 @@ extern "C" int gemhip_lap_eigmap(int64_t n, int64_t nnz, const int64_t *row_ptr,
     if (rc) return rc;
     // sigma ascending = (2 - w) ascending; lap.py wants w ascending: reverse the columns
     for (int j = 0; j < k; ++j) eigvals[j] = 2.0f - sig[k - 1 - j];
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < k / 2; ++j) std::swap(V_out[i * k + j], V_out[i * k + (k - 1 - j)]);
+    return GEMHIP_OK;
+}
+
+// ------------------------------------------------------------------ Locally Linear Embedding
+// gem/embedding/lle.py:23-35: A row-normalised (l1), u, s, vt = svds(I - A, k=d+1, which='SM'); X = vt.T[:, 1:].
+// The d+1 smallest right singular vectors of N = I - P are the d+1 largest eigenvectors of c I - N^T N
+// (c >= sigma_max(N)^2), a symmetric PSD operator: two SpMMs (P, P^T) per application on the same block-Krylov core.
+// Input: CSR of the SYMMETRIC weighted adjacency in graph.nodes order; rows are l1-normalised here.
+// sing[k]: the k smallest singular values of I - P ascending; V_out [n][k] the matching right singular vectors.
+extern "C" int gemhip_lle(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, int32_t k, int32_t oversample,
+                          int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed, float *V_out, float *sing, double *stats)
+{
+    GEMHIP_REQUIRE(n >= 2 && nnz >= 0 && row_ptr && (nnz == 0 || col), "lle: bad CSR arguments");
+    GEMHIP_REQUIRE(k >= 1 && k < n && V_out && sing, "lle: need 1 <= k < n and output buffers");
+    GEMHIP_REQUIRE(oversample >= 0 && krylov_steps >= 1 && max_restarts >= 0, "lle: bad solver parameters");
+    GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "lle: row_ptr inconsistent with nnz");
+    Hope H;
+    H.n = n; H.nnz = nnz; H.mode = 2;
+    g_eig_seconds = 0.0; g_eig_calls = 0.0;
+    std::vector<float> va(std::max<int64_t>(nnz, 1)), vaT(std::max<int64_t>(nnz, 1));
+    std::vector<int64_t> rpT(n + 1, 0);
+    std::vector<int32_t> ciT(std::max<int64_t>(nnz, 1));
+    for (int64_t i = 0; i < n; ++i) {
+        double l1 = 0.0;
+        for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+            GEMHIP_REQUIRE(col[e] >= 0 && col[e] < n, "lle: column %d outside [0,%lld)", col[e], (long long)n);
+            l1 += std::fabs(w ? w[e] : 1.0);
+            ++rpT[col[e] + 1];
+        }
+        for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) va[e] = l1 > 0.0 ? (float)((w ? w[e] : 1.0) / l1) : 0.f;   // sklearn normalize(norm='l1')
+    }
+    for (int64_t i = 0; i < n; ++i) rpT[i + 1] += rpT[i];
+    {
+        std::vector<int64_t> at(rpT.begin(), rpT.end() - 1);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { const int64_t q = at[col[e]]++; ciT[q] = (int32_t)i; vaT[q] = va[e]; }
+    }
+    // c >= sigma_max(I - P)^2: power iteration on N^T N (host), with a margin
+    double c = 4.0;
+    {
+        std::vector<double> x(n), y(n), z(n);
+        for (int64_t i = 0; i < n; ++i) x[i] = 1.0 + 0.61 * std::sin(7.31 * (double)(i + 1));
+        double est = 0.0;
+        for (int it = 0; it < 60; ++it) {
+            for (int64_t i = 0; i < n; ++i) { double sacc = 0.0; for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) sacc += va[e] * x[col[e]]; y[i] = x[i] - sacc; }
+            for (int64_t i = 0; i < n; ++i) z[i] = y[i];
+            for (int64_t i = 0; i < n; ++i) for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) z[col[e]] -= va[e] * y[i];
+            double nx = 0.0, nz = 0.0;
+            for (int64_t i = 0; i < n; ++i) { nx += x[i] * x[i]; nz += z[i] * z[i]; }
+            if (nz == 0.0 || nx == 0.0) break;
+            est = std::sqrt(nz / nx);
+            const double inv = 1.0 / std::sqrt(nz);
+            for (int64_t i = 0; i < n; ++i) x[i] = z[i] * inv;
+        }
+        if (est > 0.0) c = est * 1.05;
+    }
+    H.beta = (float)c;
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "lle: no HIP device");
+    auto up = [&](void **dp, const void *hp, size_t bytes) { HOPE_TRY(H, hipMalloc(dp, std::max<size_t>(bytes, 16))); if (!H.err && bytes) HOPE_TRY(H, hipMemcpy(*dp, hp, bytes, hipMemcpyHostToDevice)); };
+    up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
+    up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
+    if (H.err) return H.err;
+    std::vector<float> sig(k);
+    const int rc = krylov_svd(H, n, k, oversample, krylov_steps, max_restarts, tol, seed, 0, 0.0, 1, nullptr, V_out, sig.data(), stats);
+    if (rc) return rc;
+    // eigenvalue of c I - N^T N = c - s^2 (ascending in sig) -> s ascending means reversing the columns
+    for (int j = 0; j < k; ++j) sing[j] = (float)std::sqrt(std::max(c - (double)sig[k - 1 - j], 0.0));
     for (int64_t i = 0; i < n; ++i)
         for (int j = 0; j < k / 2; ++j) std::swap(V_out[i * k + j], V_out[i * k + (k - 1 - j)]);
     return GEMHIP_OK;

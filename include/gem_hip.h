@@ -227,6 +227,13 @@ int gemhip_lap_eigmap(int64_t n, int64_t nnz, const int64_t *row_ptr, const int3
                       int32_t k, int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol,
                       uint64_t seed, float *V_out, float *eigvals, double *stats);
 
+/* Locally Linear Embedding.  Replaces gem/embedding/lle.py:23-35: svds(I - D^-1 A, k=d+1, which='SM').
+ * Input as gemhip_lap_eigmap (symmetric adjacency; rows are l1-normalised here).  sing[k]: the k smallest singular
+ * values of I - P ascending; V_out [n][k]: matching right singular vectors (column 0 ~ the constant vector lle.py drops). */
+int gemhip_lle(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, int32_t k,
+               int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed,
+               float *V_out, float *sing, double *stats);
+
 /* HOPE building blocks, exposed so each kernel can be parity-tested on its own (host buffers in,
  * host buffers out, blocking).  Dense blocks are row-major with leading dimension = column count.
  *   sym_eig : host fp64 symmetric eigensolver used for the projected problems (A overwritten by

@@ -115,3 +115,15 @@ def lap_eigmap_dense(n, src, dst, w, d):
     L = np.eye(n) - dinv[:, None] * A * dinv[None, :]
     wv, v = np.linalg.eigh(L)
     return v[:, 1:d + 1], wv[:d + 1]
+
+
+def lle_dense(n, src, dst, w, d):
+    """gem/embedding/lle.py:23-35 with a dense SVD: rows of the symmetric adjacency l1-normalised, the d+1 smallest
+    singular triplets of I - P, X = vt.T[:, 1:] (ascending singular value).  Returns (X, smallest singular values)."""
+    A = np.zeros((n, n))
+    A[np.asarray(src), np.asarray(dst)] = np.asarray(w, dtype=np.float64)
+    l1 = np.abs(A).sum(axis=1, keepdims=True)
+    P = np.divide(A, l1, out=np.zeros_like(A), where=l1 > 0)
+    u, s, vt = np.linalg.svd(np.eye(n) - P)
+    V = vt[::-1].T                                    # ascending singular value
+    return V[:, 1:d + 1], s[::-1][:d + 1]

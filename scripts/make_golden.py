@@ -91,7 +91,7 @@ def main():
     with open(os.path.join(REF, 'tests/data/sbm_node_labels.pickle'), 'rb') as f:
         lab = pickle.load(f, encoding='latin1')
     np.save(os.path.join(OUT, 'sbm1024_labels.npy'), np.asarray(lab.toarray().argmax(1)).ravel().astype(np.int16))
-    for name in ('HOPE', 'GraphFactorization', 'node2vec', 'LaplacianEigenmaps'):
+    for name in ('HOPE', 'GraphFactorization', 'node2vec', 'LaplacianEigenmaps', 'LocallyLinearEmbedding'):
         shutil.copy(os.path.join(REF, 'tests/karate_res/%s.txt' % name), os.path.join(OUT, 'ref_karate_%s.txt' % name))
     tgt = np.loadtxt(os.path.join(REF, 'tests/smb_res/GraphFactorization.txt'))
     np.savez_compressed(os.path.join(OUT, 'ref_sbm_GraphFactorization.npz'), X=tgt.astype(np.float32))

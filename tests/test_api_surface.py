@@ -6,11 +6,12 @@ import pytest
 from gem_amd.embedding.gf import GraphFactorization
 from gem_amd.embedding.hope import HOPE
 from gem_amd.embedding.lap import LaplacianEigenmaps
+from gem_amd.embedding.lle import LocallyLinearEmbedding
 from gem_amd.embedding.node2vec import node2vec
 from gem_amd.embedding.static_graph_embedding import StaticGraphEmbedding
 
 
-@pytest.mark.parametrize('cls', [HOPE, GraphFactorization, node2vec, LaplacianEigenmaps])
+@pytest.mark.parametrize('cls', [HOPE, GraphFactorization, node2vec, LaplacianEigenmaps, LocallyLinearEmbedding])
 def test_construct_without_args_and_error_conventions(cls):
     model = cls()
     assert isinstance(model, StaticGraphEmbedding)

@@ -45,3 +45,22 @@ def test_sbm1024_matches_dense_oracle(sbm1024):
         assert np.linalg.norm(P - Po) <= 2e-2 * np.sqrt(d)
     with pytest.raises(ValueError):
         LaplacianEigenmaps(d=2).learn_embedding(graph=None)
+
+
+def test_lle_karate_and_sbm(karate, sbm1024):
+    """LLE (lle.py:23-35): reference golden on karate (the reference only asserts abs(mean diff) < 0.3,
+    tests/test_karate.py:52-55,78 -- here it is matched vector by vector), dense oracle on SBM-1024."""
+    from gem_amd.embedding.lle import LocallyLinearEmbedding
+    gold = np.loadtxt(golden_path('ref_karate_LocallyLinearEmbedding.txt'))
+    m = LocallyLinearEmbedding(d=2)
+    Y = m.learn_embedding(graph=karate, edge_f=None, is_weighted=True, no_python=True)
+    assert abs(np.mean(gold - Y)) < 0.3
+    assert np.allclose(align(Y, gold), gold, atol=5e-5)
+    n, src, dst, w = symmetric_arrays(sbm1024)
+    m = LocallyLinearEmbedding(d=8)
+    Y = m.learn_embedding(graph=sbm1024)
+    Xo, so = hope_oracle.lle_dense(n, src, dst, w, 8)
+    # s = sqrt(c - lambda) in fp32: the trivial s=0 comes out as sqrt(eps*c) ~ 3e-4; the others carry full precision
+    assert np.allclose(m._singvals[1:], so[1:], atol=2e-6) and m._singvals[0] < 1e-3, (m._singvals, so)
+    Ya = align(Y, Xo)
+    assert np.abs(Ya[:, :2] - Xo[:, :2]).max() < 1e-3

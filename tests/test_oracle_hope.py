@@ -43,3 +43,16 @@ def test_lap_eigmap_oracle_reproduces_reference_golden(karate):
         if np.dot(X[:, j], gold[:, j]) < 0:
             X[:, j] *= -1
     assert np.allclose(X, gold) and abs(wv[0]) < 1e-12
+
+
+def test_lle_oracle_reproduces_reference_golden(karate):
+    """tests/karate_res/LocallyLinearEmbedding.txt -- reproduced exactly by running lle.py (with a shim for the removed
+    nx.to_scipy_sparse_matrix); the dense oracle matches it up to the sign of each singular vector."""
+    from gem_amd.embedding.lap import symmetric_arrays
+    n, src, dst, w = symmetric_arrays(karate)
+    X, s = hope_oracle.lle_dense(n, src, dst, w, 2)
+    gold = np.loadtxt(golden_path('ref_karate_LocallyLinearEmbedding.txt'))
+    for j in range(2):
+        if np.dot(X[:, j], gold[:, j]) < 0:
+            X[:, j] *= -1
+    assert np.allclose(X, gold, atol=1e-7) and s[0] < 1e-12
