@@ -159,6 +159,7 @@ def ptr(a, ctype):
 
 N2V_PAD_ZERO, N2V_UNIGRAM_QUIRK, N2V_DETERMINISTIC, N2V_UNIFORM_FIRST_HOP = 1, 2, 4, 8
 N2V_SNAP_COMPAT = 11
+N2V_SHARED_NEGATIVES = 64      # opt-in fast mode, not the reference's sampling (include/gem_hip.h)
 
 
 def as_i32(a):

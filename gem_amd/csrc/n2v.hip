@@ -451,14 +451,143 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
     if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
 }
 
+// OPT-IN variant (flag GEMHIP_N2V_SHARED_NEGATIVES): the five negative targets are drawn ONCE PER CENTRE WORD and shared
+// by all of its contexts, so their rows stay in registers next to the positive row (per centre: 2*(1+5) + 2*contexts
+// row transfers instead of 2 + 12*contexts).  This is NOT the reference's sampling (TrainModel draws fresh negatives
+// for every (centre, context) pair); it is the usual GPU word2vec trade and is validated on MAP only.
+template <int VEC, int NV>
+__global__ __launch_bounds__(256) void sgns_shared_kernel(SgnsArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    int32_t *tok = lds + wave * (A.walk_len + 2 * A.window * SGNS_NEG);
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (gw >= A.nwaves) return;
+    const int d = A.d, win = A.window;
+    const bool quirk = (A.flags & 2) != 0;
+    unsigned long long npairs = 0;
+    for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
+        const int32_t *walk = A.walks + wl * A.walk_len;
+        for (int k = lane; k < A.walk_len; k += WAVE) tok[k] = walk[k];
+        __builtin_amdgcn_wave_barrier();
+        const int64_t wid = A.walk_id_offset + wl;
+        const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
+        for (int pos = 0; pos < A.walk_len; ++pos) {
+            const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
+            if (word < 0) continue;
+            const int64_t t = A.token_offset + wl * A.walk_len + pos;
+            const int64_t tq = t - (t % 10000);
+            float alpha = A.alpha0 * (1.0f - (float)((double)tq / (double)A.denom));
+            alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
+            const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
+            const int b = (int)(rw.x % (uint32_t)win);
+            int32_t mine = -1;
+            if (lane >= 1 && lane <= SGNS_NEG) {
+                const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)lane << 16));
+                const uint32_t slot = mulhi_range(rn.x, A.n);
+                const int32_t X = quirk ? A.KT[slot] : (int32_t)slot;
+                mine = (u01(rn.y) < A.UT[X]) ? X : A.KT[X];
+            }
+            int32_t tgt[SGNS_NEG]; bool use[SGNS_NEG];
+#pragma unroll
+            for (int j = 0; j < SGNS_NEG; ++j) {
+                tgt[j] = __builtin_amdgcn_readlane(mine, j + 1);
+                use[j] = tgt[j] != word;
+#pragma unroll
+                for (int jp = 0; jp < j; ++jp) use[j] = use[j] && tgt[jp] != tgt[j];     // a repeated draw counts once
+            }
+            float yp[NV][VEC], yn[SGNS_NEG][NV][VEC];
+            float *pp = A.SynNeg + (int64_t)word * d;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
+#pragma unroll
+            for (int j = 0; j < SGNS_NEG; ++j) {
+                const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
+            }
+            for (int a = b; a < 2 * win + 1 - b; ++a) {
+                if (a == win) continue;
+                const int cp = pos - win + a;
+                if (cp < 0 || cp >= A.walk_len) continue;
+                const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[cp]);
+                if (ctx < 0) continue;
+                ++npairs;
+                float xc[NV][VEC], neu[NV][VEC];
+                float *pc = A.SynPos + (int64_t)ctx * d;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) neu[c][v] = 0.f;
+                {
+                    float part = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) part += xc[c][v] * yp[c][v];
+                    const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yp[c][v]; yp[c][v] += g * xc[c][v]; }
+                }
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) {
+                    if (!use[j]) continue;
+                    float part = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) part += xc[c][v] * yn[j][c][v];
+                    const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yn[j][c][v]; yn[j][c][v] += g * xc[c][v]; }
+                }
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
+                    st_row<VEC>(pc, d, lane, c, xc[c]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SGNS_NEG; ++j)
+                if (use[j]) {
+                    float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+                }
+#pragma unroll
+            for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
+}
+
+template <int VEC, int NV>
+void launch_sgns_shared(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL((sgns_shared_kernel<VEC, NV>), dim3(blocks), dim3(threads), lds, s, A);
+}
+
 using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
 template <int VEC, int NV, bool WIDE = false>
 void launch_sgns(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
 {
     hipLaunchKernelGGL((sgns_kernel<VEC, NV, WIDE>), dim3(blocks), dim3(threads), lds, s, A);
 }
-sgns_fn pick_sgns(int d, int64_t n = 0, bool allow_wide = false)
+sgns_fn pick_sgns(int d, int64_t n = 0, bool allow_wide = false, bool shared = false)
 {
+    if (shared) {
+        if (d % 2 == 0) { const int nv = (d + 127) / 128; return nv <= 1 ? launch_sgns_shared<2, 1> : nv <= 2 ? launch_sgns_shared<2, 2> : nv <= 4 ? launch_sgns_shared<2, 4> : nullptr; }
+        const int nv = (d + 63) / 64; return nv <= 1 ? launch_sgns_shared<1, 1> : nv <= 2 ? launch_sgns_shared<1, 2> : nv <= 4 ? launch_sgns_shared<1, 4> : nullptr;
+    }
     if (allow_wide && d == 128 && n > 0 && n * 512 < ((int64_t)1 << 32)) return launch_sgns<2, 1, true>;
     if (d % 2 == 0) {
         const int nv = (d + 127) / 128;
@@ -1068,7 +1197,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     }
     const size_t lds = per_wave * (threads / 64);
     GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window too large for LDS staging (%zu bytes)", lds);
-    pick_sgns(h->d, h->n, (flags & 32) != 0)(A, blocks, threads, lds, (hipStream_t)stream);
+    pick_sgns(h->d, h->n, (flags & 32) != 0, (flags & 64) != 0)(A, blocks, threads, lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());
     return GEMHIP_OK;
 }

@@ -125,6 +125,8 @@ int gemhip_gf_objective(int64_t n, int64_t m, const int32_t *src,
 #define GEMHIP_N2V_DETERMINISTIC 4
 #define GEMHIP_N2V_UNIFORM_FIRST_HOP 8
 #define GEMHIP_N2V_SNAP_COMPAT 11
+#define GEMHIP_N2V_SHARED_NEGATIVES 64 /* OPT-IN, NOT the reference's sampling: the 5 negatives are drawn once per centre word and shared
+                                         by its contexts (rows stay in registers: ~4x less table traffic); validated on MAP only */
 #define GEMHIP_N2V_WIDE_ROWS 32 /* A/B switch (d == 128): 16-byte sc1 buffer accesses from half a wave + v_permlane32_swap; measured slower than the default 8-byte path */
 
 typedef struct gemhip_n2v *gemhip_n2v_t;

@@ -183,3 +183,16 @@ def test_baseline_scale_properties():
     P, N = dev.sgns(128, 10, 1, 7, SNAP)
     assert np.isfinite(P).all() and np.isfinite(N).all() and 0.05 < np.abs(P).max() < 50
     dev.close()
+
+
+def test_shared_negatives_opt_in_keeps_map(sbm1024):
+    """GEMHIP_N2V_SHARED_NEGATIVES (flag 64) is NOT the reference's sampling; it must still land at the reference's quality."""
+    ref = json.load(open(golden_path('n2v_ref.json')))
+    maps = []
+    for seed in (1, 2, 3):
+        m = node2vec(d=16, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, seed=seed, flags=SNAP | 64)
+        Y = m.learn_embedding(graph=sbm1024, is_weighted=True)
+        maps.append(gr.evaluateStaticGraphReconstruction(sbm1024, m, Y, None)[0])
+    node2vec.hyper_params.pop('flags', None)
+    t1 = np.mean(ref['sbm1024_d16_t1'])
+    assert abs(np.mean(maps) - t1) <= 0.08 * t1, (maps, t1)
