@@ -47,6 +47,9 @@ _SIGS = {
     'gemhip_gf_plan_current': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'gemhip_gf_plan_info': (C.c_int, [C.c_void_p, i64p]),
     'gemhip_gf_objective': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, f32p, f64p]),
+    'gemhip_hope_plan_create': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.POINTER(C.c_void_p)]),
+    'gemhip_hope_plan_solve': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64, f32p, f32p, f32p, f64p]),
+    'gemhip_hope_plan_destroy': (C.c_int, [C.c_void_p]),
     'gemhip_hope': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_float, C.c_uint64, f32p, f32p, f32p, f64p]),
     'gemhip_lap_eigmap': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,

@@ -509,10 +509,10 @@ bool chol_inverse(int b, const std::vector<double> &G, double floor, std::vector
 // CholeskyQR step (Y <- Y R^-1); otherwise the Gram eigen-decomposition Y <- Y W L^-1/2 drops directions whose
 // relative energy is below `tol` or whose absolute energy is below `abs_floor` (rank revealing).  Two passes.
 // Returns the number of columns kept.
-int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, double abs_floor = 0.0)
+int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, double abs_floor = 0.0, int passes = 2)
 {
     int keep = b;
-    for (int pass = 0; pass < 2 && keep > 0 && !H.err; ++pass) {
+    for (int pass = 0; pass < passes && keep > 0 && !H.err; ++pass) {
         std::vector<double> G, w, C;
         gram(H, Y, ld, keep, Y, ld, keep, G);
         if (H.err) return 0;
@@ -640,23 +640,24 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
             // W = S^T S V_{j-1}
             apply_S(H, Vall + prev_off, ldm, prev_b, terms, T0, T1, W0, ldb, Wk, ldb);
             apply_ST(H, Wk, ldb, prev_b, terms, T0, T1, ldb, W0, ldb);
-            // energy of the new block before projection: what is left after projecting out the basis is only
-            // kept if it stands above fp32 rounding noise relative to this
+            // energy scale of the new block before projection (what is left after projecting out the basis is only kept if
+            // it stands above fp32 rounding noise relative to this): the block is S^T S applied to orthonormal columns, so
+            // sigma_1^4 from the previous cycle bounds it; the first cycle measures it
             double ref_energy = 0.0;
-            {
+            if (rs > 0 && sig_old[0] > 0) ref_energy = sig_old[0] * sig_old[0] * sig_old[0] * sig_old[0];
+            else {
                 std::vector<double> D;
                 gram(H, W0, ldb, prev_b, W0, ldb, prev_b, D);
                 for (int c = 0; c < prev_b && !H.err; ++c) ref_energy = std::max(ref_energy, D[(size_t)c * prev_b + c]);
             }
-            // full re-orthogonalisation against the basis so far, normalise, then repeat on the normalised block:
-            // a direction that survives the rank filter with small amplitude carries rounding noise that lies
-            // INSIDE span(Vall); after normalisation that noise is O(eps / amplitude), so project again.
+            // full re-orthogonalisation against the basis so far, normalise, then project again on the normalised block:
+            // a direction that survives the rank filter with small amplitude carries rounding noise that lies INSIDE
+            // span(Vall); after normalisation that noise is O(eps / amplitude)
             auto project = [&](int cols) {
                 std::vector<double> C;
                 gram(H, Vall, ldm, mc, W0, ldb, cols, C);
                 tsgemm(H, Vall, ldm, mc, C, cols, -1.0f, W0, ldb, W0, ldb);
             };
-            project(prev_b);
             project(prev_b);
             if (j == 1 && rs > 0 && sig_old[0] > 0) {
                 // V_0 holds the Ritz vectors of the previous cycle (descending sigma): what is left of S^T S v_c after
@@ -670,7 +671,7 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
             int nb = orth(H, W0, ldb, prev_b, Tmp, ldm, 1e-11, 1e-12 * ref_energy);
             if (nb > 0) {
                 project(nb);
-                nb = orth(H, W0, ldb, nb, Tmp, ldm, 1e-9, 0.25);      // unit columns: drop what lost half its norm
+                nb = orth(H, W0, ldb, nb, Tmp, ldm, 1e-9, 0.25, 1);   // unit columns: drop what lost half its norm; one polishing pass
             }
             nb = std::min(nb, mmax - mc);
             if (nb <= 0) break;
@@ -746,18 +747,19 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
 }
 
 
-extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
-                           int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS,
-                           float *V_sqrtS, float *sigma, double *stats)
+struct gemhip_hope_plan {
+    Hope H;
+    int terms = 1;
+    double br = 0.0;
+};
+
+// Graph-dependent setup of the Katz operator: A and A^T in CSR on the device, number of series terms from sigma_max(A).
+static int hope_setup(gemhip_hope_plan &P, int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta)
 {
     GEMHIP_REQUIRE(n >= 2 && nnz >= 0 && row_ptr && (nnz == 0 || col), "hope: bad CSR arguments");
-    GEMHIP_REQUIRE(k >= 1 && k < n, "hope: k=%d must satisfy 1 <= k < n=%lld (svds requirement)", k, (long long)n);
-    GEMHIP_REQUIRE(U_sqrtS && V_sqrtS && sigma, "hope: output pointers are NULL");
-    GEMHIP_REQUIRE(oversample >= 0 && krylov_steps >= 1 && max_restarts >= 0, "hope: need oversample >= 0, krylov_steps >= 1, max_restarts >= 0");
     GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "hope: row_ptr inconsistent with nnz");
-    Hope H;
+    Hope &H = P.H;
     H.n = n; H.nnz = nnz; H.beta = beta;
-    g_eig_seconds = 0.0; g_eig_calls = 0.0;
     // transpose on the host (counting sort), values default to 1
     std::vector<int64_t> rpT(n + 1, 0);
     std::vector<int32_t> ciT(std::max<int64_t>(nnz, 1));
@@ -812,6 +814,7 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
                                            "enough on this graph (the reference forms the dense inverse); lower beta", br);
     int terms = (br <= 0.0) ? 0 : (int)std::ceil(std::log(1e-8) / std::log(br));
     terms = std::max(1, std::min(terms, 400));
+    P.terms = terms; P.br = br;
 
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "hope: no HIP device");
@@ -820,7 +823,50 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
     if (H.err) return H.err;
 
-    return krylov_svd(H, n, k, oversample, krylov_steps, max_restarts, tol, seed, terms, br, 0, U_sqrtS, V_sqrtS, sigma, stats);
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_hope_plan_create(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta,
+                                       gemhip_hope_plan_t *out)
+{
+    GEMHIP_REQUIRE(out != nullptr, "hope_plan_create: out is NULL");
+    *out = nullptr;
+    auto *P = new gemhip_hope_plan();
+    const int rc = hope_setup(*P, n, nnz, row_ptr, col, w, beta);
+    if (rc) { delete P; return rc; }
+    *out = P;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_hope_plan_destroy(gemhip_hope_plan_t P)
+{
+    delete P;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_hope_plan_solve(gemhip_hope_plan_t P, int32_t k, int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol,
+                                      uint64_t seed, float *U_sqrtS, float *V_sqrtS, float *sigma, double *stats)
+{
+    GEMHIP_REQUIRE(P != nullptr, "hope_plan_solve: NULL plan");
+    GEMHIP_REQUIRE(k >= 1 && k < P->H.n, "hope: k=%d must satisfy 1 <= k < n=%lld (svds requirement)", k, (long long)P->H.n);
+    GEMHIP_REQUIRE(U_sqrtS && V_sqrtS && sigma, "hope: output pointers are NULL");
+    GEMHIP_REQUIRE(oversample >= 0 && krylov_steps >= 1 && max_restarts >= 0, "hope: need oversample >= 0, krylov_steps >= 1, max_restarts >= 0");
+    Hope &H = P->H;
+    H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr;
+    g_eig_seconds = 0.0; g_eig_calls = 0.0;
+    return krylov_svd(H, H.n, k, oversample, krylov_steps, max_restarts, tol, seed, P->terms, P->br, 0, U_sqrtS, V_sqrtS, sigma, stats);
+}
+
+extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
+                           int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS,
+                           float *V_sqrtS, float *sigma, double *stats)
+{
+    gemhip_hope_plan_t P = nullptr;
+    int rc = gemhip_hope_plan_create(n, nnz, row_ptr, col, w, beta, &P);
+    if (rc) return rc;
+    rc = gemhip_hope_plan_solve(P, k, oversample, krylov_steps, max_restarts, tol, seed, U_sqrtS, V_sqrtS, sigma, stats);
+    gemhip_hope_plan_destroy(P);
+    return rc;
 }
 
 // ------------------------------------------------------------------ Laplacian Eigenmaps

@@ -214,6 +214,14 @@ int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs,
  * host_eig_calls, max relative Ritz residual of the previous cycle,
  * seconds inside SpMM launches (HIP events)}.
  * Returns GEMHIP_E_NOTCONVERGED when beta*sigma_max(A) >= 0.95 (Katz series too slow). */
+/* Staged form: the graph-dependent setup (A and A^T in CSR on the device, Katz series length) is done once. */
+typedef struct gemhip_hope_plan *gemhip_hope_plan_t;
+int gemhip_hope_plan_create(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
+                            float beta, gemhip_hope_plan_t *out);
+int gemhip_hope_plan_solve(gemhip_hope_plan_t plan, int32_t k, int32_t oversample, int32_t krylov_steps,
+                           int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS, float *V_sqrtS,
+                           float *sigma, double *stats);
+int gemhip_hope_plan_destroy(gemhip_hope_plan_t plan);
 int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
                 float beta, int32_t k, int32_t oversample, int32_t krylov_steps,
                 int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS, float *V_sqrtS,
