@@ -83,6 +83,8 @@ _SIGS = {
     'gemhip_n2v_build_unigram_parts': (C.c_int, [C.c_void_p, C.c_int32, f32p, i32p]),
     'gemhip_sgns_emit_pairs': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p]),
+    'gemhip_sgns_emit_pairs_bucketed': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p,
+                                                  C.c_int64, i64p, C.c_void_p]),
     'gemhip_sgns_train_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
                                           C.c_float, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p]),
     'gemhip_n2v_set_max_waves': (C.c_int, [C.c_void_p, C.c_int32]),

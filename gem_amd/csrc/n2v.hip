@@ -656,6 +656,62 @@ __global__ __launch_bounds__(256) void sgns_emit_pairs_kernel(const int32_t *__r
     }
 }
 
+
+// Bucketed emission for the partitioned schedule: pairs are written grouped by key = (context % parts) * parts + (word % parts)
+// (counting sort: a count pass, an exclusive scan on the host, a fill pass).  Per workgroup an LDS histogram reserves one
+// contiguous range per bucket with ONE global atomic per bucket; lanes then claim slots with LDS atomics.  This replaces two
+// device-wide argsorts per episode in the driver.
+template <bool FILL>
+__global__ __launch_bounds__(256) void sgns_bucket_pairs_kernel(const int32_t *__restrict__ walks, int64_t walk_lo, int64_t walk_hi, int32_t walk_len,
+                                                                int32_t window, int32_t epoch, int64_t walk_id_offset, uint64_t seed, int32_t parts,
+                                                                unsigned long long *__restrict__ counts_or_cursor, int2 *__restrict__ out, int64_t cap)
+{
+    __shared__ int hist[4096];                 // parts <= 64
+    __shared__ unsigned long long base[4096];
+    const int nb = parts * parts;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ntok = (walk_hi - walk_lo) * walk_len;
+    int b = 0, pos = 0;
+    const int32_t *walk = nullptr;
+    int32_t word = -1;
+    if (t < ntok) {
+        const int64_t wl = walk_lo + t / walk_len;
+        pos = (int)(t % walk_len);
+        walk = walks + wl * walk_len;
+        word = walk[pos];
+        if (word >= 0) {
+            const int64_t wid = walk_id_offset + wl;
+            const u32x4 rw = philox4x32_10(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)epoch << 8));
+            b = (int)(rw.x % (uint32_t)window);
+        }
+    }
+    const int wkey = word >= 0 ? word % parts : 0;
+    if (word >= 0)
+        for (int a = b; a < 2 * window + 1 - b; ++a) {
+            const int cp = pos - window + a;
+            if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) atomicAdd(&hist[(walk[cp] % parts) * parts + wkey], 1);
+        }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        const int c = hist[k];
+        if (FILL) { base[k] = c ? atomicAdd(&counts_or_cursor[k], (unsigned long long)c) : 0ull; hist[k] = 0; }
+        else if (c) atomicAdd(&counts_or_cursor[k], (unsigned long long)c);
+    }
+    if (!FILL) return;
+    __syncthreads();
+    if (word >= 0)
+        for (int a = b; a < 2 * window + 1 - b; ++a) {
+            const int cp = pos - window + a;
+            if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) {
+                const int key = (walk[cp] % parts) * parts + wkey;
+                const int64_t at = (int64_t)base[key] + atomicAdd(&hist[key], 1);
+                if (at < cap) out[at] = make_int2(walk[cp], word);
+            }
+        }
+}
+
 struct PairArgs {
     const int2 *pairs; int64_t npairs; int32_t parts; int32_t neg_part; int64_t n_local_neg;
     const float *UTp; const int32_t *KTp; float alpha_begin, alpha_end; uint64_t seed; uint32_t stream_id; int32_t flags; int32_t d;
@@ -1081,6 +1137,48 @@ extern "C" int gemhip_sgns_emit_pairs(gemhip_n2v_t h, int32_t window, int32_t ep
                        h->walk_len, window, epoch, h->walk_id_offset, seed, (int2 *)d_pairs, cap, (unsigned long long *)d_count);
     GEMHIP_CHECK(hipGetLastError());
     return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_emit_pairs_bucketed(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi, uint64_t seed,
+                                               int32_t parts, void *d_pairs, int64_t cap, int64_t *counts_host, void *stream)
+{
+    GEMHIP_REQUIRE(h && d_pairs && counts_host && cap >= 0, "sgns_emit_pairs_bucketed: bad arguments");
+    GEMHIP_REQUIRE(parts >= 1 && parts <= 64, "sgns_emit_pairs_bucketed: parts=%d (1..64)", parts);
+    GEMHIP_REQUIRE(window >= 1 && window < 16384 && epoch >= 0 && epoch < 256, "sgns_emit_pairs_bucketed: window=%d epoch=%d", window, epoch);
+    GEMHIP_REQUIRE(0 <= walk_lo && walk_lo <= walk_hi && walk_hi <= h->nwalks, "sgns_emit_pairs_bucketed: bad local walk range");
+    const int nb = parts * parts;
+    for (int k = 0; k < nb; ++k) counts_host[k] = 0;
+    const int64_t ntok = (walk_hi - walk_lo) * h->walk_len;
+    if (ntok == 0) return GEMHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *d_cnt = nullptr;
+    GEMHIP_CHECK(hipMalloc((void **)&d_cnt, nb * sizeof(unsigned long long)));
+    int rc = GEMHIP_OK;
+    const dim3 grid((unsigned)((ntok + 255) / 256)), blk(256);
+    std::vector<unsigned long long> cnt(nb), cur(nb);
+    hipError_t e = hipMemsetAsync(d_cnt, 0, nb * sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((sgns_bucket_pairs_kernel<false>), grid, blk, 0, s, h->d_walks, walk_lo, walk_hi, h->walk_len, window, epoch, h->walk_id_offset,
+                           seed, parts, d_cnt, (int2 *)nullptr, (int64_t)0);
+        e = hipMemcpyAsync(cnt.data(), d_cnt, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {
+        unsigned long long acc = 0;
+        for (int k = 0; k < nb; ++k) { cur[k] = acc; acc += cnt[k]; counts_host[k] = (int64_t)cnt[k]; }
+        if ((int64_t)acc > cap) rc = fail(GEMHIP_E_INVALID, "sgns_emit_pairs_bucketed: %llu pairs exceed the buffer capacity %lld", acc, (long long)cap);
+        else {
+            e = hipMemcpyAsync(d_cnt, cur.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL((sgns_bucket_pairs_kernel<true>), grid, blk, 0, s, h->d_walks, walk_lo, walk_hi, h->walk_len, window, epoch,
+                                   h->walk_id_offset, seed, parts, d_cnt, (int2 *)d_pairs, cap);
+                e = hipStreamSynchronize(s);          // `cur` is a host buffer; d_cnt is freed below
+            }
+        }
+    }
+    hipFree(d_cnt);
+    if (e != hipSuccess) return fail(GEMHIP_E_HIP, "sgns_emit_pairs_bucketed: %s", hipGetErrorString(e));
+    return rc;
 }
 
 extern "C" int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs, int32_t neg_part, void *dSynPos_part,

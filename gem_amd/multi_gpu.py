@@ -53,19 +53,27 @@ class TorchComm(object):
         else:
             full.copy_(own)
 
-    def all_to_all_rows(self, send, send_counts):
+    def all_gather_ints(self, values, device):
+        """Every rank's list of ints -> [world][len(values)] nested list (tiny control message)."""
+        if self.world == 1:
+            return [list(values)]
+        import torch
+        v = torch.as_tensor(list(values), dtype=torch.int64, device=device)
+        out = torch.empty(self.world * v.numel(), dtype=torch.int64, device=device)
+        self.dist.all_gather_into_tensor(out, v)
+        return out.view(self.world, v.numel()).cpu().tolist()
+
+    def all_to_all_rows(self, send, send_counts, recv_counts=None):
         """send: [m, c] rows grouped by destination rank (send_counts[r] rows for rank r, in rank order).
         Returns the rows addressed to this rank, grouped by source rank."""
         if self.world == 1:
             return send
         import torch
         dist = self.dist
-        sc = torch.as_tensor(send_counts, dtype=torch.int64, device=send.device)
-        allc = torch.empty(self.world * self.world, dtype=torch.int64, device=send.device)
-        dist.all_gather_into_tensor(allc, sc)
-        allc = allc.view(self.world, self.world).cpu()
         rank = dist.get_rank()
-        recv_counts = allc[:, rank].tolist()
+        if recv_counts is None:
+            recv_counts = [row[rank] for row in self.all_gather_ints(send_counts, send.device)]
+        recv_counts = [int(x) for x in recv_counts]
         send_counts = [int(x) for x in send_counts]
         out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         if dist.get_backend() == 'nccl':
@@ -217,20 +225,23 @@ class Node2VecPartitioned(object):
         for ep in range(self.epochs):
             for e in range(self.episodes):
                 a, z = shard_range(nloc, e, self.episodes)
-                pairs = b.emit_pairs(self.window, ep, a, z, self.seed)       # [np, 2] int32: (context, word)
-                dest = pairs[:, 0] % W
-                order = torch.argsort(dest, stable=True)
-                send = pairs[order]
-                send_counts = torch.bincount(dest, minlength=W).tolist()
-                mine = comm.all_to_all_rows(send, send_counts)               # every pair whose context row I own
-                wpart = mine[:, 1] % W
-                order = torch.argsort(wpart, stable=True)
-                mine = mine[order].contiguous()
-                off = [0] + torch.cumsum(torch.bincount(wpart, minlength=W), 0).tolist()
+                # (context, word) pairs of this slice of my walks, already grouped by (context % W, word % W) on the device
+                pairs, counts = b.emit_pairs_bucketed(self.window, ep, a, z, self.seed, W)
+                cm = comm.all_gather_ints(counts, pairs.device)              # cm[src][dest * W + wpart]
+                send_counts = [sum(counts[r * W:(r + 1) * W]) for r in range(W)]
+                recv_counts = [sum(cm[src][g * W:(g + 1) * W]) for src in range(W)]
+                mine = comm.all_to_all_rows(pairs, send_counts, recv_counts)  # grouped by source rank, then by word % W
+                seg, at = [[None] * W for _ in range(W)], 0
+                for src in range(W):
+                    for j in range(W):
+                        ln = cm[src][g * W + j]
+                        seg[src][j] = (at, at + ln)
+                        at += ln
                 step = ep * self.episodes + e
                 for s in range(W):
                     j = (g + s) % W                                          # SynNeg partition visiting me this round
-                    bucket = mine[off[j]:off[j + 1]]
+                    parts_j = [mine[x:y] for x, y in (seg[src][j] for src in range(W)) if y > x]
+                    bucket = parts_j[0] if len(parts_j) == 1 else (torch.cat(parts_j) if parts_j else mine[:0])
                     f0, f1 = (step + s / W) / total_steps, (step + (s + 1) / W) / total_steps
                     b.train_pairs(bucket, j, P_part, N_cur, self._alpha(f0), self._alpha(f1), self.seed,
                                   (step * W + g) * W + j, self.flags)
@@ -306,9 +317,23 @@ class HipBackendN2V(object):
                                                  C.c_void_p(cnt.data_ptr()), self._stream()))
         return buf[:int(cnt.item())]
 
+    def emit_pairs_bucketed(self, window, epoch, lo, hi, seed, parts):
+        """Pairs grouped by key (context % parts) * parts + (word % parts); returns (int32 [np, 2] tensor, counts list)."""
+        torch = self.torch
+        nw = C.c_int64(); wl = C.c_int32(); p = C.c_void_p()
+        _hip.check(self.L.gemhip_n2v_walks_ptr(self.h, C.byref(p), C.byref(nw), C.byref(wl)))
+        cap = max((hi - lo) * wl.value * 2 * window, 1)
+        buf = torch.empty((cap, 2), dtype=torch.int32, device=self.P.device)
+        counts = (C.c_int64 * (parts * parts))()
+        _hip.check(self.L.gemhip_sgns_emit_pairs_bucketed(self.h, window, epoch, lo, hi, seed, parts, C.c_void_p(buf.data_ptr()), cap, counts,
+                                                          self._stream()))
+        counts = list(counts)
+        return buf[:sum(counts)], counts
+
     def train_pairs(self, bucket, neg_part, P_part, N_part, a0, a1, seed, stream_id, flags):
         if bucket.shape[0] == 0:
             return
+        bucket = bucket.contiguous()
         _hip.check(self.L.gemhip_sgns_train_pairs(self.h, C.c_void_p(bucket.data_ptr()), bucket.shape[0], neg_part,
                                                   C.c_void_p(P_part.data_ptr()), C.c_void_p(N_part.data_ptr()), self.d, a0, a1, seed,
                                                   stream_id & 0xffffffff, flags, self._stream()))

@@ -195,6 +195,11 @@ int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0,
 int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, float *UT_out, int32_t *KT_out);
 int gemhip_sgns_emit_pairs(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi,
                            uint64_t seed, void *d_pairs, int64_t cap, void *d_count, void *stream);
+/* Same pairs, written GROUPED by key = (context % parts) * parts + (word % parts) (counting sort on the device);
+ * counts_host[parts*parts] receives the bucket sizes (bucket k starts at the sum of the sizes before it). */
+int gemhip_sgns_emit_pairs_bucketed(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi,
+                                    uint64_t seed, int32_t parts, void *d_pairs, int64_t cap, int64_t *counts_host,
+                                    void *stream);
 int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs, int32_t neg_part,
                             void *dSynPos_part, void *dSynNeg_part, int32_t d, float alpha_begin,
                             float alpha_end, uint64_t seed, uint32_t stream_id, int32_t flags, void *stream);

@@ -150,6 +150,12 @@ class OraclePart(OracleN2V):
     def emit_pairs(self, window, epoch, lo, hi, seed):
         return torch.from_numpy(oracle.sgns_pairs(self.w[lo:hi], window, epoch, self.lo + lo, seed))
 
+    def emit_pairs_bucketed(self, window, epoch, lo, hi, seed, parts):
+        pr = oracle.sgns_pairs(self.w[lo:hi], window, epoch, self.lo + lo, seed)
+        key = (pr[:, 0] % parts) * parts + (pr[:, 1] % parts)
+        order = np.argsort(key, kind='stable')
+        return torch.from_numpy(np.ascontiguousarray(pr[order])), np.bincount(key, minlength=parts * parts).tolist()
+
     def train_pairs(self, bucket, neg_part, P_part, N_part, a0, a1, seed, stream_id, flags):
         if bucket.shape[0] == 0:
             return

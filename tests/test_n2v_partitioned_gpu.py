@@ -33,6 +33,17 @@ def test_emit_pairs_is_the_trainmodel_pair_multiset(sbm1024):
         assert got.shape == want.shape
         key = lambda a: np.sort(a[:, 0].astype(np.int64) * n + a[:, 1])
         assert np.array_equal(key(got), key(want))
+    # bucketed emission: same multiset, grouped by (context % parts, word % parts) with the reported bucket sizes
+    for parts in (1, 3, 8):
+        got, counts = b.emit_pairs_bucketed(10, 0, 0, 1400, 7, parts)
+        got = got.cpu().numpy()
+        want = oracle.sgns_pairs(walks, 10, 0, 100, 7)
+        assert sum(counts) == len(want) == len(got)
+        keyw = (want[:, 0] % parts) * parts + (want[:, 1] % parts)
+        assert counts == np.bincount(keyw, minlength=parts * parts).tolist()
+        keyg = (got[:, 0] % parts) * parts + (got[:, 1] % parts)
+        assert np.all(np.diff(keyg) >= 0)                                  # grouped in key order
+        assert np.array_equal(key(got), key(want))
     b.close()
 
 
