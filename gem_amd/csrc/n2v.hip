@@ -733,6 +733,10 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
     // the same walk, so interleaving them over wavefronts would make concurrent waves fight over the same rows
     const int64_t chunk = (A.npairs + A.nwaves - 1) / A.nwaves;
     const int64_t i_end = (gw + 1) * chunk < A.npairs ? (gw + 1) * chunk : A.npairs;
+    // pairs arrive in walk order, so consecutive pairs usually share their centre word: its SynNeg row (the positive
+    // target) stays in registers until the word changes, like in the walk-based kernel
+    float yp[NV][VEC];
+    int32_t held = -1;                                    // local row index currently in yp
     for (int64_t i = gw * chunk; i < i_end; ++i) {
         const int2 pr = A.pairs[i];
         const int32_t ctx = __builtin_amdgcn_readfirstlane(pr.x), word = __builtin_amdgcn_readfirstlane(pr.y);
@@ -750,10 +754,21 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
 #pragma unroll
         for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readlane(mine, j + 1);
 
-        float xc[NV][VEC], neu[NV][VEC], yp[NV][VEC], yn[SGNS_NEG][NV][VEC];
-        float *pc = A.SynPos + (int64_t)ctx_l * d, *pp = A.SynNeg + (int64_t)word_l * d;
+        float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
+        float *pc = A.SynPos + (int64_t)ctx_l * d;
+        if (word_l != held) {
+            if (held >= 0) {
+                float *po = A.SynNeg + (int64_t)held * d;
 #pragma unroll
-        for (int c = 0; c < NV; ++c) { ld_row<VEC>(pc, d, lane, c, xc[c]); ld_row<VEC>(pp, d, lane, c, yp[c]); }
+                for (int c = 0; c < NV; ++c) st_row<VEC>(po, d, lane, c, yp[c]);
+            }
+            const float *pp = A.SynNeg + (int64_t)word_l * d;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
+            held = word_l;
+        }
+#pragma unroll
+        for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
 #pragma unroll
         for (int j = 0; j < SGNS_NEG; ++j) {
             const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
@@ -775,8 +790,6 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
             for (int c = 0; c < NV; ++c)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yp[c][v]; yp[c][v] += g * xc[c][v]; }
-#pragma unroll
-            for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
         }
 #pragma unroll
         for (int j = 0; j < SGNS_NEG; ++j) {
@@ -810,6 +823,11 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
             st_row<VEC>(pc, d, lane, c, xc[c]);
         }
         ++done;
+    }
+    if (held >= 0) {
+        float *po = A.SynNeg + (int64_t)held * d;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) st_row<VEC>(po, d, lane, c, yp[c]);
     }
     if (lane == 0 && A.pairs_done) atomicAdd(A.pairs_done, done);
 }
