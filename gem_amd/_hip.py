@@ -71,6 +71,7 @@ _SIGS = {
     'gemhip_n2v_get_alias': (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
     'gemhip_n2v_walks': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int64,
                                    C.c_int64, C.c_void_p]),
+    'gemhip_n2v_start_nodes': (C.c_int, [C.c_void_p, i64p]),
     'gemhip_n2v_set_walks': (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int32, C.c_int64]),
     'gemhip_n2v_get_walks': (C.c_int, [C.c_void_p, i32p]),
     'gemhip_n2v_walks_ptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p, i32p]),

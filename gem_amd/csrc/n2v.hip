@@ -60,6 +60,10 @@ struct gemhip_n2v {
     bool uniform_rows = true;         // every row has equal weights -> no alias tables needed
     int64_t *d_row_ptr = nullptr;
     int32_t *d_col = nullptr;         // columns sorted inside each row
+    // walk start nodes: the nodes that occur in the edge list (the reference binary only knows those; an isolated node
+    // never reaches it).  start[0..m_start) ascending; walk id r*m_start + j starts at start[perm_r(j)]
+    int64_t m_start = 0;
+    int32_t *d_start = nullptr;
     float *d_w = nullptr;
     float *d_U = nullptr;             // first-order alias tables (per-row segments)
     int32_t *d_K = nullptr;
@@ -138,7 +142,7 @@ __device__ __forceinline__ bool has_edge_sorted(const int64_t *__restrict__ row_
 // SimulateWalk (ELF @0x411a00).  One lane per walk; tokens are buffered 16 at a time in
 // registers so each lane writes 64 contiguous bytes (dwordx4 stores) instead of 4-byte scatters.
 template <bool SECOND, bool WEIGHTED>
-__global__ __launch_bounds__(256) void n2v_walk_kernel(int64_t n, uint32_t hb, const int64_t *__restrict__ row_ptr,
+__global__ __launch_bounds__(256) void n2v_walk_kernel(int64_t n, int64_t m, const int32_t *__restrict__ start, uint32_t hb, const int64_t *__restrict__ row_ptr,
                                                        const int32_t *__restrict__ col, const float *__restrict__ U,
                                                        const int32_t *__restrict__ K, float ip, float iq, float amax,
                                                        int32_t walk_len, uint64_t seed, int32_t flags, int64_t walk_begin,
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256) void n2v_walk_kernel(int64_t n, uint32_t hb, c
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= count) return;
     const int64_t wid = walk_begin + tid;
-    const uint32_t round = (uint32_t)(wid / n), j = (uint32_t)(wid % n);
-    int32_t cur = (int32_t)perm_node(j, (uint32_t)n, hb, seed ^ ((uint64_t)(round + 1) * 0x9E3779B97F4A7C15ull));
+    const uint32_t round = (uint32_t)(wid / m), j = (uint32_t)(wid % m);
+    int32_t cur = start[perm_node(j, (uint32_t)m, hb, seed ^ ((uint64_t)(round + 1) * 0x9E3779B97F4A7C15ull))];
     int32_t prev = -1;
     const int32_t pad = (flags & 1) ? 0 : -1;
     const bool uniform_first = (flags & 8) != 0;
@@ -896,8 +900,16 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
             for (int64_t e = a; e < b; ++e) { c[e] = tmp[e - a].first; if (w) ww[e] = tmp[e - a].second; }
         }
     }
+    std::vector<int32_t> start;
+    {
+        std::vector<char> present(n, 0);
+        for (int64_t v = 0; v < n; ++v)
+            if (row_ptr[v + 1] > row_ptr[v]) present[v] = 1;
+        for (int64_t e = 0; e < nnz; ++e) present[c[e]] = 1;
+        for (int64_t v = 0; v < n; ++v) if (present[v]) start.push_back((int32_t)v);
+    }
     auto *h = new gemhip_n2v();
-    h->n = n; h->nnz = nnz; h->uniform_rows = uniform;
+    h->n = n; h->nnz = nnz; h->uniform_rows = uniform; h->m_start = (int64_t)start.size();
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
     hipError_t e = hipMalloc((void **)&h->d_row_ptr, (n + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMemcpy(h->d_row_ptr, row_ptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
@@ -907,6 +919,8 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
         e = hipMalloc((void **)&h->d_w, nnz * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(h->d_w, ww.data(), nnz * sizeof(float), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_start, std::max<size_t>(start.size(), 4) * sizeof(int32_t));
+    if (e == hipSuccess && !start.empty()) e = hipMemcpy(h->d_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_counts, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_pairs, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->d_pairs, 0, sizeof(unsigned long long));
@@ -918,6 +932,7 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
 extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
 {
     if (!h) return GEMHIP_OK;
+    hipFree(h->d_start);
     hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks);
     if (h->own_counts) hipFree(h->d_counts);
     hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp);
@@ -971,7 +986,7 @@ extern "C" int gemhip_n2v_walks(gemhip_n2v_t h, float p, float q, int32_t num_wa
     GEMHIP_REQUIRE(h, "n2v_walks: NULL handle");
     GEMHIP_REQUIRE(p > 0.f && q > 0.f, "n2v_walks: p=%g q=%g must be > 0", (double)p, (double)q);
     GEMHIP_REQUIRE(num_walks >= 1 && walk_len >= 1 && walk_len < 65536, "n2v_walks: num_walks=%d walk_len=%d", num_walks, walk_len);
-    const int64_t total = h->n * (int64_t)num_walks;
+    const int64_t total = h->m_start * (int64_t)num_walks;
     GEMHIP_REQUIRE(0 <= walk_begin && walk_begin <= walk_end && walk_end <= total, "n2v_walks: bad walk range [%lld,%lld) of %lld",
                    (long long)walk_begin, (long long)walk_end, (long long)total);
     if (!h->uniform_rows && !h->d_U) { if (int rc = gemhip_n2v_build_alias(h, stream)) return rc; }
@@ -985,13 +1000,20 @@ extern "C" int gemhip_n2v_walks(gemhip_n2v_t h, float p, float q, int32_t num_wa
     const float amax = std::max(1.0f, std::max(ip, iq));
     const dim3 grid((unsigned)((count + 255) / 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    const uint32_t hb = half_bits((uint64_t)h->n);
-#define N2V_WALK(S, W) hipLaunchKernelGGL((n2v_walk_kernel<S, W>), grid, block, 0, s, h->n, hb, h->d_row_ptr, h->d_col, h->d_U, h->d_K, ip, \
+    const uint32_t hb = half_bits((uint64_t)h->m_start);
+#define N2V_WALK(S, W) hipLaunchKernelGGL((n2v_walk_kernel<S, W>), grid, block, 0, s, h->n, h->m_start, h->d_start, hb, h->d_row_ptr, h->d_col, h->d_U, h->d_K, ip, \
                                           iq, amax, walk_len, seed, flags, walk_begin, count, h->d_walks)
     if (second) { if (h->uniform_rows) N2V_WALK(true, false); else N2V_WALK(true, true); }
     else        { if (h->uniform_rows) N2V_WALK(false, false); else N2V_WALK(false, true); }
 #undef N2V_WALK
     GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_start_nodes(gemhip_n2v_t h, int64_t *m)
+{
+    GEMHIP_REQUIRE(h && m, "n2v_start_nodes: NULL argument");
+    *m = h->m_start;
     return GEMHIP_OK;
 }
 
@@ -1329,7 +1351,7 @@ extern "C" int gemhip_n2v_train(int64_t n, int64_t nnz, const int64_t *row_ptr, 
     if (rc) return rc;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     for (auto &e : ev) if (!rc && hipEventCreate(&e) != hipSuccess) rc = fail(GEMHIP_E_HIP, "n2v_train: hipEventCreate");
-    const int64_t nwalks = n * (int64_t)num_walks;
+    const int64_t nwalks = h->m_start * (int64_t)num_walks;
     if (!rc) { hipEventRecord(ev[0], 0); rc = gemhip_n2v_walks(h, p, q, num_walks, walk_len, seed, flags, 0, nwalks, nullptr); }
     if (!rc) rc = gemhip_n2v_vocab(h, nullptr);
     if (!rc) { hipEventRecord(ev[1], 0); rc = gemhip_n2v_build_unigram(h, nullptr, nullptr, nullptr); }

@@ -161,7 +161,7 @@ class Node2VecSharded(object):
         self.n, self.num_walks, self.walk_len, self.window, self.epochs = n, num_walks, walk_len, window, epochs
         self.seed, self.flags = seed, flags
         self.sync_chunks = max(1, sync_chunks) if world > 1 else 1
-        self.lo, self.hi = shard_range(n * num_walks, rank, world)
+        self.lo, self.hi = shard_range(backend.num_start_nodes() * num_walks, rank, world)
 
     def run(self, p=1.0, q=1.0):
         b = self.b
@@ -205,7 +205,7 @@ class Node2VecPartitioned(object):
         self.b, self.comm, self.rank, self.world = backend, comm, rank, world
         self.n, self.num_walks, self.walk_len, self.window, self.epochs = n, num_walks, walk_len, window, epochs
         self.seed, self.flags, self.episodes, self.alpha0 = seed, flags, max(1, episodes), alpha0
-        self.lo, self.hi = shard_range(n * num_walks, rank, world)
+        self.lo, self.hi = shard_range(backend.num_start_nodes() * num_walks, rank, world)
         self.pairs_trained = 0
 
     def _alpha(self, f):
@@ -264,6 +264,11 @@ class HipBackendN2V(object):
         _hip.check(self.L.gemhip_n2v_bind_counts(self.h, C.c_void_p(self.counts.data_ptr())))
         self.P = torch.empty((n, d), dtype=torch.float32, device=dev)
         self.N = torch.empty((n, d), dtype=torch.float32, device=dev)
+
+    def num_start_nodes(self):
+        m = C.c_int64()
+        _hip.check(self.L.gemhip_n2v_start_nodes(self.h, C.byref(m)))
+        return m.value
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)

@@ -150,8 +150,10 @@ int gemhip_n2v_build_alias(gemhip_n2v_t h, void *stream);
 /* Fetch tables/sorted columns for tests.  Returns 1 (not an error) when rows are uniform
  * and no tables exist. */
 int gemhip_n2v_get_alias(gemhip_n2v_t h, float *U_host, int32_t *K_host, int32_t *col_sorted_host);
-/* SimulateWalk for global walk ids [walk_begin, walk_end) of n*num_walks (walk id
- * r*n + j starts at the j-th node of round r's permutation): this rank's shard. */
+/* Walks start from the m nodes that occur in the edge list (the binary never sees an isolated node):
+ * gemhip_n2v_start_nodes returns m.  SimulateWalk for global walk ids [walk_begin, walk_end) of m*num_walks
+ * (walk id r*m + j starts at the j-th node of round r's permutation of those m nodes): this rank's shard. */
+int gemhip_n2v_start_nodes(gemhip_n2v_t h, int64_t *m);
 int gemhip_n2v_walks(gemhip_n2v_t h, float p, float q, int32_t num_walks, int32_t walk_len,
                      uint64_t seed, int32_t flags, int64_t walk_begin, int64_t walk_end,
                      void *stream);

@@ -49,7 +49,7 @@ def lib():
         L.oracle_alias_build_f32.argtypes = [C.c_int32, f32p, f32p, i32p, i32p]
         L.oracle_n2v_alias_rows.argtypes = [C.c_int64, i64p, f32p, f32p, i32p]
         L.oracle_n2v_walks.argtypes = [C.c_int64, i64p, i32p, f32p, i32p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_uint64,
-                                       C.c_int32, C.c_int64, C.c_int64, i32p]
+                                       C.c_int32, C.c_int64, C.c_int64, i32p, C.c_int64, i32p]
         L.oracle_n2v_vocab.argtypes = [C.c_int64, C.c_int64, i32p, i32p]
         L.oracle_unigram_build.argtypes = [C.c_int64, i32p, f64p, i32p]
         L.oracle_sgns_train.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_float,
@@ -125,13 +125,22 @@ def n2v_alias_rows(row_ptr, w):
     return U, K
 
 
+def start_nodes(row_ptr, col):
+    """Nodes that occur in the edge list (as source or target), ascending: the only nodes the reference binary knows."""
+    n = len(row_ptr) - 1
+    present = np.diff(row_ptr) > 0
+    present[np.asarray(col)] = True
+    return np.flatnonzero(present).astype(np.int32)
+
+
 def n2v_walks(row_ptr, col, U, K, p, q, num_walks, walk_len, seed, flags, walk_begin=0, walk_end=None):
     n = len(row_ptr) - 1
+    start = start_nodes(row_ptr, col)
     if walk_end is None:
-        walk_end = n * num_walks
+        walk_end = len(start) * num_walks
     out = np.empty((walk_end - walk_begin, walk_len), dtype=np.int32)
     lib().oracle_n2v_walks(n, _p(row_ptr, C.c_int64), _p(col, C.c_int32), _p(U, C.c_float), _p(K, C.c_int32), p, q, num_walks,
-                           walk_len, seed, flags, walk_begin, walk_end, _p(out, C.c_int32))
+                           walk_len, seed, flags, walk_begin, walk_end, _p(start, C.c_int32), len(start), _p(out, C.c_int32))
     return out
 
 

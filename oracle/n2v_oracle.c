@@ -150,9 +150,12 @@ static int has_edge_sorted(const int64_t *row_ptr, const int32_t *col, int32_t t
 
 void oracle_n2v_walks(int64_t n, const int64_t *row_ptr, const int32_t *col, const float *U, const int32_t *K,
                       float p, float q, int32_t num_walks, int32_t walk_len, uint64_t seed, int32_t flags,
-                      int64_t walk_begin, int64_t walk_end, int32_t *walks /* [(walk_end-walk_begin)][walk_len] */)
+                      int64_t walk_begin, int64_t walk_end, const int32_t *start, int64_t m,
+                      int32_t *walks /* [(walk_end-walk_begin)][walk_len] */)
 {
-    (void)num_walks;
+    /* start[0..m): the nodes that occur in the edge list, ascending -- the binary builds its graph from the edge
+     * list, so an isolated node never starts a walk (node2vec(): `for NI = InNet->BegNI()...`). */
+    (void)num_walks; (void)n;
     const int32_t pad = (flags & 1) ? 0 : -1;
     const int second = !(p == 1.0f && q == 1.0f);
     const float ip = 1.0f / p, iq = 1.0f / q;
@@ -161,8 +164,8 @@ void oracle_n2v_walks(int64_t n, const int64_t *row_ptr, const int32_t *col, con
     if (iq > amax) amax = iq;
     for (int64_t wid = walk_begin; wid < walk_end; ++wid) {
         int32_t *out = walks + (wid - walk_begin) * walk_len;
-        const uint32_t round = (uint32_t)(wid / n), j = (uint32_t)(wid % n);
-        int32_t cur = (int32_t)oracle_perm(j, (uint32_t)n, seed ^ ((uint64_t)(round + 1) * 0x9E3779B97F4A7C15ull));
+        const uint32_t round = (uint32_t)(wid / m), j = (uint32_t)(wid % m);
+        int32_t cur = start[oracle_perm(j, (uint32_t)m, seed ^ ((uint64_t)(round + 1) * 0x9E3779B97F4A7C15ull))];
         int32_t prev = -1;
         int32_t len = 0;
         out[len++] = cur;

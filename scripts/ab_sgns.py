@@ -10,12 +10,12 @@ g = sbm_graph(1000000, 10000000, 100, seed=20260927)
 n, src, dst, w, _ = edge_arrays(g)
 row_ptr, col, ww = to_csr(n, src, dst, w)
 b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, 128)
-b.walks(1.0, 1.0, r, 80, 1, 11, 0, n * r); b.vocab(); b.build_unigram()
+m = b.num_start_nodes(); b.walks(1.0, 1.0, r, 80, 1, 11, 0, m * r); b.vocab(); b.build_unigram()
 for rep in range(2):
     for flags in variants:
         b.init_tables(1); b.pairs(reset=True)
         torch.cuda.synchronize(); t = time.time()
-        b.train(10, 1, 0, 0, n * r, n * r * 80, 0, 1, flags)
+        b.train(10, 1, 0, 0, m * r, m * r * 80, 0, 1, flags)
         torch.cuda.synchronize(); el = time.time() - t
         pairs = b.pairs()
         print('flags', flags, 'sgns %.3f s' % el, 'algorithmic TB/s %.3f' % (pairs * 7192 / el / 1e12), 'absmax', float(b.P.abs().max()), flush=True)

@@ -14,7 +14,7 @@ for weighted in (False, True):
     for p, q in ((1.0, 1.0), (0.25, 4.0), (4.0, 0.25)):
         for rep in range(2):
             torch.cuda.synchronize(); t = time.time()
-            b.walks(p, q, 10, 80, 1, 11, 0, n * 10)
+            b.walks(p, q, 10, 80, 1, 11, 0, b.num_start_nodes() * 10)
             torch.cuda.synchronize(); el = time.time() - t
         print('weighted', weighted, 'alias build %.1f ms' % (ta * 1e3), 'p', p, 'q', q, 'walks %.1f ms' % (el * 1e3), '%.1f G steps/s' % (n * 10 * 79 / el / 1e9), flush=True)
     b.close()

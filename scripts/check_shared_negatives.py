@@ -15,10 +15,10 @@ for flags in (11, 11 | 64):
 g = sbm_graph(1000000, 10000000, 100, seed=20260927)
 n, src, dst, w, _ = edge_arrays(g); row_ptr, col, ww = to_csr(n, src, dst, w)
 b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, 128)
-b.walks(1.0, 1.0, 10, 80, 1, 11, 0, n * 10); b.vocab(); b.build_unigram()
+m = b.num_start_nodes(); b.walks(1.0, 1.0, 10, 80, 1, 11, 0, m * 10); b.vocab(); b.build_unigram()
 rng = np.random.RandomState(0); nodes = rng.choice(n, 256, replace=False)
 for flags in (11 | 64, 11):
     b.init_tables(1); torch.cuda.synchronize(); t = time.time()
-    b.train(10, 1, 0, 0, n * 10, n * 800, 0, 1, flags); torch.cuda.synchronize(); el = time.time() - t
+    b.train(10, 1, 0, 0, m * 10, m * 800, 0, 1, flags); torch.cuda.synchronize(); el = time.time() - t
     ap = gr.sampled_ap_gpu(g, None, b.P.cpu().numpy(), nodes)
     print('1M flags', flags, 'sgns %.2f s' % el, 'sampled MAP %.4f' % ap.mean(), flush=True)

@@ -46,6 +46,9 @@ class OracleN2V(object):
         self.n, self.d = n, d
         self.row_ptr, self.col, _ = oracle.sorted_csr(n, src, dst, None)
 
+    def num_start_nodes(self):
+        return len(oracle.start_nodes(self.row_ptr, self.col))
+
     def walks(self, p, q, num_walks, walk_len, seed, flags, lo, hi):
         self.w = oracle.n2v_walks(self.row_ptr, self.col, None, None, p, q, num_walks, walk_len, seed, flags, lo, hi)
         self.lo = lo

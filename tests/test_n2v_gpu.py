@@ -32,7 +32,8 @@ class Dev(object):
         _hip.check(self.L.gemhip_n2v_destroy(self.h))
 
     def walks(self, p, q, r, l, seed, flags, lo=0, hi=None):
-        hi = self.n * r if hi is None else hi
+        m = C.c_int64(); _hip.check(self.L.gemhip_n2v_start_nodes(self.h, C.byref(m)))
+        hi = m.value * r if hi is None else hi
         _hip.check(self.L.gemhip_n2v_walks(self.h, p, q, r, l, seed, flags, lo, hi, None))
         out = np.empty((hi - lo, l), np.int32)
         _hip.check(self.L.gemhip_n2v_get_walks(self.h, _hip.ptr(out, C.c_int32)))
@@ -81,6 +82,24 @@ def test_walks_and_tables_bit_exact(p, q, weighted):
     assert np.array_equal(c, oracle.n2v_vocab(n, got))
     UTo, KTo = oracle.unigram_build(c)
     assert np.array_equal(KT, KTo) and np.array_equal(UT, UTo)
+    dev.close()
+
+
+def test_isolated_nodes_never_start_a_walk():
+    """The reference binary builds its graph from the edge list: a node without any edge does not exist for it."""
+    n = 40
+    src = np.array([0, 1, 2, 5, 5, 9, 30], np.int32); dst = np.array([1, 2, 0, 9, 2, 5, 31], np.int32)      # 31 is a sink, most ids isolated
+    dev = Dev(n, src, dst, None)
+    row_ptr, col, _ = oracle.sorted_csr(n, src, dst, None)
+    starts = oracle.start_nodes(row_ptr, col)
+    assert list(starts) == [0, 1, 2, 5, 9, 30, 31]
+    for flags in (SNAP, 8):
+        got = dev.walks(1.0, 1.0, 4, 10, 3, flags)
+        assert got.shape == (28, 10)
+        assert np.array_equal(got, oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, 4, 10, 3, flags))
+        assert set(got[:, 0].tolist()) == set(starts.tolist())
+    c, UT, KT = dev.unigram()
+    assert c[[3, 4, 6, 7, 8, 10]].sum() == 0
     dev.close()
 
 
@@ -169,8 +188,11 @@ def test_baseline_scale_properties():
     n, src, dst, w, _ = edge_arrays(g)
     dev = Dev(n, src, dst, w)
     walks = dev.walks(1.0, 1.0, 2, 80, 7, SNAP)
-    assert walks.shape == (2 * n, 80) and walks.min() >= 0 and walks.max() < n
-    assert np.array_equal(np.sort(walks[:n, 0]), np.arange(n)) and np.array_equal(np.sort(walks[n:, 0]), np.arange(n))
+    starts = oracle.start_nodes(*oracle.sorted_csr(n, src, dst, None)[:2])          # nodes that occur in the edge list
+    m = len(starts)
+    assert n - 50 < m <= n
+    assert walks.shape == (2 * m, 80) and walks.min() >= 0 and walks.max() < n
+    assert np.array_equal(np.sort(walks[:m, 0]), starts) and np.array_equal(np.sort(walks[m:, 0]), starts)
     key = set((src.astype(np.int64) * n + dst).tolist())
     sel = walks[::997]
     pairs = sel[:, :-1].astype(np.int64) * n + sel[:, 1:]
