@@ -741,22 +741,28 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
     // target) stays in registers until the word changes, like in the walk-based kernel
     float yp[NV][VEC];
     int32_t held = -1;                                    // local row index currently in yp
-    for (int64_t i = gw * chunk; i < i_end; ++i) {
-        const int2 pr = A.pairs[i];
-        const int32_t ctx = __builtin_amdgcn_readfirstlane(pr.x), word = __builtin_amdgcn_readfirstlane(pr.y);
-        const int32_t ctx_l = ctx / A.parts, word_l = word / A.parts;
-        const float alpha = A.alpha_begin + (A.alpha_end - A.alpha_begin) * (float)((double)i / (double)(A.npairs > 1 ? A.npairs : 1));
-        int32_t mine = -1;
+    // lanes 1..5 draw the five negative targets of pair i from the visiting partition's alias table
+    auto draw = [&](int64_t i) -> int32_t {
+        int32_t m = -1;
         if (lane >= 1 && lane <= SGNS_NEG) {
             const u32x4 rn = philox4x32_10(A.seed, (uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.stream_id,
                                            (uint32_t)TAG_NEG | ((uint32_t)lane << 16) | 0x80000000u);
             const uint32_t slot = mulhi_range(rn.x, (uint32_t)A.n_local_neg);
             const int32_t X = quirk ? A.KTp[slot] : (int32_t)slot;
-            mine = (u01(rn.y) < A.UTp[X]) ? X : A.KTp[X];
+            m = (u01(rn.y) < A.UTp[X]) ? X : A.KTp[X];
         }
+        return m;
+    };
+    int32_t mine = gw * chunk < i_end ? draw(gw * chunk) : -1;
+    for (int64_t i = gw * chunk; i < i_end; ++i) {
+        const int2 pr = A.pairs[i];
+        const int32_t ctx = __builtin_amdgcn_readfirstlane(pr.x), word = __builtin_amdgcn_readfirstlane(pr.y);
+        const int32_t ctx_l = ctx / A.parts, word_l = word / A.parts;
+        const float alpha = A.alpha_begin + (A.alpha_end - A.alpha_begin) * (float)((double)i / (double)(A.npairs > 1 ? A.npairs : 1));
         int32_t tgt[SGNS_NEG];
 #pragma unroll
         for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readlane(mine, j + 1);
+        if (i + 1 < i_end) mine = draw(i + 1);          // next pair's negatives: two dependent table lookups, hidden behind this pair
 
         float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
         float *pc = A.SynPos + (int64_t)ctx_l * d;
