@@ -42,3 +42,17 @@ def test_walks_weighted_second_order_on_hubs(rmat):
     c, UT, KT = dev.unigram()
     assert np.array_equal(c, oracle.n2v_vocab(n, got))
     dev.close()
+
+
+def test_node2vec_hogwild_map_on_power_law_graph(rmat):
+    """Hub rows are the contended ones under Hogwild: the GPU path must still land on the sequential oracle's MAP."""
+    from gem_amd.embedding.node2vec import node2vec
+    from gem_amd.evaluation import reconstruction as gr
+    n, src, dst, w, _ = edge_arrays(rmat)
+    maps = []
+    for seed in (1, 2):
+        m = node2vec(d=16, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, seed=seed)
+        maps.append(gr.evaluateStaticGraphReconstruction(rmat, m, m.learn_embedding(graph=rmat), None)[0])
+    X, _ = oracle.n2v_train(n, src, dst, None, 16, 80, 10, 10, 1, 1.0, 1.0, 1, 11)
+    ref = gr.evaluateStaticGraphReconstruction(rmat, m, X.astype(np.float64), None)[0]
+    assert abs(np.mean(maps) - ref) <= 0.1 * ref, (maps, ref)
