@@ -164,11 +164,15 @@ def test_hogwild_map_parity_with_oracle_and_snap(karate, sbm1024):
     t1 = np.mean(ref['sbm1024_d16_t1'])
     assert abs(np.mean(maps) - t1) <= 0.03 * t1, (maps, ref['sbm1024_d16_t1'])
     assert np.mean(maps) > np.mean(ref['sbm1024_d16_t8'])
-    m = node2vec(d=128, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, seed=4)
-    Y = m.learn_embedding(graph=sbm1024, is_weighted=True, no_python=True)
-    M = gr.evaluateStaticGraphReconstruction(sbm1024, m, Y, None)[0]
+    # d=128: the binary's own two race-free runs differ by 5.6 % (0.1725 / 0.1825): compare means, tolerance = that spread
+    maps = []
+    for seed in (4, 5, 6):
+        m = node2vec(d=128, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, seed=seed)
+        Y = m.learn_embedding(graph=sbm1024, is_weighted=True, no_python=True)
+        maps.append(gr.evaluateStaticGraphReconstruction(sbm1024, m, Y, None)[0])
     t1 = np.mean(ref['sbm1024_d128_t1'])
-    assert abs(M - t1) <= 0.03 * t1, (M, ref['sbm1024_d128_t1'])
+    assert abs(np.mean(maps) - t1) <= 0.056 * t1, (maps, ref['sbm1024_d128_t1'])
+    assert np.mean(maps) > np.mean(ref['sbm1024_d128_t8'])
     # karate: reference acceptance test (tests/test_karate.py:57-60,78) + MAP inside the binary's observed band
     tgt = np.loadtxt(golden_path('ref_karate_node2vec.txt'))
     maps = []
