@@ -66,3 +66,21 @@ def test_sampled_map_equals_full(sbm1024):
     nodes = [0, 17, 500, 1000, 1023]
     got = gr.sampled_map(sbm1024, lambda i: np.where(np.arange(1024) == i, 0.0, X @ X[i]), nodes)
     assert got == pytest.approx(ap[nodes].mean(), abs=1e-12)
+
+
+def test_stored_snap_embeddings_carry_the_recorded_map(sbm1024):
+    """tests/golden/n2v_snap_sbm1024_*.npz are embeddings written by the real SNAP binary (first run of each setting in
+    scripts/make_golden.py); their MAP under this evaluator equals the value the reference evaluator recorded in
+    n2v_ref.json, and they show what racing OpenMP threads do to the result (t8: collapsed onto one direction)."""
+    ref = json.load(open(golden_path('n2v_ref.json')))
+    m = node2vec(d=128, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
+    cos = {}
+    for thr in ('t1', 't8'):
+        for d in (16, 128):
+            X = np.load(golden_path('n2v_snap_sbm1024_d%d_%s.npz' % (d, thr)))['X'].astype(np.float64)
+            MAP = gr.evaluateStaticGraphReconstruction(sbm1024, m, X, None)[0]
+            assert MAP == pytest.approx(ref['sbm1024_d%d_%s' % (d, thr)][0], abs=3e-4)        # stored as float32
+            U = X / np.linalg.norm(X, axis=1, keepdims=True)
+            cos[(d, thr)] = float(np.linalg.norm(U.mean(axis=0)))                               # 1.0 = all rows parallel
+    # race-free rows share a common component (|mean unit vector| ~0.88-0.89); the 8-thread runs are almost parallel (~0.995)
+    assert cos[(16, 't8')] > 0.99 > 0.93 > cos[(16, 't1')] and cos[(128, 't8')] > 0.99 > 0.93 > cos[(128, 't1')]
