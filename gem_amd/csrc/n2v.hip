@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void sgns_bucket_pairs_kernel(const int32_t *_
             if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) {
                 const int key = (walk[cp] % parts) * parts + wkey;
                 const int64_t at = (int64_t)base[key] + atomicAdd(&hist[key], 1);
-                if (at < cap) out[at] = make_int2(walk[cp], word);
+                if (at < cap) out[at] = make_int2(walk[cp] / parts, word / parts);     // LOCAL row indices inside their partitions
             }
         }
 }
@@ -739,30 +739,39 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
     const int64_t i_end = (gw + 1) * chunk < A.npairs ? (gw + 1) * chunk : A.npairs;
     // pairs arrive in walk order, so consecutive pairs usually share their centre word: its SynNeg row (the positive
     // target) stays in registers until the word changes, like in the walk-based kernel
+    const float alpha_slope = (A.alpha_end - A.alpha_begin) / (float)(A.npairs > 1 ? A.npairs : 1);
     float yp[NV][VEC];
     int32_t held = -1;                                    // local row index currently in yp
-    // lanes 1..5 draw the five negative targets of pair i from the visiting partition's alias table
-    auto draw = [&](int64_t i) -> int32_t {
+    // negative targets are drawn for PAIR_BATCH = 12 pairs at a time: lane 5p + (j-1) draws target j of pair i0 + p from the
+    // visiting partition's alias table (two dependent lookups), one batch ahead of its use
+    constexpr int PAIR_BATCH = 12;
+    auto draw = [&](int64_t i0) -> int32_t {
         int32_t m = -1;
-        if (lane >= 1 && lane <= SGNS_NEG) {
+        const int p = lane / SGNS_NEG, j = lane - p * SGNS_NEG + 1;
+        const int64_t i = i0 + p;
+        if (p < PAIR_BATCH && i < i_end) {
             const u32x4 rn = philox4x32_10(A.seed, (uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.stream_id,
-                                           (uint32_t)TAG_NEG | ((uint32_t)lane << 16) | 0x80000000u);
+                                           (uint32_t)TAG_NEG | ((uint32_t)j << 16) | 0x80000000u);
             const uint32_t slot = mulhi_range(rn.x, (uint32_t)A.n_local_neg);
             const int32_t X = quirk ? A.KTp[slot] : (int32_t)slot;
             m = (u01(rn.y) < A.UTp[X]) ? X : A.KTp[X];
         }
         return m;
     };
-    int32_t mine = gw * chunk < i_end ? draw(gw * chunk) : -1;
-    for (int64_t i = gw * chunk; i < i_end; ++i) {
+    const int64_t i_begin = gw * chunk;
+    int32_t mine_cur = i_begin < i_end ? draw(i_begin) : -1, mine_next = -1;
+    for (int64_t i = i_begin; i < i_end; ++i) {
+        const int slot_in_batch = (int)((i - i_begin) % PAIR_BATCH);
+        if (slot_in_batch == 0) {
+            if (i != i_begin) mine_cur = mine_next;
+            mine_next = draw(i + PAIR_BATCH);
+        }
         const int2 pr = A.pairs[i];
-        const int32_t ctx = __builtin_amdgcn_readfirstlane(pr.x), word = __builtin_amdgcn_readfirstlane(pr.y);
-        const int32_t ctx_l = ctx / A.parts, word_l = word / A.parts;
-        const float alpha = A.alpha_begin + (A.alpha_end - A.alpha_begin) * (float)((double)i / (double)(A.npairs > 1 ? A.npairs : 1));
+        const int32_t ctx_l = __builtin_amdgcn_readfirstlane(pr.x), word_l = __builtin_amdgcn_readfirstlane(pr.y);   // local rows
+        const float alpha = A.alpha_begin + alpha_slope * (float)i;
         int32_t tgt[SGNS_NEG];
 #pragma unroll
-        for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readlane(mine, j + 1);
-        if (i + 1 < i_end) mine = draw(i + 1);          // next pair's negatives: two dependent table lookups, hidden behind this pair
+        for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readlane(mine_cur, slot_in_batch * SGNS_NEG + j);
 
         float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
         float *pc = A.SynPos + (int64_t)ctx_l * d;

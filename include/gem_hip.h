@@ -192,13 +192,14 @@ int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0,
  * node v belongs to partition v % parts with local row v / parts; the (context, word) pairs TrainModel forms are
  * materialised (emit_pairs: int32 pairs {context, word}, appended at an atomic cursor `d_count` the caller zeroes),
  * bucketed by the caller by (context % parts, word % parts), and each bucket is trained against ONE SynPos
- * partition and ONE SynNeg partition (train_pairs; negatives come from the unigram table restricted to the word's
+ * partition and ONE SynNeg partition (train_pairs takes LOCAL row indices {context / parts, word / parts}; negatives come from the unigram table restricted to the word's
  * partition, built by build_unigram_parts from the global counts). */
 int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, float *UT_out, int32_t *KT_out);
 int gemhip_sgns_emit_pairs(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi,
                            uint64_t seed, void *d_pairs, int64_t cap, void *d_count, void *stream);
-/* Same pairs, written GROUPED by key = (context % parts) * parts + (word % parts) (counting sort on the device);
- * counts_host[parts*parts] receives the bucket sizes (bucket k starts at the sum of the sizes before it). */
+/* Same pairs, written GROUPED by key = (context % parts) * parts + (word % parts) (counting sort on the device) and
+ * as LOCAL row indices {context / parts, word / parts} -- what train_pairs consumes; counts_host[parts*parts]
+ * receives the bucket sizes (bucket k starts at the sum of the sizes before it). */
 int gemhip_sgns_emit_pairs_bucketed(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi,
                                     uint64_t seed, int32_t parts, void *d_pairs, int64_t cap, int64_t *counts_host,
                                     void *stream);

@@ -347,7 +347,7 @@ void oracle_sgns_train_pairs(int32_t d, int64_t npairs, const int32_t *ctx, cons
 {
     float *neu1e = (float *)malloc(sizeof(float) * (size_t)d);
     for (int64_t i = 0; i < npairs; ++i) {
-        const float alpha = alpha_begin + (alpha_end - alpha_begin) * (float)((double)i / (double)(npairs > 1 ? npairs : 1));
+        const float alpha = alpha_begin + ((alpha_end - alpha_begin) / (float)(npairs > 1 ? npairs : 1)) * (float)i;
         float *xc = SynPos + (size_t)ctx[i] * d;
         const int32_t w = word[i];
         for (int32_t k = 0; k < d; ++k) neu1e[k] = 0.0f;

@@ -157,12 +157,12 @@ class OraclePart(OracleN2V):
         pr = oracle.sgns_pairs(self.w[lo:hi], window, epoch, self.lo + lo, seed)
         key = (pr[:, 0] % parts) * parts + (pr[:, 1] % parts)
         order = np.argsort(key, kind='stable')
-        return torch.from_numpy(np.ascontiguousarray(pr[order])), np.bincount(key, minlength=parts * parts).tolist()
+        return torch.from_numpy(np.ascontiguousarray(pr[order] // parts)), np.bincount(key, minlength=parts * parts).tolist()   # local rows
 
     def train_pairs(self, bucket, neg_part, P_part, N_part, a0, a1, seed, stream_id, flags):
         if bucket.shape[0] == 0:
             return
-        local = (bucket // self.parts).numpy()
+        local = bucket.numpy()                                   # already local row indices
         j0, j1 = self.off[neg_part], self.off[neg_part + 1]
         oracle.sgns_train_pairs_local(local, self.UTp[j0:j1], self.KTp[j0:j1], a0, a1, seed, stream_id & 0xffffffff, flags,
                                       P_part.numpy(), N_part.numpy())

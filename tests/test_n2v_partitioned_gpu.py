@@ -41,9 +41,9 @@ def test_emit_pairs_is_the_trainmodel_pair_multiset(sbm1024):
         assert sum(counts) == len(want) == len(got)
         keyw = (want[:, 0] % parts) * parts + (want[:, 1] % parts)
         assert counts == np.bincount(keyw, minlength=parts * parts).tolist()
-        keyg = (got[:, 0] % parts) * parts + (got[:, 1] % parts)
-        assert np.all(np.diff(keyg) >= 0)                                  # grouped in key order
-        assert np.array_equal(key(got), key(want))
+        keyg = np.repeat(np.arange(parts * parts), counts)                 # bucket of every output position
+        glob = np.stack([got[:, 0] * parts + keyg // parts, got[:, 1] * parts + keyg % parts], axis=1)   # local rows -> global ids
+        assert np.array_equal(key(glob), key(want))
     b.close()
 
 
@@ -60,14 +60,14 @@ def test_train_pairs_deterministic_matches_oracle(sbm1024, d, parts, flags):
     pairs = b.emit_pairs(5, 0, 0, 256, 3)
     gi, gj = 1 % parts, 0                                     # bucket (context partition gi, word partition gj)
     sel = (pairs[:, 0] % parts == gi) & (pairs[:, 1] % parts == gj)
-    bucket = pairs[sel].contiguous()
+    bucket = (pairs[sel] // parts).contiguous()              # train_pairs takes local row indices
     assert bucket.shape[0] > 200
     P, N, _ = b.init_part_tables(3, gi, parts)
     Np = (0.05 * torch.randn(N.shape, generator=torch.Generator().manual_seed(1))).to(N.device)
     Po, No = P.cpu().numpy().copy(), Np.cpu().numpy().copy()
     b.train_pairs(bucket, gj, P, Np, 0.025, 0.01, 3, 77, flags | 4)
     torch.cuda.synchronize()
-    oracle.sgns_train_pairs_local((bucket // parts).cpu().numpy(), UT[off[gj]:off[gj + 1]], KT[off[gj]:off[gj + 1]], 0.025, 0.01, 3, 77, flags, Po, No)
+    oracle.sgns_train_pairs_local(bucket.cpu().numpy(), UT[off[gj]:off[gj + 1]], KT[off[gj]:off[gj + 1]], 0.025, 0.01, 3, 77, flags, Po, No)
     for got, want in ((P.cpu().numpy(), Po), (Np.cpu().numpy(), No)):
         assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max() + 1e-6
     b.close()
