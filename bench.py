@@ -226,9 +226,7 @@ class N2VWorkload(object):
         evaluator's semantics (gem_amd/csrc/eval.hip) -- shows the timed pass really trained the embedding."""
         from gem_amd.evaluation import reconstruction as gr
         rng = np.random.RandomState(0)
-        deg = np.bincount(self.g.src, minlength=self.g.n)
-        pool = np.flatnonzero(deg <= 512)             # the evaluation kernel keeps a node's true neighbours in registers (<= 512)
-        nodes = rng.choice(pool, size=min(nsample, len(pool)), replace=False)
+        nodes = rng.choice(self.g.n, size=min(nsample, self.g.n), replace=False)        # uniform over all nodes, hubs included
         ap = gr.sampled_ap_gpu(self.g, None, self.P.cpu().numpy(), nodes)
         return {'sampled_map': float(ap.mean()), 'nodes_sampled': int(len(nodes)), 'evaluator': 'metrics.computeMAP semantics on the GPU'}
 

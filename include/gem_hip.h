@@ -278,7 +278,8 @@ int gemhip_hope_tsgemm(int64_t n, int32_t m, int32_t b2, const float *X_host, co
  * score(i, j) = A_i . B_j  (A = B = X for GF / node2vec, gf.py:103-104; A = X[:, :k], B = X[:, k:] for
  * HOPE, hope.py:43-44) -- without the n x n matrix of static_graph_embedding.py:48-65.
  * A_host, B_host: [n][ld] float32 (B_host NULL = A); row_ptr/col: CSR of the TRUE graph; ap_out[nsample].
- * MAP over the sample = mean(ap_out).  Sampled nodes may have at most 512 candidate neighbours. */
+ * MAP over the sample = mean(ap_out).  Any degree: a hub's true neighbours are processed in chunks of 512
+ * (one workgroup per chunk); duplicate columns in the CSR count once. */
 int gemhip_eval_sampled_ap(int64_t n, int32_t da, int32_t ld, const float *A_host, const float *B_host,
                            const int64_t *row_ptr, const int32_t *col, int32_t undirected,
                            int64_t nsample, const int32_t *nodes, double *ap_out);

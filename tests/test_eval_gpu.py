@@ -40,3 +40,30 @@ def test_matches_evaluator_on_reference_goldens(karate, sbm1024):
 def test_ties_follow_the_stable_sort_rule(sbm1024):
     X = np.round(np.random.RandomState(0).randn(1024, 4) * 2) / 2                   # coarse grid -> many exact ties
     check(sbm1024, GraphFactorization(d=4, max_iter=1, eta=0.1, regu=0.1), X)
+
+
+def test_hub_nodes_with_more_than_512_neighbours():
+    """Power-law hubs: a node's true neighbours are processed in chunks of 512 (one workgroup per chunk)."""
+    from gem_amd.graph import EdgeListGraph
+    n = 3000
+    rng = np.random.RandomState(3)
+    hub_nb = {0: rng.choice(np.arange(1, n), 1700, replace=False), 7: rng.choice(np.arange(8, n), 513, replace=False)}
+    src = [rng.randint(0, n, 6000)]; dst = [rng.randint(0, n, 6000)]
+    for h, nb in hub_nb.items():
+        src.append(np.full(len(nb), h)); dst.append(nb)
+    src = np.concatenate(src); dst = np.concatenate(dst)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    key = np.unique(np.minimum(src, dst) * n + np.maximum(src, dst))
+    a, b = key // n, key % n
+    G = EdgeListGraph(n, np.concatenate([a, b]), np.concatenate([b, a]), None)
+    X = rng.randn(n, 16) * 0.5
+    X32 = X.astype(np.float32).astype(np.float64)
+    nodes = np.array([0, 7, 1, 2999, 1500], dtype=np.int32)
+    ap = gr.sampled_ap_gpu(G, None, X32, nodes)
+    adj = np.zeros((n, n), dtype=bool); adj[G.src, G.dst] = True
+    ap_ref = gr.average_precision_rows(X32 @ X32.T, adj, undirected=True)[nodes]
+    assert np.abs(ap - ap_ref).max() < 1e-9
+    ap_d = gr.sampled_ap_gpu(G, None, X32, nodes, is_undirected=False)
+    ap_ref_d = gr.average_precision_rows(X32 @ X32.T, adj, undirected=False)[nodes]
+    assert np.abs(ap_d - ap_ref_d).max() < 1e-9
