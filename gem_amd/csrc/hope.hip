@@ -509,7 +509,7 @@ bool chol_inverse(int b, const std::vector<double> &G, double floor, std::vector
 // CholeskyQR step (Y <- Y R^-1); otherwise the Gram eigen-decomposition Y <- Y W L^-1/2 drops directions whose
 // relative energy is below `tol` or whose absolute energy is below `abs_floor` (rank revealing).  Two passes.
 // Returns the number of columns kept.
-int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, double abs_floor = 0.0, int passes = 2)
+int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, double abs_floor = 0.0, int passes = 2, bool *remixed = nullptr)
 {
     int keep = b;
     for (int pass = 0; pass < passes && keep > 0 && !H.err; ++pass) {
@@ -522,6 +522,7 @@ int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, doub
         // Cholesky pivots are Schur complements: a pivot below 1e-4 * dmax means condition > ~1e4 (or rank loss)
         if (!chol_inverse(keep, G, std::max(1e-4 * dmax, abs_floor), C)) {
             sym_eig(keep, G, w);                                  // ascending; G columns = eigenvectors
+            if (remixed) *remixed = true;                         // columns are no longer (triangular) images of the input columns
             const double lmax = std::max(w[keep - 1], 0.0);
             int first = 0;
             while (first < keep && !(w[first] > tol * lmax && w[first] > abs_floor && w[first] > 0.0)) ++first;
@@ -615,10 +616,10 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
     const int mmax = (int)std::min<int64_t>(std::min<int64_t>((int64_t)b * (krylov_steps + 1), n), 512);
     GEMHIP_REQUIRE(b <= 512 && k <= mmax, "hope: k + oversample = %d too large (max 512)", b);
     const int ldm = (mmax + 31) / 32 * 32, ldb = (b + 31) / 32 * 32;
-    float *Vall = nullptr, *Ball = nullptr, *Wk = nullptr, *T0 = nullptr, *T1 = nullptr, *W0 = nullptr, *Tmp = nullptr;
+    float *Vall = nullptr, *Ball = nullptr, *T0 = nullptr, *T1 = nullptr, *W0 = nullptr, *Tmp = nullptr;
     auto dalloc = [&](float **p, size_t cols) { HOPE_TRY(H, hipMalloc((void **)p, (size_t)n * cols * sizeof(float))); if (!H.err) HOPE_TRY(H, hipMemset(*p, 0, (size_t)n * cols * sizeof(float))); };
-    dalloc(&Vall, ldm); dalloc(&Ball, ldm); dalloc(&Wk, ldb); dalloc(&T0, ldb); dalloc(&T1, ldb); dalloc(&W0, ldb); dalloc(&Tmp, ldm);
-    auto cleanup = [&]() { hipFree(Vall); hipFree(Ball); hipFree(Wk); hipFree(T0); hipFree(T1); hipFree(W0); hipFree(Tmp); };
+    dalloc(&Vall, ldm); dalloc(&Ball, ldm); dalloc(&T0, ldb); dalloc(&T1, ldb); dalloc(&W0, ldb); dalloc(&Tmp, ldm);
+    auto cleanup = [&]() { hipFree(Vall); hipFree(Ball); hipFree(T0); hipFree(T1); hipFree(W0); hipFree(Tmp); };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (!H.err) { HOPE_TRY(H, hipEventCreate(&ev0)); HOPE_TRY(H, hipEventCreate(&ev1)); HOPE_TRY(H, hipEventCreate(&H.sp0)); HOPE_TRY(H, hipEventCreate(&H.sp1)); H.time_spmm = (stats != nullptr); }
     if (H.err) { cleanup(); return H.err; }
@@ -628,18 +629,30 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
     hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, H.s, Vall, n, b, ldm, seed);
     int m0 = orth(H, Vall, ldm, b, Tmp, ldm, 1e-10);
 
-    std::vector<double> sig_old(k, 0.0), sig(k, 0.0), Wv, ev;
-    int mc = 0, restarts_done = 0;
+    // Locking (deflation): a leading Ritz pair of the restart block whose residual ||S^T S v - sigma^2 v|| / sigma^2 fell
+    // below lock_tol is frozen -- columns [0, nl) of Vall / Ball hold the locked right vectors and S v.  Later cycles only
+    // orthogonalise against them: the Krylov blocks, the S applications and the projected eigenproblem shrink with every
+    // lock.  (|sigma error| / sigma ~ residual^2 * sigma^2 / gap, so sqrt(tol)/10 keeps locked values inside `tol`.)
+    std::vector<double> sig_old(k, 0.0), sig(k, 0.0), Wv, ev, lock_sig, act_sig;
+    int mc = 0, restarts_done = 0, nl = 0, ma = 0;
+    bool v0_is_ritz = false;
+    const bool locking = getenv("GEMHIP_HOPE_NO_LOCK") == nullptr;
+    const double lock_tol = 0.1 * std::sqrt(std::max((double)tol, 1e-12));
+    const int b_min = std::min(b, std::max(2 * (int)oversample, 16));
     double last_change = 1.0, last_residual = 1.0;
     bool exact = false;
     const bool debug = getenv("GEMHIP_HOPE_DEBUG") != nullptr;
     for (int rs = 0; rs <= max_restarts && !H.err; ++rs) {
-        mc = m0;
-        int prev_off = 0, prev_b = m0;
-        for (int j = 1; j <= krylov_steps && mc < mmax && !H.err; ++j) {
-            // W = S^T S V_{j-1}
-            apply_S(H, Vall + prev_off, ldm, prev_b, terms, T0, T1, W0, ldb, Wk, ldb);
-            apply_ST(H, Wk, ldb, prev_b, terms, T0, T1, ldb, W0, ldb);
+        mc = nl + m0;
+        int prev_off = nl, prev_b = m0, b_valid = nl;               // Ball columns [0, b_valid) hold S Vall
+        // the basis budget (mmax columns) that locked pairs no longer need buys a deeper Krylov polynomial for the rest
+        int steps = krylov_steps;
+        if (nl > 0 && m0 > 0 && getenv("GEMHIP_HOPE_FIXED_DEPTH") == nullptr) steps = std::max(steps, (mmax - nl) / m0 - 1);
+        for (int j = 1; j <= steps && mc < mmax && !H.err; ++j) {
+            // W = S^T S V_{j-1};  S V_{j-1} is also the block of B = S Vall the Rayleigh-Ritz step needs: keep it in place
+            apply_S(H, Vall + prev_off, ldm, prev_b, terms, T0, T1, W0, ldb, Ball + prev_off, ldm);
+            apply_ST(H, Ball + prev_off, ldm, prev_b, terms, T0, T1, ldb, W0, ldb);
+            b_valid = prev_off + prev_b;
             // energy scale of the new block before projection (what is left after projecting out the basis is only kept if
             // it stands above fp32 rounding noise relative to this): the block is S^T S applied to orthonormal columns, so
             // sigma_1^4 from the previous cycle bounds it; the first cycle measures it
@@ -653,69 +666,103 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
             // full re-orthogonalisation against the basis so far, normalise, then project again on the normalised block:
             // a direction that survives the rank filter with small amplitude carries rounding noise that lies INSIDE
             // span(Vall); after normalisation that noise is O(eps / amplitude)
+            float *Wp = W0;                                         // the part of the new block that is kept
+            int wcols = prev_b;
             auto project = [&](int cols) {
                 std::vector<double> C;
-                gram(H, Vall, ldm, mc, W0, ldb, cols, C);
-                tsgemm(H, Vall, ldm, mc, C, cols, -1.0f, W0, ldb, W0, ldb);
+                gram(H, Vall, ldm, mc, Wp, ldb, cols, C);
+                tsgemm(H, Vall, ldm, mc, C, cols, -1.0f, Wp, ldb, Wp, ldb);
             };
-            project(prev_b);
+            project(wcols);
             if (j == 1 && rs > 0 && sig_old[0] > 0) {
-                // V_0 holds the Ritz vectors of the previous cycle (descending sigma): what is left of S^T S v_c after
+                // V_0 holds Ritz vectors of the previous cycle (descending sigma): what is left of S^T S v_c after
                 // projecting out span(V_0) is exactly the residual  ||S^T S v_c - sigma_c^2 v_c||  of Ritz pair c
                 std::vector<double> D;
                 gram(H, W0, ldb, prev_b, W0, ldb, prev_b, D);
                 double r2 = 0.0;
-                for (int c = 0; c < std::min(k, prev_b) && !H.err; ++c) r2 = std::max(r2, D[(size_t)c * prev_b + c]);
+                const int want = k - nl;                            // wanted pairs still active (the leading ones of V_0)
+                for (int c = 0; c < std::min(want, prev_b) && !H.err; ++c) r2 = std::max(r2, D[(size_t)c * prev_b + c]);
                 last_residual = std::sqrt(r2) / (sig_old[0] * sig_old[0]);
+                int newl = 0;
+                if (locking && v0_is_ritz && !H.err)
+                    while (newl < want - 1 && newl < prev_b - b_min && act_sig[newl] > 0 &&
+                           std::sqrt(std::max(D[(size_t)newl * prev_b + newl], 0.0)) < lock_tol * act_sig[newl] * act_sig[newl]) ++newl;
+                if (newl > 0) {
+                    // columns [nl, nl+newl) of Vall / Ball already are v_c and S v_c: freezing them is a change of bookkeeping
+                    for (int c = 0; c < newl; ++c) lock_sig.push_back(act_sig[c]);
+                    nl += newl; Wp = W0 + newl; wcols = prev_b - newl;
+                    if (debug) fprintf(stderr, "[hope] cycle %d locked %d pairs (%d in total)\n", rs, newl, nl);
+                }
             }
-            int nb = orth(H, W0, ldb, prev_b, Tmp, ldm, 1e-11, 1e-12 * ref_energy);
+            int nb = orth(H, Wp, ldb, wcols, Tmp, ldm, 1e-11, 1e-12 * ref_energy);
             if (nb > 0) {
                 project(nb);
-                nb = orth(H, W0, ldb, nb, Tmp, ldm, 1e-9, 0.25, 1);   // unit columns: drop what lost half its norm; one polishing pass
+                nb = orth(H, Wp, ldb, nb, Tmp, ldm, 1e-9, 0.25, 1);   // unit columns: drop what lost half its norm; one polishing pass
             }
             nb = std::min(nb, mmax - mc);
             if (nb <= 0) break;
-            HOPE_TRY(H, hipMemcpy2DAsync(Vall + mc, (size_t)ldm * sizeof(float), W0, (size_t)ldb * sizeof(float), (size_t)nb * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
+            HOPE_TRY(H, hipMemcpy2DAsync(Vall + mc, (size_t)ldm * sizeof(float), Wp, (size_t)ldb * sizeof(float), (size_t)nb * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
             prev_off = mc; prev_b = nb; mc += nb;
         }
-        // B = S Vall, block by block
-        for (int off = 0; off < mc && !H.err; off += b) {
+        // B = S Vall for the blocks the Krylov steps did not produce (the last one)
+        for (int off = b_valid; off < mc && !H.err; off += b) {
             const int bb = std::min(b, mc - off);
             apply_S(H, Vall + off, ldm, bb, terms, T0, T1, W0, ldb, Ball + off, ldm);
         }
-        // Rayleigh-Ritz: B^T B = Wv diag(ev) Wv^T
-        gram(H, Ball, ldm, mc, Ball, ldm, mc, Wv);
+        // Rayleigh-Ritz on the active columns: B_a^T B_a = Wv diag(ev) Wv^T
+        ma = mc - nl;
+        gram(H, Ball + nl, ldm, ma, Ball + nl, ldm, ma, Wv);
         if (H.err) break;
-        sym_eig(mc, Wv, ev);
+        sym_eig(ma, Wv, ev);
         GEMHIP_REQUIRE(mc >= k || (cleanup(), false), "hope: Krylov space collapsed to %d < k=%d columns (rank-deficient S?)", mc, k);
-        for (int j = 0; j < k; ++j) sig[j] = std::sqrt(std::max(ev[mc - 1 - j], 0.0));          // descending
+        {
+            std::vector<double> all(lock_sig);
+            for (int j = 0; j < std::min(ma, k); ++j) all.push_back(std::sqrt(std::max(ev[ma - 1 - j], 0.0)));
+            std::sort(all.begin(), all.end(), std::greater<double>());
+            for (int j = 0; j < k; ++j) sig[j] = all[j];                                           // descending
+        }
         double change = 0.0;
         for (int j = 0; j < k; ++j) change = std::max(change, std::fabs(sig[j] - sig_old[j]));
         last_change = sig[0] > 0 ? change / sig[0] : 0.0;
         sig_old = sig;
         restarts_done = rs;
-        if (debug) fprintf(stderr, "[hope] cycle %d basis %d sigma_k %.6g sigma_1 %.6g change %.3e residual(prev cycle) %.3e\n", rs, mc, sig[k - 1], sig[0], last_change, last_residual);
-        exact = (mc >= n) || (krylov_steps == 0 && false);
+        if (debug) fprintf(stderr, "[hope] cycle %d basis %d (%d locked) sigma_k %.6g sigma_1 %.6g change %.3e residual(prev cycle) %.3e\n", rs, mc, nl, sig[k - 1], sig[0], last_change, last_residual);
+        exact = (mc >= n);
         const bool done = exact || (rs > 0 && last_change < tol) || rs == max_restarts;
         if (done) break;
-        // restart from the best b right Ritz vectors:  V0 <- Vall Wv[:, top b]
-        const int nb = std::min(b, mc);
-        std::vector<double> C((size_t)mc * nb);
-        for (int i = 0; i < mc; ++i)
-            for (int j = 0; j < nb; ++j) C[(size_t)i * nb + j] = Wv[(size_t)i * mc + (mc - 1 - j)];
-        tsgemm(H, Vall, ldm, mc, C, nb, 1.0f, nullptr, 0, Tmp, ldm);
-        HOPE_TRY(H, hipMemcpy2DAsync(Vall, (size_t)ldm * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)nb * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
-        m0 = orth(H, Vall, ldm, nb, Tmp, ldm, 1e-10);
+        // restart from the best right Ritz vectors of the active part:  V0 <- Vall[:, nl:] Wv[:, top]
+        const int nb = std::min(ma, std::max(b - nl, b_min));
+        std::vector<double> C((size_t)ma * nb);
+        for (int i = 0; i < ma; ++i)
+            for (int j = 0; j < nb; ++j) C[(size_t)i * nb + j] = Wv[(size_t)i * ma + (ma - 1 - j)];
+        tsgemm(H, Vall + nl, ldm, ma, C, nb, 1.0f, nullptr, 0, Tmp, ldm);
+        HOPE_TRY(H, hipMemcpy2DAsync(Vall + nl, (size_t)ldm * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)nb * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
+        bool remixed = false;
+        m0 = orth(H, Vall + nl, ldm, nb, Tmp, ldm, 1e-10, 0.0, 2, &remixed);
+        act_sig.assign(nb, 0.0);
+        for (int j = 0; j < nb; ++j) act_sig[j] = std::sqrt(std::max(ev[ma - 1 - j], 0.0));
+        v0_is_ritz = !remixed && m0 == nb;
     }
     if (!H.err) {
-        // U sqrt(S) = B Wv S^-1/2 ,  V sqrt(S) = Vall Wv S^1/2 ; columns in ASCENDING sigma (svds order, hope.py:33)
-        std::vector<double> Cu((size_t)mc * k), Cv((size_t)mc * k);
-        for (int j = 0; j < k; ++j) {
-            const int src = mc - k + j;                      // ascending eigenvalue index
-            const double s = std::sqrt(std::max(ev[src], 0.0));
+        // U sqrt(S) = B W S^-1/2 ,  V sqrt(S) = Vall W S^1/2 over the locked columns (W = identity there) and the active Ritz
+        // vectors; the k largest sigma, columns in ASCENDING sigma (svds order, hope.py:33)
+        struct Cand { double s; int locked; int idx; };
+        std::vector<Cand> cand;
+        for (int l = 0; l < nl; ++l) cand.push_back({lock_sig[l], 1, l});
+        for (int j = 0; j < std::min(ma, k); ++j) cand.push_back({std::sqrt(std::max(ev[ma - 1 - j], 0.0)), 0, ma - 1 - j});
+        std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.s > y.s; });
+        std::vector<double> Cu((size_t)mc * k, 0.0), Cv((size_t)mc * k, 0.0);
+        for (int r = 0; r < k; ++r) {
+            const int j = k - 1 - r;                         // output column (ascending sigma)
+            const double s = cand[r].s;
             sigma[j] = (float)s;
             const double su = out_mode == 1 ? (s > 0 ? 1.0 / s : 0.0) : (s > 0 ? 1.0 / std::sqrt(s) : 0.0), sv = out_mode == 1 ? 1.0 : std::sqrt(s);
-            for (int i = 0; i < mc; ++i) { Cu[(size_t)i * k + j] = Wv[(size_t)i * mc + src] * su; Cv[(size_t)i * k + j] = Wv[(size_t)i * mc + src] * sv; }
+            if (cand[r].locked) { Cu[(size_t)cand[r].idx * k + j] = su; Cv[(size_t)cand[r].idx * k + j] = sv; }
+            else
+                for (int i = 0; i < ma; ++i) {
+                    const double wv = Wv[(size_t)i * ma + cand[r].idx];
+                    Cu[(size_t)(nl + i) * k + j] = wv * su; Cv[(size_t)(nl + i) * k + j] = wv * sv;
+                }
         }
         if (U_sqrtS) {
             tsgemm(H, Ball, ldm, mc, Cu, k, 1.0f, nullptr, 0, Tmp, ldm);
