@@ -275,6 +275,9 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
     const EigOps &op = eig_ops();
     std::vector<double> e(n, 0.0);
     d.assign(n, 0.0);
+    const bool eig_dbg = getenv("GEMHIP_EIG_DEBUG") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tA = tnow();
     // column-major accessor: every O(n^3) loop below runs over the FIRST index, i.e. contiguous memory
     // (the input is symmetric, so its layout does not matter; the result is transposed back at the end)
     auto A = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
@@ -319,6 +322,7 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
         }
         d[i] = h;
     }
+    auto tB = tnow();
     for (int i = 0; i < n - 1; ++i) {
         A(n - 1, i) = A(i, i);
         A(i, i) = 1.0;
@@ -335,6 +339,7 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
     for (int j = 0; j < n; ++j) { d[j] = A(n - 1, j); A(n - 1, j) = 0.0; }
     A(n - 1, n - 1) = 1.0;
     e[0] = 0.0;
+    auto tC = tnow();
     // QL
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0.0;
@@ -381,6 +386,8 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
         d[l] += f;
         e[l] = 0.0;
     }
+    if (eig_dbg) { auto tD = tnow(); auto ms = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+        fprintf(stderr, "[eig] n=%d reduce %.2f ms  accumulate %.2f ms  ql %.2f ms\n", n, ms(tA, tB), ms(tB, tC), ms(tC, tD)); }
     for (int i = 0; i < n - 1; ++i) {                   // sort ascending
         int k = i; double p = d[i];
         for (int j = i + 1; j < n; ++j) if (d[j] < p) { k = j; p = d[j]; }
@@ -613,7 +620,9 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
                       int terms, double br, int out_mode, float *U_sqrtS, float *V_sqrtS, float *sigma, double *stats)
 {
     const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
-    const int mmax = (int)std::min<int64_t>(std::min<int64_t>((int64_t)b * (krylov_steps + 1), n), 512);
+    int64_t basis_cols = (int64_t)b * (krylov_steps + 1);
+    if (const char *e = getenv("GEMHIP_HOPE_BASIS_COLS")) basis_cols = std::max<int64_t>(basis_cols, atoi(e));
+    const int mmax = (int)std::min<int64_t>(std::min<int64_t>(basis_cols, n), 512);
     GEMHIP_REQUIRE(b <= 512 && k <= mmax, "hope: k + oversample = %d too large (max 512)", b);
     const int ldm = (mmax + 31) / 32 * 32, ldb = (b + 31) / 32 * 32;
     float *Vall = nullptr, *Ball = nullptr, *T0 = nullptr, *T1 = nullptr, *W0 = nullptr, *Tmp = nullptr;
@@ -647,7 +656,11 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
         int prev_off = nl, prev_b = m0, b_valid = nl;               // Ball columns [0, b_valid) hold S Vall
         // the basis budget (mmax columns) that locked pairs no longer need buys a deeper Krylov polynomial for the rest
         int steps = krylov_steps;
-        if (nl > 0 && m0 > 0 && getenv("GEMHIP_HOPE_FIXED_DEPTH") == nullptr) steps = std::max(steps, (mmax - nl) / m0 - 1);
+        if (nl > 0 && m0 > 0 && getenv("GEMHIP_HOPE_FIXED_DEPTH") == nullptr) {
+            int cols = mmax;
+            if (const char *e = getenv("GEMHIP_HOPE_DEPTH_COLS")) cols = std::min(mmax, std::max(atoi(e), nl + m0));
+            steps = std::max(steps, (cols - nl) / m0 - 1);
+        }
         for (int j = 1; j <= steps && mc < mmax && !H.err; ++j) {
             // W = S^T S V_{j-1};  S V_{j-1} is also the block of B = S Vall the Rayleigh-Ritz step needs: keep it in place
             apply_S(H, Vall + prev_off, ldm, prev_b, terms, T0, T1, W0, ldb, Ball + prev_off, ldm);
