@@ -9,8 +9,11 @@ with j > i fire and only row i is written; returns and stores the (n, d)
 float64 array.  The sweeps run in libgem_hip.so (gem_amd/csrc/gf.hip) in fp32 --
 the precision of the reference's own native path gem/c_src/gf.cpp.
 
-Extra kwarg (through the usual hyper-parameter mechanism): `seed` (use a private
-RandomState instead of numpy's global RNG).
+Extra kwargs (through the usual hyper-parameter mechanism): `seed` (use a private
+RandomState instead of numpy's global RNG); `device_init=True` draws the
+0.01*N(0,1) initial table on the GPU from a Philox stream keyed by `seed` (what
+gf.cpp:41-52 does with its own generator) -- at 1M x 128 numpy's randn alone
+costs more than 100 sweeps.
 """
 import ctypes as C
 
@@ -37,16 +40,35 @@ class GraphFactorization(StaticGraphEmbedding):
         d = int(self._d)
         self._node_num = n
         seed = getattr(self, '_seed', None)
-        rng = np.random if seed is None else np.random.RandomState(seed)
-        X0 = (0.01 * rng.randn(n, d)).astype(np.float32)          # gf.py:92
         _hip.require_device()
         L = _hip.lib()
-        stats = (C.c_double * 4)()
-        _hip.check(L.gemhip_gf_train(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32),
-                                     _hip.ptr(_hip.as_f32(w), C.c_float), d, float(self._eta), float(self._regu),
-                                     int(self._max_iter), _hip.ptr(X0, C.c_float), stats))
-        self._stats = {'kernel_seconds': stats[0], 'updates_per_sweep': stats[1], 'rows_per_sweep': stats[2],
-                       'levels': stats[3]}
+        if getattr(self, '_device_init', False):
+            X0 = np.empty((n, d), dtype=np.float32)
+            plan = C.c_void_p()
+            info = (C.c_int64 * 8)()
+            _hip.check(L.gemhip_gf_plan_create(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32),
+                                               _hip.ptr(_hip.as_f32(w), C.c_float), d, 0, n, C.byref(plan)))
+            try:
+                _hip.check(L.gemhip_gf_plan_init_embedding(plan, int(seed if seed is not None else np.random.randint(2 ** 31 - 1)), 0.01))
+                _hip.check(L.gemhip_gf_plan_info(plan, info))
+                import time
+                t0 = time.time()
+                _hip.check(L.gemhip_gf_plan_sweeps(plan, int(self._max_iter), float(self._eta), float(self._regu), None))
+                _hip.check(L.gemhip_synchronize(None))
+                el = time.time() - t0
+                _hip.check(L.gemhip_gf_plan_get_embedding(plan, _hip.ptr(X0, C.c_float)))
+            finally:
+                L.gemhip_gf_plan_destroy(plan)
+            self._stats = {'kernel_seconds': el, 'updates_per_sweep': info[0], 'rows_per_sweep': info[1], 'levels': info[2]}
+        else:
+            rng = np.random if seed is None else np.random.RandomState(seed)
+            X0 = (0.01 * rng.randn(n, d)).astype(np.float32)          # gf.py:92
+            stats = (C.c_double * 4)()
+            _hip.check(L.gemhip_gf_train(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32),
+                                         _hip.ptr(_hip.as_f32(w), C.c_float), d, float(self._eta), float(self._regu),
+                                         int(self._max_iter), _hip.ptr(X0, C.c_float), stats))
+            self._stats = {'kernel_seconds': stats[0], 'updates_per_sweep': stats[1], 'rows_per_sweep': stats[2],
+                           'levels': stats[3]}
         self._X = X0.astype(np.float64)
         return self._X
 

@@ -7,6 +7,9 @@ Kept behaviours:
     expanded the same way (static_graph_embedding.py:8-19).  The class-level
     mutation is deliberate -- the reference does it and its tests rely on
     `model.hyper_params['method_name'] == model.get_method_name()`.
+    The knobs this backend ADDS (`backend_params`: seed, tolerances, ...) are not part
+    of that contract and stay on the instance: a model built without them always gets
+    the defaults, whatever an earlier model in the same process was given.
   * get_embedding() raises ValueError("Embedding not learned yet") before a fit (:38-46)
   * get_reconstructed_adj(X=None, node_l=None): stores X when given, zero
     diagonal (:48-65).  Here the n^2 Python loop is replaced by one matrix
@@ -18,14 +21,18 @@ import numpy as np
 
 class StaticGraphEmbedding(object):
     hyper_params = {}
+    backend_params = ('seed', 'device_init', 'flags', 'tol', 'oversample', 'krylov_steps', 'max_restarts')
 
     def __init__(self, *args, **kwargs):
         self._method_name = None
         self._d = None
         self._X = None
-        self.hyper_params.update(kwargs)
+        self.hyper_params.update({name: value for name, value in kwargs.items() if name not in self.backend_params})
         for name, value in self.hyper_params.items():
             setattr(self, '_' + name, value)
+        for name in self.backend_params:
+            if name in kwargs:
+                setattr(self, '_' + name, kwargs[name])
         for extra in args:
             for name in extra:
                 setattr(self, '_' + name, extra[name])

@@ -41,6 +41,20 @@ def test_kwargs_and_positional_dicts_become_attributes():
     assert GraphFactorization()._d == 8
 
 
+def test_backend_only_kwargs_stay_on_the_instance():
+    """seed / device_init / tol ... are knobs of this backend, not of GEM: they must not reach the next model through the
+    class-level hyper_params the way GEM's own keys do."""
+    a = GraphFactorization(d=4, eta=0.1, regu=0.1, max_iter=1, seed=3, device_init=True)
+    assert (a._seed, a._device_init) == (3, True)
+    b = GraphFactorization(d=4, eta=0.1, regu=0.1, max_iter=1)
+    assert not hasattr(b, '_seed') and not hasattr(b, '_device_init')
+    assert 'seed' not in GraphFactorization.hyper_params and 'device_init' not in GraphFactorization.hyper_params
+    h = HOPE(d=4, beta=0.01, tol=1e-3, oversample=4)
+    assert (h._tol, h._oversample) == (1e-3, 4) and not hasattr(HOPE(d=4, beta=0.01), '_tol')
+    n = node2vec(d=2, max_iter=1, walk_len=5, num_walks=1, con_size=2, ret_p=1, inout_p=1, seed=9, flags=8)
+    assert (n._seed, n._flags) == (9, 8) and not hasattr(node2vec(d=2), '_seed')
+
+
 def test_reconstructed_adj_sets_embedding_and_zero_diagonal():
     m = HOPE(d=4, beta=0.01)
     X = np.arange(12.0).reshape(3, 4)

@@ -163,3 +163,19 @@ def test_device_init_distribution():
     _hip.check(L.gemhip_gf_plan_destroy(plan))
     assert abs(X.mean()) < 1e-4 and abs(X.std() - 0.01) < 1e-4
     assert abs(float(((X / 0.01) ** 4).mean()) - 3.0) < 0.05             # gaussian kurtosis
+
+
+def test_device_init_option_trains_like_the_numpy_init(sbm1024):
+    """device_init=True: same algorithm from a Philox-drawn 0.01*N(0,1) table (what gf.cpp does with its own generator)."""
+    from gem_amd.evaluation import reconstruction as gr
+    maps = {}
+    for dev in (False, True):
+        m = GraphFactorization(d=32, max_iter=60, eta=0.02, regu=0.01, seed=3, device_init=dev)
+        X = m.learn_embedding(graph=sbm1024, is_weighted=True, no_python=True)
+        assert X.shape == (1024, 32) and X.dtype == np.float64 and np.isfinite(X).all()
+        assert m._stats['levels'] == 1 and m._stats['updates_per_sweep'] == 21045
+        maps[dev] = gr.evaluateStaticGraphReconstruction(sbm1024, m, X, None)[0]
+    assert abs(maps[True] - maps[False]) < 0.25 * maps[False], maps          # two different random inits
+    a = GraphFactorization(d=32, max_iter=2, eta=0.02, regu=0.01, seed=3, device_init=True).learn_embedding(graph=sbm1024)
+    b = GraphFactorization(d=32, max_iter=2, eta=0.02, regu=0.01, seed=3, device_init=True).learn_embedding(graph=sbm1024)
+    assert np.array_equal(a, b)                                   # seeded and deterministic
