@@ -229,6 +229,7 @@ void sym_eig(int n, std::vector<double> &V, std::vector<double> &d)
     g_eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     g_eig_calls += 1.0;
 }
+static inline double eig_hypot(double a, double b) { const double r = std::sqrt(a * a + b * b); return (r > 1e-150 && r < 1e150) ? r : std::hypot(a, b); }
 // Inner loops of the eigensolver, written over contiguous columns with restrict pointers and compiled twice
 // (baseline x86-64 and AVX2+FMA, chosen at run time) -- host code only.
 #define EIG_KERNELS(SFX, ATTR)                                                                                         \
@@ -270,16 +271,11 @@ static const EigOps &eig_ops()
     return has ? avx2 : base;
 }
 
-void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
+// Householder reduction to tridiagonal form (the first half of tred2), column-major access.  On return: the diagonal of T
+// is A(i,i), e[i] (i >= 1) couples i-1 and i, column i+1 rows 0..i hold the reflector u_{i+1} and d[i+1] its h = |u|^2/2
+// (0: no reflector), so that  Q = P_{n-1} ... P_1,  P_i = I - u_i u_i^T / h_i  on the leading i coordinates.
+static void eig_reduce(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op)
 {
-    const EigOps &op = eig_ops();
-    std::vector<double> e(n, 0.0);
-    d.assign(n, 0.0);
-    const bool eig_dbg = getenv("GEMHIP_EIG_DEBUG") != nullptr;
-    auto tnow = [] { return std::chrono::steady_clock::now(); };
-    auto tA = tnow();
-    // column-major accessor: every O(n^3) loop below runs over the FIRST index, i.e. contiguous memory
-    // (the input is symmetric, so its layout does not matter; the result is transposed back at the end)
     auto A = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
     auto col = [&](int j) -> double * { return V.data() + (size_t)j * n; };
     for (int j = 0; j < n; ++j) d[j] = A(n - 1, j);
@@ -322,6 +318,21 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
         }
         d[i] = h;
     }
+}
+
+void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
+{
+    const EigOps &op = eig_ops();
+    std::vector<double> e(n, 0.0);
+    d.assign(n, 0.0);
+    const bool eig_dbg = getenv("GEMHIP_EIG_DEBUG") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tA = tnow();
+    // column-major accessor: every O(n^3) loop below runs over the FIRST index, i.e. contiguous memory
+    // (the input is symmetric, so its layout does not matter; the result is transposed back at the end)
+    auto A = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
+    auto col = [&](int j) -> double * { return V.data() + (size_t)j * n; };
+    eig_reduce(n, V, d, e, op);
     auto tB = tnow();
     for (int i = 0; i < n - 1; ++i) {
         A(n - 1, i) = A(i, i);
@@ -370,7 +381,7 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
                     c3 = c2; c2 = c; s2 = s;
                     g = c * e[i];
                     h = c * p;
-                    r = std::hypot(p, e[i]);
+                    r = eig_hypot(p, e[i]);
                     e[i + 1] = s * r;
                     s = e[i] / r;
                     c = p / r;
@@ -398,6 +409,175 @@ void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
     }
     for (int i = 0; i < n; ++i)                              // back to row-major: V[i*n + j] = component i of eigenvector j
         for (int j = i + 1; j < n; ++j) std::swap(V[(size_t)i * n + j], V[(size_t)j * n + i]);
+}
+
+// Eigenvalues of the symmetric tridiagonal (diag a, a[i]~a[i+1] coupled by b[i]) by implicit QL without vectors: O(n^2).
+static void tridiag_eigenvalues(int n, std::vector<double> d, std::vector<double> e, std::vector<double> &w)
+{
+    // d: diagonal; e[i] couples i and i+1 (e[n-1] = 0), the layout tql2 above uses after its shift
+    e.resize(n, 0.0); e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = std::pow(2.0, -52.0);
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }
+        if (m > l) {
+            int iter = 0;
+            do {
+                ++iter;
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = eig_hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1 && iter < 200);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    std::sort(d.begin(), d.end());
+    w = d;
+}
+
+// The m LARGEST eigenpairs of a symmetric matrix: Householder reduction, eigenvalues of the tridiagonal by QL, the m
+// eigenvectors by inverse iteration (LU with partial pivoting of T - lambda I, close eigenvalues re-orthogonalised as one
+// cluster -- the scheme of LAPACK's dstein), then the reflectors applied to those m vectors only.  2/3 n^3 + O(n^2 m)
+// flops instead of the ~5 n^3 of the full solver: the Rayleigh-Ritz step of the Krylov solver only ever uses the leading
+// block of Ritz vectors.  A (n x n row-major symmetric) is destroyed; w: m eigenvalues DESCENDING; Z: column-major n x m.
+void sym_eig_top_impl(int n, std::vector<double> &V, int m, std::vector<double> &w, std::vector<double> &Z)
+{
+    const EigOps &op = eig_ops();
+    std::vector<double> d(n, 0.0), e(n, 0.0);
+    const bool eig_dbg = getenv("GEMHIP_EIG_DEBUG") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](auto x, auto y) { return std::chrono::duration<double>(y - x).count() * 1e3; };
+    const auto tA = tnow();
+    eig_reduce(n, V, d, e, op);
+    const auto tB = tnow();
+    auto col = [&](int j) -> double * { return V.data() + (size_t)j * n; };
+    std::vector<double> a(n), b(n, 0.0), hh(d);                      // T: diagonal a, b[i] couples i, i+1 ; hh[i] = h of reflector i
+    for (int i = 0; i < n; ++i) a[i] = V[(size_t)i * n + i];
+    for (int i = 0; i + 1 < n; ++i) b[i] = e[i + 1];
+    std::vector<double> all;
+    tridiag_eigenvalues(n, a, b, all);                                // ascending
+    const auto tC = tnow();
+    double norm = 0.0;
+    for (int i = 0; i < n; ++i) norm = std::max(norm, std::fabs(a[i]) + (i ? std::fabs(b[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(b[i]) : 0.0));
+    const double eps = std::pow(2.0, -52.0);
+    const double tiny = std::max(eps * norm, 1e-300), ortol = 1e-3 * norm, pert = 10.0 * eps * norm;
+    w.assign(m, 0.0);
+    Z.assign((size_t)n * m, 0.0);
+    std::vector<double> p(n), q(n), r(n), mult(n), x(n);
+    std::vector<char> swp(n);
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)((rng >> 11) & 0xFFFFFFFFFFFFFull) / 4503599627370496.0 * 2.0 - 1.0; };
+    double prev_shift = 0.0;
+    int cluster0 = 0;
+    for (int j = 0; j < m; ++j) {
+        const double lam_true = all[n - 1 - j];
+        w[j] = lam_true;
+        double lam = lam_true;
+        if (j > 0 && prev_shift - lam < pert) lam = prev_shift - pert;               // identical shifts would give identical vectors
+        if (j == 0 || all[n - j] - lam_true > ortol) cluster0 = j;                    // gap to the previous eigenvalue opens a new cluster
+        prev_shift = lam;
+        // LU of T - lam I with row interchanges: row i becomes [p, q, r], multiplier mult[i] applied to the row below
+        double u = a[0] - lam, v = n > 1 ? b[0] : 0.0;
+        for (int i = 0; i + 1 < n; ++i) {
+            const double sub = b[i], nd = a[i + 1] - lam, nsup = i + 2 < n ? b[i + 1] : 0.0;
+            if (std::fabs(sub) > std::fabs(u)) {
+                swp[i] = 1; mult[i] = u / sub; p[i] = sub; q[i] = nd; r[i] = nsup;
+                u = v - mult[i] * nd; v = -mult[i] * nsup;
+            } else {
+                if (u == 0.0) u = tiny;
+                swp[i] = 0; mult[i] = sub / u; p[i] = u; q[i] = v; r[i] = 0.0;
+                u = nd - mult[i] * v; v = nsup;
+            }
+        }
+        p[n - 1] = u; q[n - 1] = 0.0; r[n - 1] = 0.0;
+        for (int i = 0; i < n; ++i) { if (std::fabs(p[i]) < tiny) p[i] = p[i] < 0 ? -tiny : tiny; p[i] = 1.0 / p[i]; }
+        for (int i = 0; i < n; ++i) x[i] = rnd();
+        double *zj = Z.data() + (size_t)j * n;
+        for (int it = 0; it < 5; ++it) {
+            for (int i = 0; i + 1 < n; ++i) {                                         // forward: the recorded row operations
+                if (swp[i]) { const double t = x[i]; x[i] = x[i + 1]; x[i + 1] = t - mult[i] * x[i]; }
+                else x[i + 1] -= mult[i] * x[i];
+            }
+            for (int i = n - 1; i >= 0; --i) {                                        // back substitution, two super-diagonals
+                double t = x[i];
+                if (i + 1 < n) t -= q[i] * x[i + 1];
+                if (i + 2 < n) t -= r[i] * x[i + 2];
+                x[i] = t * p[i];
+            }
+            double big = 0.0;
+            for (int i = 0; i < n; ++i) big = std::max(big, std::fabs(x[i]));
+            if (!(big > 0.0) || !std::isfinite(big)) { for (int i = 0; i < n; ++i) x[i] = rnd(); continue; }
+            for (int i = 0; i < n; ++i) x[i] /= big;                                  // keeps the next products in range
+            for (int c = cluster0; c < j; ++c) {                                      // modified Gram-Schmidt inside the cluster
+                const double *zc = Z.data() + (size_t)c * n;
+                op.axpy(x.data(), -op.dot(zc, x.data(), n), zc, n);
+            }
+            const double nrm = std::sqrt(op.dot(x.data(), x.data(), n));
+            if (!(nrm > 1e-8)) { for (int i = 0; i < n; ++i) x[i] = rnd(); continue; }   // fell into the span of the cluster: restart
+            for (int i = 0; i < n; ++i) x[i] /= nrm;
+            if (it >= 2 && big > 0.0) { /* three solves from a random start: converged to working precision */ if (it >= 2) break; }
+        }
+        std::copy(x.begin(), x.end(), zj);
+    }
+    const auto tD = tnow();
+    // eigenvectors of A = Q z :  apply P_1, ..., P_{n-1} in that order (P_{i+1} acts on coordinates 0..i)
+    for (int j = 0; j < m; ++j) {
+        double *zj = Z.data() + (size_t)j * n;
+        for (int i = 0; i + 1 < n; ++i) {
+            const double h = hh[i + 1];
+            if (h != 0.0) op.axpy(zj, -op.dot(col(i + 1), zj, i + 1) / h, col(i + 1), i + 1);
+        }
+    }
+    if (eig_dbg) fprintf(stderr, "[eig-top] n=%d m=%d reduce %.2f ms  eigenvalues %.2f ms  inverse iteration %.2f ms  back-transform %.2f ms\n", n, m,
+                         tms(tA, tB), tms(tB, tC), tms(tC, tD), tms(tD, tnow()));
+}
+
+// Top-m eigenpairs for the Rayleigh-Ritz step (w descending, Z column-major n x m); small or nearly-full requests and a
+// host-supplied solver go through the full decomposition.
+void sym_eig_top(int n, std::vector<double> &G, int m, std::vector<double> &w, std::vector<double> &Z)
+{
+    static const bool no_partial = getenv("GEMHIP_EIG_FULL") != nullptr;
+    if (g_eig_cb || no_partial || n < 96 || 2 * m > n) {
+        std::vector<double> ev;
+        sym_eig(n, G, ev);
+        w.assign(m, 0.0); Z.assign((size_t)n * m, 0.0);
+        for (int j = 0; j < m; ++j) {
+            w[j] = ev[n - 1 - j];
+            for (int i = 0; i < n; ++i) Z[(size_t)j * n + i] = G[(size_t)i * n + (n - 1 - j)];
+        }
+        return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    sym_eig_top_impl(n, G, m, w, Z);
+    g_eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_eig_calls += 1.0;
 }
 
 // ---------------------------------------------------------------------- solver state
@@ -620,8 +800,11 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
                       int terms, double br, int out_mode, float *U_sqrtS, float *V_sqrtS, float *sigma, double *stats)
 {
     const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
+    // basis capacity: (krylov_steps + 1) blocks for the first cycles, 20 % more for the deeper polynomial of the locked phase
+    // (fewer cycles and SpMMs against a dearer projected eigenproblem: measured optimum, scripts/hope_basis_sweep.sh)
     int64_t basis_cols = (int64_t)b * (krylov_steps + 1);
-    if (const char *e = getenv("GEMHIP_HOPE_BASIS_COLS")) basis_cols = std::max<int64_t>(basis_cols, atoi(e));
+    basis_cols += basis_cols / 5;
+    if (const char *e = getenv("GEMHIP_HOPE_BASIS_COLS")) basis_cols = std::max<int64_t>((int64_t)b * (krylov_steps + 1), atoi(e));
     const int mmax = (int)std::min<int64_t>(std::min<int64_t>(basis_cols, n), 512);
     GEMHIP_REQUIRE(b <= 512 && k <= mmax, "hope: k + oversample = %d too large (max 512)", b);
     const int ldm = (mmax + 31) / 32 * 32, ldb = (b + 31) / 32 * 32;
@@ -642,7 +825,8 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
     // below lock_tol is frozen -- columns [0, nl) of Vall / Ball hold the locked right vectors and S v.  Later cycles only
     // orthogonalise against them: the Krylov blocks, the S applications and the projected eigenproblem shrink with every
     // lock.  (|sigma error| / sigma ~ residual^2 * sigma^2 / gap, so sqrt(tol)/10 keeps locked values inside `tol`.)
-    std::vector<double> sig_old(k, 0.0), sig(k, 0.0), Wv, ev, lock_sig, act_sig;
+    std::vector<double> sig_old(k, 0.0), sig(k, 0.0), Wv, ev, Zt, lock_sig, act_sig;   // ev: Ritz values DESCENDING, Zt: their vectors (column-major ma x mt)
+    int mt = 0;
     int mc = 0, restarts_done = 0, nl = 0, ma = 0;
     bool v0_is_ritz = false;
     const bool locking = getenv("GEMHIP_HOPE_NO_LOCK") == nullptr;
@@ -726,11 +910,12 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
         ma = mc - nl;
         gram(H, Ball + nl, ldm, ma, Ball + nl, ldm, ma, Wv);
         if (H.err) break;
-        sym_eig(ma, Wv, ev);
+        mt = std::min(ma, b);                                       // restart block and output never use more than b Ritz pairs
+        sym_eig_top(ma, Wv, mt, ev, Zt);
         GEMHIP_REQUIRE(mc >= k || (cleanup(), false), "hope: Krylov space collapsed to %d < k=%d columns (rank-deficient S?)", mc, k);
         {
             std::vector<double> all(lock_sig);
-            for (int j = 0; j < std::min(ma, k); ++j) all.push_back(std::sqrt(std::max(ev[ma - 1 - j], 0.0)));
+            for (int j = 0; j < std::min(mt, k); ++j) all.push_back(std::sqrt(std::max(ev[j], 0.0)));
             std::sort(all.begin(), all.end(), std::greater<double>());
             for (int j = 0; j < k; ++j) sig[j] = all[j];                                           // descending
         }
@@ -744,16 +929,16 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
         const bool done = exact || (rs > 0 && last_change < tol) || rs == max_restarts;
         if (done) break;
         // restart from the best right Ritz vectors of the active part:  V0 <- Vall[:, nl:] Wv[:, top]
-        const int nb = std::min(ma, std::max(b - nl, b_min));
+        const int nb = std::min(mt, std::max(b - nl, b_min));
         std::vector<double> C((size_t)ma * nb);
         for (int i = 0; i < ma; ++i)
-            for (int j = 0; j < nb; ++j) C[(size_t)i * nb + j] = Wv[(size_t)i * ma + (ma - 1 - j)];
+            for (int j = 0; j < nb; ++j) C[(size_t)i * nb + j] = Zt[(size_t)j * ma + i];
         tsgemm(H, Vall + nl, ldm, ma, C, nb, 1.0f, nullptr, 0, Tmp, ldm);
         HOPE_TRY(H, hipMemcpy2DAsync(Vall + nl, (size_t)ldm * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)nb * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
         bool remixed = false;
         m0 = orth(H, Vall + nl, ldm, nb, Tmp, ldm, 1e-10, 0.0, 2, &remixed);
         act_sig.assign(nb, 0.0);
-        for (int j = 0; j < nb; ++j) act_sig[j] = std::sqrt(std::max(ev[ma - 1 - j], 0.0));
+        for (int j = 0; j < nb; ++j) act_sig[j] = std::sqrt(std::max(ev[j], 0.0));
         v0_is_ritz = !remixed && m0 == nb;
     }
     if (!H.err) {
@@ -762,7 +947,7 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
         struct Cand { double s; int locked; int idx; };
         std::vector<Cand> cand;
         for (int l = 0; l < nl; ++l) cand.push_back({lock_sig[l], 1, l});
-        for (int j = 0; j < std::min(ma, k); ++j) cand.push_back({std::sqrt(std::max(ev[ma - 1 - j], 0.0)), 0, ma - 1 - j});
+        for (int j = 0; j < std::min(mt, k); ++j) cand.push_back({std::sqrt(std::max(ev[j], 0.0)), 0, j});
         std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.s > y.s; });
         std::vector<double> Cu((size_t)mc * k, 0.0), Cv((size_t)mc * k, 0.0);
         for (int r = 0; r < k; ++r) {
@@ -773,7 +958,7 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
             if (cand[r].locked) { Cu[(size_t)cand[r].idx * k + j] = su; Cv[(size_t)cand[r].idx * k + j] = sv; }
             else
                 for (int i = 0; i < ma; ++i) {
-                    const double wv = Wv[(size_t)i * ma + cand[r].idx];
+                    const double wv = Zt[(size_t)cand[r].idx * ma + i];
                     Cu[(size_t)(nl + i) * k + j] = wv * su; Cv[(size_t)(nl + i) * k + j] = wv * sv;
                 }
         }
@@ -1056,6 +1241,16 @@ extern "C" int gemhip_sym_eig_builtin(int32_t n, double *A_inout, double *w_out)
     sym_eig_impl(n, V, w);
     std::copy(V.begin(), V.end(), A_inout);
     std::copy(w.begin(), w.end(), w_out);
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sym_eig_top(int32_t n, double *A_inout, int32_t m, double *w_out, double *Z_out)
+{
+    GEMHIP_REQUIRE(n >= 1 && m >= 1 && m <= n && A_inout && w_out && Z_out, "sym_eig_top: bad arguments");
+    std::vector<double> V(A_inout, A_inout + (size_t)n * n), w, Z;
+    sym_eig_top_impl(n, V, m, w, Z);
+    std::copy(w.begin(), w.end(), w_out);
+    std::copy(Z.begin(), Z.end(), Z_out);
     return GEMHIP_OK;
 }
 

@@ -260,6 +260,10 @@ int gemhip_lle(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *co
  *   tsgemm  : Out[n][b2] = (Src or 0) + alpha * X[n][m] C[m][b2]   (C given in fp64, MFMA fp32). */
 int gemhip_sym_eig(int32_t n, double *A_inout, double *w_out);
 int gemhip_sym_eig_builtin(int32_t n, double *A_inout, double *w_out);
+/* The m largest eigenpairs only (what the Rayleigh-Ritz step consumes): Householder reduction, QL eigenvalues, inverse
+ * iteration, back-transformation of m vectors.  A destroyed; w_out: m eigenvalues DESCENDING; Z_out: m eigenvectors,
+ * one after the other (n doubles each).  Host code, callable without a GPU. */
+int gemhip_sym_eig_top(int32_t n, double *A_inout, int32_t m, double *w_out, double *Z_out);
 /* Optional: let the host supply a faster symmetric eigensolver for the projected problems (same contract as
  * gemhip_sym_eig: row-major symmetric A overwritten by eigenvectors in columns, w ascending, return 0).  The Python
  * layer registers numpy's LAPACK (dsyevd) here; NULL restores the built-in Householder/QL solver. */
