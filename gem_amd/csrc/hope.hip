@@ -133,13 +133,14 @@ __global__ void hope_reduce1_kernel(const float *__restrict__ P, int nslabs, int
     for (int k = c; k < nslabs; k += C) s += (double)P[k * stride + (int64_t)i * m2p + j];
     part[(int64_t)c * m1 * m2 + idx] = s;
 }
-__global__ void hope_reduce2_kernel(const double *__restrict__ part, int C, int total, double *__restrict__ G)
+__global__ void hope_reduce2_kernel(const double *__restrict__ part, int C, int total, double *__restrict__ G, float *__restrict__ Gf)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     double s = 0.0;
     for (int c = 0; c < C; ++c) s += part[(int64_t)c * total + idx];
     G[idx] = s;
+    if (Gf) Gf[idx] = (float)s;                          // the rounding tsgemm() applies to host coefficients
 }
 
 // ------------------------------------------- tall-skinny GEMM  O = Src + alpha X C  (MFMA fp32)
@@ -619,9 +620,9 @@ void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const f
 }
 
 // G (host, fp64, m1 x m2 row-major) = X[:, :m1]^T Y[:, :m2]
-void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int m2, std::vector<double> &Gh)
+// device part: H.G (fp64, m1 x m2 row-major) = X^T Y ; optionally the same values rounded to fp32 into Gf (device)
+static void gram_launch(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int m2, float *Gf)
 {
-    Gh.assign((size_t)m1 * m2, 0.0);
     if (H.err || m1 == 0 || m2 == 0) return;
     const int t1 = (m1 + 31) / 32, t2 = (m2 + 31) / 32, m1p = t1 * 32, m2p = t2 * 32;
     const int ntiles_ = t1 * t2;
@@ -641,7 +642,15 @@ void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int
     if ((size_t)Cr * m1 * m2 > H.Gpart_elems) { hipFree(H.Gpart); H.Gpart = nullptr; H.Gpart_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.Gpart, (size_t)Cr * m1 * m2 * sizeof(double))); if (!H.err) H.Gpart_elems = (size_t)Cr * m1 * m2; }
     if (H.err) return;
     hipLaunchKernelGGL(hope_reduce1_kernel, dim3((m1 * m2 + 255) / 256, Cr), dim3(256), 0, H.s, H.P, nslabs, (int64_t)m1p * m2p, m1, m2, m2p, Cr, H.Gpart);
-    hipLaunchKernelGGL(hope_reduce2_kernel, dim3((m1 * m2 + 255) / 256), dim3(256), 0, H.s, H.Gpart, Cr, m1 * m2, H.G);
+    hipLaunchKernelGGL(hope_reduce2_kernel, dim3((m1 * m2 + 255) / 256), dim3(256), 0, H.s, H.Gpart, Cr, m1 * m2, H.G, Gf);
+}
+
+void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int m2, std::vector<double> &Gh)
+{
+    Gh.assign((size_t)m1 * m2, 0.0);
+    if (H.err || m1 == 0 || m2 == 0) return;
+    gram_launch(H, X, ldx, m1, Y, ldy, m2, nullptr);
+    if (H.err) return;
     HOPE_TRY(H, hipMemcpyAsync(Gh.data(), H.G, (size_t)m1 * m2 * sizeof(double), hipMemcpyDeviceToHost, H.s));
     HOPE_TRY(H, hipStreamSynchronize(H.s));
 }
@@ -660,6 +669,22 @@ void tsgemm(Hope &H, const float *X, int ldx, int m, const std::vector<double> &
     const int64_t tiles = ((H.n + 31) / 32) * ct;
     hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, H.Csmall, b2, b2, alpha, Src, lds_, Out,
                        ldo, ct);
+}
+
+// W[:, :cols] -= V[:, :m] (V[:, :m]^T W[:, :cols]) with the coefficients kept in HBM: Gram, fp64 slab reduction, fp32 rounding and
+// the tall-skinny GEMM are four back-to-back launches, no host round trip (same arithmetic as gram() + tsgemm()).
+void project_out(Hope &H, const float *V, int ldv, int m, float *W, int ldw, int cols)
+{
+    if (H.err || m == 0 || cols == 0) return;
+    const size_t need = (size_t)m * cols;
+    if (need > H.C_elems) { HOPE_TRY(H, hipStreamSynchronize(H.s)); hipFree(H.Csmall); H.Csmall = nullptr; H.C_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.Csmall, need * sizeof(float))); if (!H.err) H.C_elems = need; }
+    if (H.err) return;
+    gram_launch(H, V, ldv, m, W, ldw, cols, H.Csmall);
+    if (H.err) return;
+    const int ct = (cols + 31) / 32;
+    const int64_t tiles = ((H.n + 31) / 32) * ct;
+    hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, V, ldv, m, H.Csmall, cols, cols, -1.0f, W, ldw, W,
+                       ldw, ct);
 }
 
 // Upper-triangular Cholesky G = R^T R in fp64 with a pivot floor; on success C = R^-1 (so that (Y C)^T (Y C) = I).
@@ -865,7 +890,9 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
             // span(Vall); after normalisation that noise is O(eps / amplitude)
             float *Wp = W0;                                         // the part of the new block that is kept
             int wcols = prev_b;
+            static const bool host_project = getenv("GEMHIP_HOPE_HOST_PROJECT") != nullptr;
             auto project = [&](int cols) {
+                if (!host_project) { project_out(H, Vall, ldm, mc, Wp, ldb, cols); return; }
                 std::vector<double> C;
                 gram(H, Vall, ldm, mc, Wp, ldb, cols, C);
                 tsgemm(H, Vall, ldm, mc, C, cols, -1.0f, Wp, ldb, Wp, ldb);
@@ -963,18 +990,26 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
                 }
         }
         if (U_sqrtS) {
-            tsgemm(H, Ball, ldm, mc, Cu, k, 1.0f, nullptr, 0, Tmp, ldm);
-            HOPE_TRY(H, hipMemcpy2D(U_sqrtS, (size_t)k * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)k * sizeof(float), n, hipMemcpyDeviceToHost));
+            tsgemm(H, Ball, ldm, mc, Cu, k, 1.0f, nullptr, 0, Tmp, k);           // compact [n][k]: one contiguous download
+            HOPE_TRY(H, hipMemcpy(U_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
         }
-        tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, ldm);
-        HOPE_TRY(H, hipMemcpy2D(V_sqrtS, (size_t)k * sizeof(float), Tmp, (size_t)ldm * sizeof(float), (size_t)k * sizeof(float), n, hipMemcpyDeviceToHost));
-        // deterministic sign: largest-magnitude entry of each left vector positive (svds signs are arbitrary)
-        for (int j = 0; j < k; ++j) {
+        tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, k);
+        HOPE_TRY(H, hipMemcpy(V_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
+        // deterministic sign: largest-magnitude entry of each left vector positive (svds signs are arbitrary).  One
+        // row-major pass for the k arg-maxima and one for the flips (the tables are n x k, 25 MB each at 100k x 64).
+        {
             const float *ref = U_sqrtS ? U_sqrtS : V_sqrtS;
-            int64_t arg = 0; float best = 0.f;
-            for (int64_t i = 0; i < n; ++i) { const float a = std::fabs(ref[i * k + j]); if (a > best) { best = a; arg = i; } }
-            if (ref[arg * k + j] < 0.f)
-                for (int64_t i = 0; i < n; ++i) { if (U_sqrtS) U_sqrtS[i * k + j] = -U_sqrtS[i * k + j]; V_sqrtS[i * k + j] = -V_sqrtS[i * k + j]; }
+            std::vector<float> best(k, 0.f), val(k, 0.f);
+            for (int64_t i = 0; i < n; ++i) {
+                const float *row = ref + i * k;
+                for (int j = 0; j < k; ++j) { const float a = std::fabs(row[j]); if (a > best[j]) { best[j] = a; val[j] = row[j]; } }
+            }
+            bool any = false;
+            std::vector<float> sgn(k, 1.f);
+            for (int j = 0; j < k; ++j) if (val[j] < 0.f) { sgn[j] = -1.f; any = true; }
+            if (any)
+                for (int64_t i = 0; i < n; ++i)
+                    for (int j = 0; j < k; ++j) { if (U_sqrtS) U_sqrtS[i * k + j] *= sgn[j]; V_sqrtS[i * k + j] *= sgn[j]; }
         }
     }
     float ms = 0.f;
