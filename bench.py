@@ -91,12 +91,16 @@ class GFWorkload(object):
         Xb = Xa.clone()
         r0, r1 = rank * (n_pad // world), min((rank + 1) * (n_pad // world), n)
         self.b = multi_gpu.HipBackendGF(n, src, dst, None, self.d, r0, r1, Xa, Xb)
-        self.job = multi_gpu.GFSharded(self.b, comm, rank, world, n)
+        self.job = multi_gpu.GFSharded(self.b, comm, rank, world, n, src, dst)       # N>1: halo exchange per sweep, one gather at the end
         self.kernel_ms, self.launches = 0.0, 0
         log('[rank %d] GF plan: rows %d updates %d levels %d' % (rank, self.b.rows, self.b.updates, self.b.levels))
 
     def step(self):
         self.last = self.job.sweep(self.eta, self.regu)
+
+    def finish(self):
+        """End of a training run (inside the timed region): every rank assembles the full table."""
+        self.last = self.job.gather(self.last)
 
     def units_per_step(self):
         return self.n_edges
@@ -358,6 +362,8 @@ def main():
 
     for _ in range(W):
         wl.step()
+    if W and hasattr(wl, 'finish'):
+        wl.finish()
     barrier()
     if hasattr(wl, 'reset_counters'):
         wl.reset_counters()
@@ -366,6 +372,8 @@ def main():
     ev0.record()
     for _ in range(K):
         wl.step()
+    if hasattr(wl, 'finish'):
+        wl.finish()
     ev1.record()
     barrier()
     el = time.perf_counter() - t0

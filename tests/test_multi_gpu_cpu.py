@@ -87,6 +87,20 @@ def _worker(rank, world, port, out):
         last = job.sweep(0.05, 0.01)
     ref = oracle.gf_train_f32(n, src, dst, None, 8, 0.05, 0.01, 3, X0)
     ok_gf = bool(np.array_equal(last.numpy()[:n], ref))
+    # ---- the same with the halo exchange (only the remote rows my firing edges read travel per sweep) + one final gather
+    job = multi_gpu.GFSharded(None, comm, rank, world, n, src, dst)
+    job.b = OracleGF(n, src, dst, 8, job.r0, job.r1, X0p)
+    for _ in range(3):
+        last = job.sweep(0.05, 0.01)
+    halo_used = bool(job.halo)
+    halo_small = 0 < job.halo_rows[0] < 0.75 * job.block and job.halo_rows[world - 1] == 0   # dst > src: the last rank reads nobody
+    ok_gf = ok_gf and halo_used and halo_small and bool(np.array_equal(job.gather(last).numpy()[:n], ref))
+    # a graph without locality falls back to the all-gather
+    rs = np.random.RandomState(1); s2 = np.sort(rs.randint(0, n, 20000)).astype(np.int32); d2 = rs.randint(0, n, 20000).astype(np.int32)   # rows visited in ascending order
+    job = multi_gpu.GFSharded(None, comm, rank, world, n, s2, d2)
+    job.b = OracleGF(n, s2, d2, 8, job.r0, job.r1, X0p)
+    last = job.sweep(0.05, 0.01)
+    ok_gf = ok_gf and job.halo is False and bool(np.array_equal(last.numpy()[:n], oracle.gf_train_f32(n, s2, d2, None, 8, 0.05, 0.01, 1, X0)))
     # ---- node2vec: counts all-reduce, identical tables on all ranks, quality preserved
     G = load_sbm1024()
     n, src, dst, w, _ = edge_arrays(G)
