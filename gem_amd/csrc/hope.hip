@@ -1067,7 +1067,7 @@ static int hope_setup(gemhip_hope_plan &P, int64_t n, int64_t nnz, const int64_t
         for (int64_t i = 0; i < n; ++i) cs_max = std::max(cs_max, cs[i]);
     }
     double rho = 0.0;
-    {   // power iteration on A^T A (host, 40 steps): sigma_max(A) >= rho(A); converges from below, hence the margin
+    {   // power iteration on A^T A (host, at most 40 steps): sigma_max(A) >= rho(A); converges from below, hence the margin
         std::vector<double> x(n), y(n), z(n);
         for (int64_t i = 0; i < n; ++i) x[i] = 1.0 + 0.37 * std::sin(12.9898 * (double)(i + 1));
         for (int it = 0; it < 40; ++it) {
@@ -1082,9 +1082,11 @@ static int hope_setup(gemhip_hope_plan &P, int64_t n, int64_t nnz, const int64_t
             double nx = 0.0, nz = 0.0;
             for (int64_t i = 0; i < n; ++i) { nx += x[i] * x[i]; nz += z[i] * z[i]; }
             if (nz == 0.0 || nx == 0.0) break;
+            const double prev = rho;
             rho = std::sqrt(std::sqrt(nz / nx));
             const double inv = 1.0 / std::sqrt(nz);
             for (int64_t i = 0; i < n; ++i) x[i] = z[i] * inv;
+            if (it >= 4 && std::fabs(rho - prev) <= 1e-3 * rho) break;        // the 10 % margin below covers the rest
         }
         rho = std::min(std::max(rho * 1.1, 1e-30), std::sqrt(rs_max * cs_max));
     }
