@@ -31,6 +31,55 @@ def test_ctypes_binding_covers_the_header():
     assert _hip.lib().gemhip_version() == 100
 
 
+def header_prototypes():
+    """name -> list of C parameter type strings, parsed from include/gem_hip.h."""
+    txt = open(os.path.join(ROOT, 'include', 'gem_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(?:int|const char \*)\s*(gemhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', txt, flags=re.S):
+        params = ' '.join(m.group(2).split())
+        if re.match(r'int \(\*\w+\)\(', params):                 # one parameter that is a function pointer
+            out[m.group(1)] = ['fnptr']
+            continue
+        plist = [] if params in ('', 'void') else [q.strip() for q in params.split(',')]
+        out[m.group(1)] = plist
+    return out
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Arity and the pointer / integer / float class of every parameter: an ABI drift between include/gem_hip.h and the
+    ctypes table would corrupt arguments silently."""
+    protos = header_prototypes()
+    assert sorted(protos) == header_symbols()
+
+    def klass_c(t):
+        if t == 'fnptr' or '*' in t or re.search(r'\bgemhip_\w+_t\b', t):
+            return 'ptr'
+        if re.match(r'(const )?(float)\b', t):
+            return 'f32'
+        if re.match(r'(const )?(double)\b', t):
+            return 'f64'
+        m = re.match(r'(const )?(u?int(32|64)_t|int)\b', t)
+        assert m, t
+        return {'int': 'i32', 'int32_t': 'i32', 'uint32_t': 'i32', 'int64_t': 'i64', 'uint64_t': 'i64'}[m.group(2)]
+
+    def klass_py(a):
+        if a in (ctypes.c_float,):
+            return 'f32'
+        if a in (ctypes.c_double,):
+            return 'f64'
+        if a in (ctypes.c_int, ctypes.c_int32, ctypes.c_uint32):
+            return 'i32'
+        if a in (ctypes.c_int64, ctypes.c_uint64):
+            return 'i64'
+        return 'ptr'
+
+    for name, (res, args) in _hip._SIGS.items():
+        want = [klass_c(t) for t in protos[name]]
+        got = [klass_py(a) for a in args]
+        assert got == want, '%s: header %s vs ctypes %s' % (name, want, got)
+
+
 def test_no_silent_fallback_without_gpu():
     """On a machine without a HIP device the product path must fail loudly."""
     import numpy as np
