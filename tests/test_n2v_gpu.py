@@ -211,6 +211,42 @@ def test_baseline_scale_properties():
     dev.close()
 
 
+def test_baseline_full_size_properties():
+    """BASELINE configs[3] at FULL size (SBM 1M nodes / 10M edges, l=80, k=10, d=128; one walk round instead of ten):
+    size-independent properties -- every hop is an edge, each present node starts exactly one walk per round, the
+    vocabulary conserves tokens, a walk shard is the slice of the full run, and one SGNS pass leaves a finite, bounded
+    table; then the drop-in call at the full configuration reaches the reconstruction MAP bench.py reports."""
+    g = sbm_graph(1000000, 10000000, 100, seed=20260927)
+    n, src, dst, w, _ = edge_arrays(g)
+    dev = Dev(n, src, dst, w)
+    walks = dev.walks(1.0, 1.0, 1, 80, 11, SNAP)
+    deg = np.bincount(src, minlength=n) + np.bincount(dst, minlength=n)
+    starts = np.flatnonzero(deg > 0)
+    assert walks.shape == (len(starts), 80) and walks.min() >= 0 and walks.max() < n
+    assert np.array_equal(np.sort(walks[:, 0]), starts)
+    keys = np.sort(src.astype(np.int64) * n + dst)
+    sel = walks[::499].astype(np.int64)
+    hop = (sel[:, :-1] * n + sel[:, 1:]).ravel()
+    pos = np.searchsorted(keys, hop)
+    assert np.all(keys[np.minimum(pos, len(keys) - 1)] == hop)              # every hop is an edge (the SBM has no sinks)
+    c, UT, KT = dev.unigram()
+    assert int(c.sum(dtype=np.int64)) == walks.size and np.array_equal(c, np.bincount(walks.ravel(), minlength=n))
+    part = dev.walks(1.0, 1.0, 1, 80, 11, SNAP, 700000, 700000 + 2048)
+    assert np.array_equal(part, walks[700000:700000 + 2048])
+    dev.walks(1.0, 1.0, 1, 80, 11, SNAP); dev.unigram()
+    P, N = dev.sgns(128, 10, 1, 11, SNAP)
+    assert np.isfinite(P).all() and np.isfinite(N).all() and 0.05 < np.abs(P).max() < 50
+    dev.close()
+    # the drop-in call itself at the BASELINE configuration (r=10): sampled reconstruction MAP (reference evaluator semantics)
+    from gem_amd.evaluation import reconstruction as gr
+    m = node2vec(d=128, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, seed=1)
+    Y = m.learn_embedding(graph=g, is_weighted=True, no_python=True)
+    assert Y.shape == (n, 128) and Y.dtype == np.float64 and np.isfinite(Y).all()
+    nodes = np.random.RandomState(0).choice(n, 128, replace=False)
+    MAP = float(gr.sampled_ap_gpu(g, m, Y, nodes).mean())
+    assert MAP > 0.4, MAP                              # 0.48-0.49 in every bench.py run; chance is ~1e-5
+
+
 def test_shared_negatives_opt_in_keeps_map(sbm1024):
     """GEMHIP_N2V_SHARED_NEGATIVES (flag 64) is NOT the reference's sampling; it must still land at the reference's quality."""
     ref = json.load(open(golden_path('n2v_ref.json')))
