@@ -215,8 +215,10 @@ int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs,
  * nx.to_numpy_matrix, whose index is insertion order).  Outputs, all caller-owned float32:
  *   U_sqrtS [n][k] = u * sqrt(s),  V_sqrtS [n][k] = vt.T * sqrt(s)   (hope.py:34-35; X = [U | V]),
  *   sigma [k] ASCENDING like svds (hope.py:33).  Column signs: largest |entry| of each u positive.
- * Solver knobs: oversample (block = k + oversample columns), krylov_steps (blocks per cycle),
- * max_restarts, tol (max relative change of the k singular values between cycles).
+ * Solver knobs: oversample (block = k + oversample columns), krylov_steps (Krylov blocks per cycle until pairs
+ * start to lock; converged leading pairs are frozen and the freed basis columns -- capacity 1.2 * (krylov_steps + 1)
+ * blocks -- deepen the polynomial for the rest), max_restarts, tol (max relative change of the k singular values
+ * between cycles; pairs lock at a relative residual of 0.1 * sqrt(tol)).
  * stats (optional, 12 doubles): {device_seconds, spmm_launches, spmm_columns_total, katz_terms,
  * basis_columns, restarts_done, last_sigma_change, beta*sigma_max(A) estimate, host_eig_seconds,
  * host_eig_calls, max relative Ritz residual of the previous cycle,
