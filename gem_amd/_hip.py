@@ -90,6 +90,7 @@ _SIGS = {
     'gemhip_sgns_train_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
                                           C.c_float, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p]),
     'gemhip_n2v_set_max_waves': (C.c_int, [C.c_void_p, C.c_int32]),
+    'gemhip_sgns_set_window_cache': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_sgns_set_tables': (C.c_int, [C.c_void_p, f32p, f32p]),
     'gemhip_sgns_get_tables': (C.c_int, [C.c_void_p, f32p, f32p]),
     'gemhip_sgns_train': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
@@ -166,6 +167,7 @@ def ptr(a, ctype):
 
 N2V_PAD_ZERO, N2V_UNIGRAM_QUIRK, N2V_DETERMINISTIC, N2V_UNIFORM_FIRST_HOP = 1, 2, 4, 8
 N2V_SNAP_COMPAT = 11
+N2V_NO_WINDOW_CACHE = 128       # A/B switch: round-1 SGNS kernel without the LDS window of context rows
 N2V_SHARED_NEGATIVES = 64      # opt-in fast mode, not the reference's sampling (include/gem_hip.h)
 
 

@@ -83,6 +83,9 @@ struct gemhip_n2v {
     float *SynPos = nullptr, *SynNeg = nullptr;
     bool own_syn = false;
     int32_t max_waves = 0;            // 0 = auto (see gemhip_sgns_train)
+    int32_t cache_radius = -1;        // sgns_win_kernel LDS window radius: -1 auto, 0 = off (sgns_kernel)
+    int32_t cache_delta = -1;         // -1 auto, 0 overwrite on leave, 1 delta write-back
+    float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
     // per-partition unigram tables (multi-GPU episode schedule): partition p = {v : v % parts == p}, local index v / parts
     int32_t parts = 0;
@@ -294,6 +297,8 @@ struct SgnsArgs {
     float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
     const float *UT; const int32_t *KT; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
     float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs;
+    float *dummy;               // sgns_win_kernel: nwaves rows, never read for their value
+    int32_t cache_radius;       // sgns_win_kernel: tokens within this many positions of the centre keep their SynPos row in LDS
 };
 
 // gradient scale of TrainModel: (label - sigma(f)) * alpha with the +-MaxExp clamps
@@ -455,6 +460,372 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
     if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
 }
 
+// ---- window-cached TrainModel (default since round 2) ------------------------------------------------------------
+// Same arithmetic, same order and same Philox draws as sgns_kernel; what changes is WHERE the context rows live.
+// A token is a context of every centre within `window` positions, so sgns_kernel moves its SynPos row 2 x ~11 times.
+// Here one wavefront (= one 64-thread block = one walk at a time) keeps the rows of the tokens within `R` positions
+// of the centre in LDS: a token's row is read once when it enters the window and written once when it leaves
+// (2R+1 slots; repeated nodes share a slot through a (node -> slot) directory held across the lanes, so the sequence of
+// values every row takes inside one wavefront is exactly TrainModel's).  Contexts farther than R (only possible when
+// R < window) go straight to memory as before -- the directory lookup precedes every access, so cached and direct
+// accesses never alias.
+// Hogwild: other wavefronts may update a cached row while it sits in LDS.  DELTA mode (multi-wave launches) keeps the
+// row as loaded next to the working copy and leaves with `row_now + (working - loaded)`: nothing another wavefront
+// wrote in between is lost (the read-modify-write window is one centre step, as short as sgns_kernel's per-pair
+// windows); a single-wave (deterministic) launch writes the working copy back as is.
+// Latency at 1 wave per SIMD-ish occupancy (the LDS window bounds residency at ~7-13 waves per CU): the negative rows of
+// the next TWO (centre, context) pairs are in flight while a pair is computed (targets equal to a row updated in
+// between are re-forwarded from registers: exact), and the negative targets are drawn two centres ahead.
+template <int VEC, int NV>
+struct NegSet {
+    int32_t tv;                 // lanes 0..4: the five targets (lane form, for the any-match test)
+    int32_t tgt[SGNS_NEG];
+    float y[SGNS_NEG][NV][VEC]; // their SynNeg rows (in flight, then updated in place)
+};
+
+// FULL: d == NV * VEC * 64, rows need no tail guard.  ALLC: R >= window, every context row is in the LDS window.
+// With both, the pair loop has a STATIC number of memory operations per pair (skipped targets and exhausted prefetch slots
+// go to a per-wave dummy row instead of branching), which is what lets the compiler keep two pairs' rows in flight with
+// counted s_waitcnt vmcnt(N) instead of draining to vmcnt(0) at every control-flow merge.
+template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC>
+__global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    constexpr int RW = NV * VEC * WAVE;              // floats per cached row (row padded to the wave's footprint)
+    constexpr int NS = 2;                            // negative samples per lane and centre: 2*window*5 <= 128
+    const int lane = lane_id();
+    const int64_t gw = blockIdx.x;
+    if (gw >= A.nwaves) return;
+    const int d = A.d, win = A.window, len = A.walk_len, R = A.cache_radius, S = 2 * R + 1;
+    const int nsamp = 2 * win * SGNS_NEG;
+    const bool quirk = (A.flags & 2) != 0;
+    int32_t *tok = lds;
+    int32_t *negs = tok + len;                       // [2][nsamp]
+    float *rowsL = reinterpret_cast<float *>(lds + ((len + 2 * nsamp + 3) & ~3));
+    float *rowsO = rowsL + (size_t)(S + 1) * RW;     // DELTA only; slot S of rowsL stages a context row that is not cached
+
+    auto lds_ld = [&](const float *row, float (&v)[NV][VEC]) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[c][k] = row[(c * WAVE + lane) * VEC + k];
+    };
+    auto lds_st = [&](float *row, const float (&v)[NV][VEC]) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) row[(c * WAVE + lane) * VEC + k] = v[c][k];
+    };
+    const int dg = FULL ? NV * VEC * WAVE : d;       // guard bound of ld_row/st_row: a compile-time constant when FULL
+    auto g_ld = [&](const float *p, float (&v)[NV][VEC]) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) ld_row<VEC>(p, dg, lane, c, v[c]);
+    };
+    auto g_st = [&](float *p, const float (&v)[NV][VEC]) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) st_row<VEC>(p, dg, lane, c, v[c]);
+    };
+
+    float *dummy = A.dummy + (size_t)gw * RW;        // this wave's private sink / source for predicated-off row traffic
+    unsigned long long npairs = 0;
+    for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
+        const int32_t *walk = A.walks + wl * len;
+        for (int k = lane; k < len; k += WAVE) tok[k] = walk[k];
+        __builtin_amdgcn_wave_barrier();
+        const int64_t wid = A.walk_id_offset + wl;
+        const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
+
+        // slot directory: lane s < S describes slot s
+        int32_t slot_node = -1, slot_ref = 0;
+
+        // --- negative-target pipeline: stage A (table slot -> X) for centre p, stage B (UT[X], KT[X]), finalize -> LDS
+        int32_t XA[NS], XB[NS], KTv[NS]; float uA[NS], uB[NS], UTv[NS];
+        auto stage_a = [&](int p) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = lane + k * WAVE;
+                XA[k] = 0; uA[k] = 0.f;
+                if (p < len && s < nsamp) {
+                    const int ai = s / SGNS_NEG;
+                    const int a = ai < win ? ai : ai + 1;
+                    const int j = s - ai * SGNS_NEG + 1;
+                    const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p | ((uint32_t)a << 16),
+                                                   (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
+                    const uint32_t slot = mulhi_range(rn.x, A.n);
+                    XA[k] = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
+                    uA[k] = u01(rn.y);
+                }
+            }
+        };
+        auto stage_b = [&]() {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { XB[k] = XA[k]; uB[k] = uA[k]; UTv[k] = A.UT[XB[k]]; KTv[k] = A.KT[XB[k]]; }
+        };
+        auto stage_fin = [&](int p) {
+            int32_t *dst = negs + (p & 1) * nsamp;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = lane + k * WAVE;
+                if (s < nsamp) dst[s] = (uB[k] < UTv[k]) ? XB[k] : KTv[k];
+            }
+        };
+        stage_a(0); stage_b(); stage_fin(0);
+        stage_a(1);
+
+        // --- cache: enter token q (directory now, row through `rowE` -> LDS by the caller), leave token q
+        // rows of tokens 0 .. R-1 enter before the first centre
+        for (int q = 0; q < R && q < len; ++q) {
+            const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
+            if (v < 0) continue;
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
+            if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; continue; }
+            const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node < 0 && lane < S));
+            float r[NV][VEC];
+            g_ld(A.SynPos + (int64_t)v * d, r);
+            lds_st(rowsL + (size_t)s * RW, r);
+            if constexpr (DELTA) lds_st(rowsO + (size_t)s * RW, r);
+            if (lane == s) { slot_node = v; slot_ref = 1; }
+        }
+
+        for (int pos = 0; pos < len; ++pos) {
+            const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
+            // token pos+R enters
+            float rowE[NV][VEC]; int sE = -1;
+            if (pos + R < len) {
+                const int32_t v = __builtin_amdgcn_readfirstlane(tok[pos + R]);
+                if (v >= 0) {
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
+                    if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; }
+                    else {
+                        sE = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node < 0 && lane < S));
+                        g_ld(A.SynPos + (int64_t)v * d, rowE);
+                        if (lane == sE) { slot_node = v; slot_ref = 1; }
+                    }
+                }
+            }
+            // token pos-R leaves after this centre: when it is the last holder of its slot, fetch the row as it is NOW
+            float rowG[NV][VEC]; int sX = -1; int32_t vX = -1;
+            if (pos - R >= 0) {
+                vX = __builtin_amdgcn_readfirstlane(tok[pos - R]);
+                if (vX >= 0) {
+                    const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node == vX));
+                    const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
+                    if (lane == s) slot_ref = refc;
+                    if (refc == 0) {
+                        sX = s;
+                        if constexpr (DELTA) g_ld(A.SynPos + (int64_t)vX * d, rowG);
+                    }
+                }
+            }
+            // negatives: B for centre pos+1, A for centre pos+2
+            stage_b();
+            stage_a(pos + 2);
+
+            if (word >= 0) {
+                const int64_t t = A.token_offset + wl * len + pos;
+                const int64_t tq = t - (t % 10000);
+                float alpha = A.alpha0 * (1.0f - (float)((double)tq / (double)A.denom));
+                alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
+                const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
+                const int b = (int)(rw.x % (uint32_t)win);
+                const int32_t *ncur = negs + (pos & 1) * nsamp;
+
+                float yp[NV][VEC];
+                float *pp = A.SynNeg + (int64_t)word * d;
+                g_ld(pp, yp);
+
+                // the contexts of this centre, ascending (TrainModel's order): bit a <-> position pos - win + a
+                bool valid = false;
+                {
+                    const int a = lane, cp = pos - win + a;
+                    if (a >= b && a < 2 * win + 1 - b && a != win && cp >= 0 && cp < len) valid = tok[cp] >= 0;
+                }
+                unsigned long long m_proc = __builtin_amdgcn_ballot_w64(valid), m_iss = m_proc;
+                npairs += (unsigned long long)__builtin_popcountll(m_proc);
+
+                NegSet<VEC, NV> q0, q1, q2;          // three register sets rotate: processed now / next / the one after
+                auto issue = [&](NegSet<VEC, NV> &Q) __attribute__((always_inline)) {
+                    const bool live = m_iss != 0;                   // exhausted: the same five loads, from the dummy row
+                    const int a = live ? (int)__builtin_ctzll(m_iss) : 0;
+                    m_iss &= m_iss - 1;
+                    const int ai = a < win ? a : a - 1;
+                    Q.tv = ncur[ai * SGNS_NEG + (lane < SGNS_NEG ? lane : 0)];
+                    if (lane >= SGNS_NEG || !live) Q.tv = -1;
+#pragma unroll
+                    for (int j = 0; j < SGNS_NEG; ++j) {
+                        Q.tgt[j] = __builtin_amdgcn_readlane(Q.tv, j);
+                        g_ld(live ? A.SynNeg + (int64_t)Q.tgt[j] * d : dummy, Q.y[j]);
+                    }
+                };
+                issue(q0);
+                issue(q1);
+
+                if (sE >= 0) {               // the entering row has landed by now (requested before everything above)
+                    lds_st(rowsL + (size_t)sE * RW, rowE);
+                    if constexpr (DELTA) lds_st(rowsO + (size_t)sE * RW, rowE);
+                }
+
+                // one (centre, context) pair: C holds its negative rows, P1 the next pair's (in flight), P2 is free
+                auto step = [&](NegSet<VEC, NV> &C, NegSet<VEC, NV> &P1, NegSet<VEC, NV> &P2) __attribute__((always_inline)) {
+                    const int a = (int)__builtin_ctzll(m_proc);
+                    m_proc &= m_proc - 1;
+                    issue(P2);
+
+                    const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[pos - win + a]);
+                    const unsigned long long chit = __builtin_amdgcn_ballot_w64(slot_node == ctx);
+                    float *lrow = rowsL + (size_t)((ALLC || chit) ? (int)__builtin_ctzll(chit) : S) * RW;
+                    float *pc = A.SynPos + (int64_t)ctx * d;
+                    float xc[NV][VEC], neu[NV][VEC];
+                    if constexpr (!ALLC)
+                        if (!chit) {        // beyond the cached radius: stage through LDS so that the wait for this row stays inside the branch
+                            float t[NV][VEC];
+                            g_ld(pc, t);
+                            lds_st(lrow, t);
+                        }
+                    lds_ld(lrow, xc);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) neu[c][k] = 0.f;
+                    {   // positive target (label 1), row lives in registers
+                        float part = 0.f;
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) part += xc[c][k] * yp[c][k];
+                        const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) { neu[c][k] += g * yp[c][k]; yp[c][k] += g * xc[c][k]; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < SGNS_NEG; ++j) {
+                        const bool skip = C.tgt[j] == word || C.tgt[j] < 0;  // TrainModel: `if (Target == Word) continue` (predicated: g = 0, row -> dummy)
+#pragma unroll
+                        for (int jp = 0; jp < j; ++jp)                       // a target drawn twice sees the first update
+                            if (C.tgt[jp] == C.tgt[j]) {
+#pragma unroll
+                                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                    for (int k = 0; k < VEC; ++k) C.y[j][c][k] = C.y[jp][c][k];
+                            }
+                        float part = 0.f;
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) part += xc[c][k] * C.y[j][c][k];
+                        float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+                        g = skip ? 0.f : g;
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) { neu[c][k] += g * C.y[j][c][k]; C.y[j][c][k] += g * xc[c][k]; }
+                        g_st(skip ? dummy : A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) xc[c][k] += neu[c][k];
+                    if (ALLC || chit) lds_st(lrow, xc); else g_st(pc, xc);
+
+                    // P1/P2's rows were requested before the stores above: a target of theirs that was just updated
+                    // takes the updated row from registers (rare; keeps the exact sequential semantics)
+                    bool same = false;
+#pragma unroll
+                    for (int j = 0; j < SGNS_NEG; ++j)
+                        if (C.tgt[j] != word) same = same || P1.tv == C.tgt[j] || P2.tv == C.tgt[j];
+                    if (__builtin_amdgcn_ballot_w64(same)) {
+#pragma unroll
+                        for (int j = 0; j < SGNS_NEG; ++j) {
+                            if (C.tgt[j] == word) continue;
+#pragma unroll
+                            for (int jp = 0; jp < SGNS_NEG; ++jp) {
+                                if (P1.tgt[jp] == C.tgt[j]) {
+#pragma unroll
+                                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                        for (int k = 0; k < VEC; ++k) P1.y[jp][c][k] = C.y[j][c][k];
+                                }
+                                if (P2.tgt[jp] == C.tgt[j]) {
+#pragma unroll
+                                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                        for (int k = 0; k < VEC; ++k) P2.y[jp][c][k] = C.y[j][c][k];
+                                }
+                            }
+                        }
+                    }
+                };
+                while (true) {
+                    if (!m_proc) break;
+                    step(q0, q1, q2);
+                    if (!m_proc) break;
+                    step(q1, q2, q0);
+                    if (!m_proc) break;
+                    step(q2, q0, q1);
+                }
+                // the prefetch slots that were filled past the last pair are dead; "use" them so that the compiler's wait-count
+                // bookkeeping retires their loads here instead of carrying them into the next centre's loop header
+                auto retire = [&](NegSet<VEC, NV> &Q) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int j = 0; j < SGNS_NEG; ++j)
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(Q.y[j][c][k]));
+                };
+                retire(q0); retire(q1); retire(q2);
+                g_st(pp, yp);
+            } else if (sE >= 0) {
+                lds_st(rowsL + (size_t)sE * RW, rowE);
+                if constexpr (DELTA) lds_st(rowsO + (size_t)sE * RW, rowE);
+            }
+
+            stage_fin(pos + 1);
+            if (sX >= 0) {
+                float l[NV][VEC];
+                lds_ld(rowsL + (size_t)sX * RW, l);
+                if constexpr (DELTA) {
+                    float o[NV][VEC];
+                    lds_ld(rowsO + (size_t)sX * RW, o);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) l[c][k] = rowG[c][k] + (l[c][k] - o[c][k]);
+                }
+                g_st(A.SynPos + (int64_t)vX * d, l);
+                if (lane == sX) slot_node = -1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the last R tokens are still in the window
+        for (int q = (len - R > 0 ? len - R : 0); q < len; ++q) {
+            const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
+            if (v < 0) continue;
+            const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node == v));
+            const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
+            if (lane == s) slot_ref = refc;
+            if (refc != 0) continue;
+            float l[NV][VEC];
+            lds_ld(rowsL + (size_t)s * RW, l);
+            if constexpr (DELTA) {
+                float o[NV][VEC], g[NV][VEC];
+                lds_ld(rowsO + (size_t)s * RW, o);
+                g_ld(A.SynPos + (int64_t)v * d, g);
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) l[c][k] = g[c][k] + (l[c][k] - o[c][k]);
+            }
+            g_st(A.SynPos + (int64_t)v * d, l);
+            if (lane == s) slot_node = -1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
+}
+
 // OPT-IN variant (flag GEMHIP_N2V_SHARED_NEGATIVES): the five negative targets are drawn ONCE PER CENTRE WORD and shared
 // by all of its contexts, so their rows stay in registers next to the positive row (per centre: 2*(1+5) + 2*contexts
 // row transfers instead of 2 + 12*contexts).  This is NOT the reference's sampling (TrainModel draws fresh negatives
@@ -586,6 +957,28 @@ void launch_sgns(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStre
 {
     hipLaunchKernelGGL((sgns_kernel<VEC, NV, WIDE>), dim3(blocks), dim3(threads), lds, s, A);
 }
+template <int VEC, int NV, bool DELTA>
+void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
+{
+    const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window;
+    if (full && allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true>), dim3(blocks), dim3(threads), lds, s, A);
+    else if (full) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, false>), dim3(blocks), dim3(threads), lds, s, A);
+    else if (allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, true>), dim3(blocks), dim3(threads), lds, s, A);
+    else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, false>), dim3(blocks), dim3(threads), lds, s, A);
+}
+template <bool DELTA>
+sgns_fn pick_sgns_win(int d)
+{
+    if (d % 2 == 0) {
+        const int nv = (d + 127) / 128;
+        return nv <= 1 ? launch_sgns_win<2, 1, DELTA> : nv <= 2 ? launch_sgns_win<2, 2, DELTA> : nv <= 4 ? launch_sgns_win<2, 4, DELTA> : nullptr;
+    }
+    const int nv = (d + 63) / 64;
+    return nv <= 1 ? launch_sgns_win<1, 1, DELTA> : nv <= 2 ? launch_sgns_win<1, 2, DELTA> : nv <= 4 ? launch_sgns_win<1, 4, DELTA> : nullptr;
+}
+// floats one cached row occupies in LDS (the wave's footprint of a row, see sgns_win_kernel)
+int sgns_win_row_floats(int d) { return d % 2 == 0 ? ((d + 127) / 128) * 128 : ((d + 63) / 64) * 64; }
+
 sgns_fn pick_sgns(int d, int64_t n = 0, bool allow_wide = false, bool shared = false)
 {
     if (shared) {
@@ -948,7 +1341,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
 {
     if (!h) return GEMHIP_OK;
     hipFree(h->d_start);
-    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks);
+    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy);
     if (h->own_counts) hipFree(h->d_counts);
     hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
@@ -1332,26 +1725,75 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.UT = h->d_UT; A.KT = h->d_KT; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     const bool deterministic = (flags & 4) != 0;
+    // Hogwild concurrency.  Each in-flight wavefront has ~7 embedding rows open (read-modify-write) at any
+    // time; when (waves x 7) approaches n, concurrent writers overwrite each other's updates and the
+    // embedding degrades (measured: tests/test_n2v_gpu.py).  Cap the number of concurrent
+    // wavefronts at n/HOGWILD_ROWS_PER_WAVE; at BASELINE scale (n >= 1M) the cap is the machine.
+    const int64_t hog_cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / HOGWILD_ROWS_PER_WAVE);
+
+    // window-cached kernel (default): radius R = tokens either side of the centre whose SynPos row stays in LDS
+    int R = h->cache_radius;
+    if (const char *e = getenv("GEMHIP_SGNS_CACHE_R")) R = atoi(e);
+    if (R < 0) R = 10;
+    R = std::min(R, std::min(window, 31));
+    const bool win_ok = R > 0 && !(flags & (32 | 64 | GEMHIP_N2V_NO_WINDOW_CACHE)) && 2 * window * SGNS_NEG <= 2 * WAVE && h->walk_len >= 2;
+    if (win_ok) {
+        int mode = h->cache_delta;                       // -1 auto: delta write-back whenever other wavefronts train concurrently
+        if (const char *e = getenv("GEMHIP_SGNS_CACHE_DELTA")) mode = atoi(e);
+        const int rw = sgns_win_row_floats(h->d);
+        const size_t ints = (size_t)((h->walk_len + 4 * window * SGNS_NEG + 3) & ~3);
+        auto lds_bytes = [&](bool delta) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * (delta ? 2 : 1) + 1) * rw * sizeof(float); };
+        int64_t waves = 1;
+        bool delta = false;
+        if (!deterministic) {
+            delta = mode != 0;
+            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(delta) + 512)));
+            waves = std::min<int64_t>(std::min<int64_t>(hog_cap, 256 * per_cu), walk_hi - walk_lo);
+            if (waves == 1 && mode < 0) delta = false;
+        }
+        const size_t lds = lds_bytes(delta);
+        GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for the LDS window (%zu bytes)", lds);
+        A.nwaves = (int32_t)waves; A.cache_radius = R;
+        const size_t need = (size_t)waves * rw * sizeof(float);
+        if (need > h->dummy_bytes) {
+            if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
+            GEMHIP_CHECK(hipMalloc(&h->d_dummy, need));
+            GEMHIP_CHECK(hipMemset(h->d_dummy, 0, need));
+            h->dummy_bytes = need;
+        }
+        A.dummy = h->d_dummy;
+        sgns_fn fn = delta ? pick_sgns_win<true>(h->d) : pick_sgns_win<false>(h->d);
+        GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
+        fn(A, (int)waves, 64, lds, (hipStream_t)stream);
+        GEMHIP_CHECK(hipGetLastError());
+        return GEMHIP_OK;
+    }
+
     const size_t per_wave = (size_t)(h->walk_len + 2 * window * SGNS_NEG) * sizeof(int32_t);
     int blocks, threads;
+    A.cache_radius = 0; A.dummy = nullptr;
     if (deterministic) { blocks = 1; threads = 64; A.nwaves = 1; }
     else {
         threads = 256;
-        // Hogwild concurrency.  Each in-flight wavefront has ~7 embedding rows open (read-modify-write) at any
-        // time; when (waves x 7) approaches n, concurrent writers overwrite each other's updates and the
-        // embedding degrades (measured: tests/test_n2v_gpu.py).  Cap the number of concurrent
-        // wavefronts at n/HOGWILD_ROWS_PER_WAVE; at BASELINE scale (n >= 1M) the cap is the machine
-        // (256 CUs x 16 waves) and never binds.
-        int64_t cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / HOGWILD_ROWS_PER_WAVE);
-        cap = std::min<int64_t>(cap, 256 * 16);          // 16 waves/CU already saturate the fabric (scripts/ab_sgns_waves.py)
+        const int64_t cap = std::min<int64_t>(hog_cap, 256 * 16);          // 16 waves/CU already saturate the fabric (scripts/ab_sgns_waves.py)
         const int64_t waves = std::min<int64_t>(cap, walk_hi - walk_lo);
         blocks = (int)((waves + 3) / 4);
         A.nwaves = (int32_t)waves;
     }
     const size_t lds = per_wave * (threads / 64);
     GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window too large for LDS staging (%zu bytes)", lds);
-    pick_sgns(h->d, h->n, (flags & 32) != 0, (flags & 64) != 0)(A, blocks, threads, lds, (hipStream_t)stream);
+    sgns_fn fn = pick_sgns(h->d, h->n, (flags & 32) != 0, (flags & 64) != 0);
+    GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
+    fn(A, blocks, threads, lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_set_window_cache(gemhip_n2v_t h, int32_t radius, int32_t delta_writeback)
+{
+    GEMHIP_REQUIRE(h && radius >= -1 && radius <= 31 && delta_writeback >= -1 && delta_writeback <= 1, "sgns_set_window_cache: bad arguments");
+    h->cache_radius = radius;
+    h->cache_delta = delta_writeback;
     return GEMHIP_OK;
 }
 

@@ -127,6 +127,8 @@ int gemhip_gf_objective(int64_t n, int64_t m, const int32_t *src,
 #define GEMHIP_N2V_SNAP_COMPAT 11
 #define GEMHIP_N2V_SHARED_NEGATIVES 64 /* OPT-IN, NOT the reference's sampling: the 5 negatives are drawn once per centre word and shared
                                          by its contexts (rows stay in registers: ~4x less table traffic); validated on MAP only */
+#define GEMHIP_N2V_NO_WINDOW_CACHE 128 /* A/B switch: train with the round-1 kernel (every context row goes to memory for every pair) instead of the
+                                          LDS-window kernel (gemhip_sgns_set_window_cache); same arithmetic and draws either way */
 #define GEMHIP_N2V_WIDE_ROWS 32 /* A/B switch (d == 128): 16-byte sc1 buffer accesses from half a wave + v_permlane32_swap; measured slower than the default 8-byte path */
 
 typedef struct gemhip_n2v *gemhip_n2v_t;
@@ -177,6 +179,11 @@ int gemhip_sgns_pairs(gemhip_n2v_t h, int64_t *pairs, int32_t reset);
 /* Cap on concurrently training wavefronts (Hogwild width).  0 = auto: min(4096, n/128),
  * which keeps lost updates negligible on small graphs and never binds at n >= 1M. */
 int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves);
+/* LDS window of TrainModel's context rows (no reference counterpart: the binary keeps its tables in host RAM).
+ * radius = tokens either side of the centre word whose SynPos row stays in LDS between its first and last use
+ * (-1 = auto = min(window, 10); 0 = off); delta_writeback: a row leaves the window as `row_now + (working - loaded)`
+ * so that concurrent wavefronts' updates survive (1), or is written back as is (0); -1 = auto (1 unless one wavefront trains). */
+int gemhip_sgns_set_window_cache(gemhip_n2v_t h, int32_t radius, int32_t delta_writeback);
 int gemhip_sgns_set_tables(gemhip_n2v_t h, const float *SynPos_host, const float *SynNeg_host);
 int gemhip_sgns_get_tables(gemhip_n2v_t h, float *SynPos_host, float *SynNeg_host);
 /* TrainModel over LOCAL walks [walk_lo, walk_hi) for epoch `epoch` of `epochs`.

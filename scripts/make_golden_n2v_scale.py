@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""node2vec reference points at (and near) the BASELINE headline size.
+
+Runs the real SNAP binary (gem/c_exe/node2vec, argv of gem/embedding/node2vec.py:34-53) race-free
+(OMP_NUM_THREADS=1) -- or, with --engine oracle, the sequential C restatement oracle/n2v_oracle.c -- on the graph
+bench.py builds (gem_amd.graph.sbm_graph, block size 10k, seed 20260923+4), then scores graph-reconstruction MAP
+(metrics.computeMAP semantics, gem_amd.evaluation.reconstruction.sampled_map) over a FIXED node sample
+(np.random.RandomState(0).choice(n, 1024, replace=False)) and writes tests/golden/n2v_ref_<tag>.json with the MAP,
+its standard error and the per-node APs, so that the -m gpu test and bench.py's `quality.reference_map` can compare
+the HIP path on the very same graph and sample.
+
+    python scripts/make_golden_n2v_scale.py --nodes 100000 --edges 1000000 --blocks 10           # ~35 min of one core
+    python scripts/make_golden_n2v_scale.py --nodes 1000000 --edges 10000000 --blocks 100        # ~5.5 h of one core
+"""
+import argparse, json, os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from gem_amd.graph import sbm_graph, edge_arrays
+from gem_amd.evaluation import reconstruction as gr
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--nodes', type=int, required=True)
+ap.add_argument('--edges', type=int, required=True)
+ap.add_argument('--blocks', type=int, required=True)
+ap.add_argument('--seed', type=int, default=20260923 + 4)
+ap.add_argument('--engine', default='snap', choices=['snap', 'oracle'])
+ap.add_argument('--threads', default='1')
+ap.add_argument('--p', type=float, default=1.0)
+ap.add_argument('--q', type=float, default=1.0)
+ap.add_argument('--sample', type=int, default=1024)
+ap.add_argument('--tag', default=None)
+ap.add_argument('--workdir', default=None)
+a = ap.parse_args()
+PARAMS = dict(n=a.nodes, edges=a.edges, blocks=a.blocks, seed=a.seed, d=128, walk_len=80, num_walks=10, window=10, p=a.p, q=a.q)
+
+g = sbm_graph(a.nodes, a.edges, a.blocks, a.seed)
+n = g.n
+nodes = np.random.RandomState(0).choice(n, size=min(a.sample, n), replace=False)
+tmp = a.workdir or tempfile.mkdtemp(prefix='n2vgold_')
+os.makedirs(tmp, exist_ok=True)
+print('graph %d nodes %d directed edges, workdir %s' % (n, g.number_of_edges(), tmp), flush=True)
+
+t = time.time()
+if a.engine == 'snap':
+    gf = os.path.join(tmp, 'g.graph')
+    import pandas as pd
+    pd.DataFrame({'s': g.src, 'd': g.dst, 'w': np.ones(len(g.src))}).to_csv(gf, sep=' ', header=False, index=False, float_format='%f')
+    rc = subprocess.call(['/root/reference/gem/c_exe/node2vec', '-i:' + gf, '-o:' + os.path.join(tmp, 'g.emb'), '-d:%d' % PARAMS['d'],
+                          '-l:%d' % PARAMS['walk_len'], '-r:%d' % PARAMS['num_walks'], '-k:%d' % PARAMS['window'], '-e:1',
+                          '-p:%f' % a.p, '-q:%f' % a.q, '-dr', '-w'], stdout=subprocess.DEVNULL,
+                         env=dict(os.environ, OMP_NUM_THREADS=a.threads))
+    el = time.time() - t
+    assert rc == 0, rc
+    import pandas as pd
+    df = pd.read_csv(os.path.join(tmp, 'g.emb'), sep=' ', header=None, skiprows=1, dtype=np.float64)
+    df = df.dropna(axis=1, how='all')
+    X = np.zeros((n, PARAMS['d']), np.float32)
+    X[df[0].to_numpy().astype(np.int64)] = df.iloc[:, 1:1 + PARAMS['d']].to_numpy(dtype=np.float32)
+    engine = 'gem/c_exe/node2vec (SNAP ELF), OMP_NUM_THREADS=%s' % a.threads
+else:
+    import oracle
+    _, src, dst, w, _ = edge_arrays(g)
+    X = oracle.n2v_train(n, src, dst, None, PARAMS['d'], PARAMS['walk_len'], PARAMS['num_walks'], PARAMS['window'], 1, a.p, a.q, 20260923, 11)    # flags 11 = SNAP_COMPAT
+    if isinstance(X, tuple):
+        X = X[0]
+    X = np.asarray(X, dtype=np.float32)
+    el = time.time() - t
+    engine = 'oracle/n2v_oracle.c (sequential restatement of SNAP)'
+print('trained in %.0fs' % el, flush=True)
+
+Xd = X.astype(np.float64)
+aps = []
+order = np.argsort(g.src, kind='stable')
+s_sorted, d_sorted = g.src[order], g.dst[order]
+starts = np.searchsorted(s_sorted, np.arange(n + 1))
+for i in nodes:
+    s = Xd @ Xd[i]
+    tr = np.zeros(n, dtype=bool); tr[d_sorted[starts[i]:starts[i + 1]]] = True
+    s, tr = s[i + 1:], tr[i + 1:]
+    pos = s > 0
+    s, tr = s[pos], tr[pos]
+    if s.size == 0 or tr.sum() == 0:
+        aps.append(0.0); continue
+    hit = tr[np.argsort(-s, kind='stable')]
+    prec = np.cumsum(hit) / np.arange(1, hit.size + 1)
+    aps.append(float(prec[hit].sum() / hit.sum()))
+aps = np.asarray(aps)
+out = {'params': PARAMS, 'engine': engine, 'seconds': el, 'edges_per_s': g.number_of_edges() / el,
+       'sample': 'np.random.RandomState(0).choice(n, %d, replace=False)' % len(nodes),
+       'MAP': float(aps.mean()), 'MAP_se': float(aps.std(ddof=1) / np.sqrt(len(aps))), 'ap': [round(float(v), 6) for v in aps]}
+tag = a.tag or ('%s_%dk' % (a.engine, n // 1000))
+path = os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_%s.json' % tag)
+json.dump(out, open(path, 'w'))
+print(path, 'MAP %.4f +- %.4f, %.0f edges/s' % (out['MAP'], out['MAP_se'], out['edges_per_s']), flush=True)

@@ -138,6 +138,53 @@ def test_sgns_deterministic_matches_oracle(gname, d, window, l, epochs, flags, r
     dev.close()
 
 
+@pytest.mark.parametrize('gname,d,window,l,radius,delta', [('karate', 8, 10, 80, -1, 0), ('karate', 8, 10, 80, 3, 0), ('karate', 7, 4, 30, 2, 0),
+                                                           ('sbm1024', 128, 10, 40, -1, 0), ('sbm1024', 128, 10, 40, 4, 0),
+                                                           ('sbm1024', 128, 10, 40, -1, 1), ('karate', 256, 5, 20, 5, 1),
+                                                           ('karate', 16, 12, 9, -1, 0)])
+def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, delta, request):
+    """The LDS-window kernel (default) and the round-1 kernel (flag 128) are the same algorithm: one wavefront in walk order gives
+    bit-identical tables when rows leave the window as they are (delta=0), whatever the cached radius; the delta write-back
+    (row_now + (working - loaded), what multi-wave launches use) differs by fp32 rounding only."""
+    G = request.getfixturevalue(gname)
+    n, src, dst, w, _ = edge_arrays(G)
+    dev = Dev(n, src, dst, w)
+    walks = dev.walks(1.0, 1.0, 10 if gname == 'karate' else 1, l, 5, SNAP)
+    if gname == 'sbm1024':
+        walks = walks[:128]
+        _hip.check(dev.L.gemhip_n2v_set_walks(dev.h, _hip.ptr(walks, C.c_int32), walks.shape[0], l, 0))
+    dev.unigram()
+    P0, N0 = dev.sgns(d, window, 1, 5, SNAP | 4 | _hip.N2V_NO_WINDOW_CACHE)
+    _hip.check(dev.L.gemhip_sgns_set_window_cache(dev.h, radius, delta))
+    P1, N1 = dev.sgns(d, window, 1, 5, SNAP | 4)
+    if delta == 0:
+        assert np.array_equal(P0, P1) and np.array_equal(N0, N1)
+    else:
+        for a, b in ((P0, P1), (N0, N1)):
+            assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(a).max())
+    dev.close()
+
+
+def test_sgns_window_cache_hogwild_quality(sbm1024):
+    """Multi-wave launches (delta write-back): MAP of the window kernel == MAP of the round-1 kernel within noise, for the full
+    radius and a partial one, and the pair count (the unit of the roofline) is identical."""
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    m = node2vec(d=128, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
+    res = {}
+    for name, flags, radius in (('r1', SNAP | _hip.N2V_NO_WINDOW_CACHE, 0), ('win', SNAP, -1), ('win4', SNAP, 4)):
+        dev = Dev(n, src, dst, w)
+        dev.walks(1.0, 1.0, 10, 80, 7, SNAP); dev.unigram()
+        if radius:
+            _hip.check(dev.L.gemhip_sgns_set_window_cache(dev.h, radius, -1))
+        P, _ = dev.sgns(128, 10, 1, 7, flags)
+        pairs = C.c_int64(); _hip.check(dev.L.gemhip_sgns_pairs(dev.h, C.byref(pairs), 0))
+        res[name] = (gr.evaluateStaticGraphReconstruction(sbm1024, m, P.astype(np.float64), None)[0], pairs.value)
+        dev.close()
+    assert res['r1'][1] == res['win'][1] == res['win4'][1]
+    for k in ('win', 'win4'):
+        assert abs(res[k][0] - res['r1'][0]) <= 0.05 * res['r1'][0], res
+
+
 def test_init_tables_bit_exact():
     n, src, dst, w = small_graph(False, n=50, m=300)
     dev = Dev(n, src, dst, w)
