@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgem_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-Wno-unused-value',
-          '-Wno-unused-result']
+          '-Wno-unused-result'] + os.environ.get('GEM_HIP_EXTRA_CFLAGS', '').split()
 
 
 def sources():

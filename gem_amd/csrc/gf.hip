@@ -239,10 +239,33 @@ extern "C" int gemhip_gf_plan_create(int64_t n, int64_t m, const int32_t *src, c
     std::vector<int32_t> pos(n, -1);          // pos[i] = rank of row i among firing source rows (reference order)
     std::vector<int32_t> order;               // row ids by pos
     std::vector<int64_t> deg;
+    // The plan gives a source row ONE wavefront and all of its firing edges in one go, reading X_new[j] for neighbours whose
+    // row comes earlier in first-visit order and X_old[j] otherwise.  That equals the reference's strictly sequential loop
+    // (gf.py:93-100, gf.cpp:152-164) iff every firing edge (i,j) at position t sees either ALL of j's updates of this sweep
+    // (j's last firing edge is before t, and j was first visited before i) or NONE (j's first firing edge is after t) --
+    // always true when a source's edges are contiguous (graph.edges(), saveGraphToEdgeListTxt), and for many interleaved
+    // lists too.  A list that needs an intermediate version of a row (e.g. (1,2),(0,1),(1,3): row 0 must see X_1 between its
+    // two updates) has no schedule with two table versions; it is rejected instead of silently reordered.
+    std::vector<int64_t> first_t(n, -1), last_t(n, -1);
     for (int64_t e = 0; e < m; ++e) {
         const int32_t i = src[e], j = dst[e];
         GEMHIP_REQUIRE(i >= 0 && i < n && j >= 0 && j < n, "gf_plan_create: edge %lld = (%d,%d) outside [0,%lld)", (long long)e, i, j,
                        (long long)n);
+        if (j <= i) continue;                        // does not fire (gf.py:95, gf.cpp:157)
+        if (first_t[i] < 0) first_t[i] = e;
+        last_t[i] = e;
+    }
+    for (int64_t e = 0; e < m; ++e) {
+        const int32_t i = src[e], j = dst[e];
+        if (j <= i || first_t[j] < 0) continue;      // j never fires: its row is the same in both tables
+        const bool ok = first_t[j] < first_t[i] ? last_t[j] < e : first_t[j] > e;
+        GEMHIP_REQUIRE(ok, "gf_plan_create: edge %lld = (%d,%d) reads row %d while that row is only partly updated in file order "
+                       "(its firing edges span positions %lld..%lld); the sequential semantics of gf.cpp need the edges of a source "
+                       "to be contiguous (graph.edges() order) -- group the list by source first if the reordering is acceptable",
+                       (long long)e, i, j, j, (long long)first_t[j], (long long)last_t[j]);
+    }
+    for (int64_t e = 0; e < m; ++e) {
+        const int32_t i = src[e], j = dst[e];
         if (j <= i || i < row_begin || i >= row_end) continue;
         if (pos[i] < 0) { pos[i] = (int32_t)order.size(); order.push_back(i); deg.push_back(0); }
         ++deg[pos[i]];

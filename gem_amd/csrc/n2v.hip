@@ -298,6 +298,7 @@ struct SgnsArgs {
     const float *UT; const int32_t *KT; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
     float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs;
     float *dummy;               // sgns_win_kernel: nwaves rows, never read for their value
+    unsigned long long *prof;   // GEMHIP_SGNS_PROFILE builds only: per-phase cycle sums (s_memtime)
     int32_t cache_radius;       // sgns_win_kernel: tokens within this many positions of the centre keep their SynPos row in LDS
 };
 
@@ -407,12 +408,12 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) part += xc[c][v] * yp[c][v];
+                        for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yp[c][v], part);
                     const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yp[c][v]; yp[c][v] += g * xc[c][v]; }
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yp[c][v], neu[c][v]); yp[c][v] = fmaf(g, xc[c][v], yp[c][v]); }
                 }
 #pragma unroll
                 for (int j = 0; j < SGNS_NEG; ++j) {
@@ -430,12 +431,12 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) part += xc[c][v] * yn[j][c][v];
+                        for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yn[j][c][v], part);
                     const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yn[j][c][v]; yn[j][c][v] += g * xc[c][v]; }
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
                     float *pn = A.SynNeg + (int64_t)tgt[j] * d;
                     if constexpr (WIDE) st_row_wide(rsN, tgt[j], lane, yn[j][0]);
                     else
@@ -460,6 +461,19 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
     if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
 }
 
+#ifdef GEMHIP_SGNS_PROFILE
+#define PROF_T() ({ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long _t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); _t; })
+#define PROF_DECL unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t = 0
+#define PROF_START() prof_t = PROF_T()
+#define PROF_LAP(k) do { const unsigned long long _n = PROF_T(); prof_acc[k] += _n - prof_t; prof_t = _n; } while (0)
+#define PROF_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_LAP(k)
+#define PROF_WAIT_VM(n)
+#endif
+
 // ---- window-cached TrainModel (default since round 2) ------------------------------------------------------------
 // Same arithmetic, same order and same Philox draws as sgns_kernel; what changes is WHERE the context rows live.
 // A token is a context of every centre within `window` positions, so sgns_kernel moves its SynPos row 2 x ~11 times.
@@ -476,6 +490,41 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 // Latency at 1 wave per SIMD-ish occupancy (the LDS window bounds residency at ~7-13 waves per CU): the negative rows of
 // the next TWO (centre, context) pairs are in flight while a pair is computed (targets equal to a row updated in
 // between are re-forwarded from registers: exact), and the negative targets are drawn two centres ahead.
+// Six dot products at once.  Every lane holds its partial sums p[0..5]; on return lane l holds the WAVE TOTAL of value
+// idx(l) = (l & 4) ? 4 + (l & 1) : (l & 3)  (so lanes 0..5 hold totals 0..5).  Transposing while reducing (each lane keeps the half
+// of the values its lane bit selects and hands the other half to its partner) costs 22 lane operations for all six sums,
+// against 6 x 11 for six wave_sum calls -- and leaves the six totals in six LANES, so the sigmoid of TrainModel runs once,
+// lane-parallel, instead of six times.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+typedef unsigned int n2v_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float wave_sum6(const float (&p)[6], int lane)
+{
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+    // lane bit 0 (partner l^1): values (0,1) (2,3) (4,5)
+    const float a0 = (b0 ? p[1] : p[0]) + dpp_mov<0xB1>(b0 ? p[0] : p[1]);
+    const float a1 = (b0 ? p[3] : p[2]) + dpp_mov<0xB1>(b0 ? p[2] : p[3]);
+    const float a2 = (b0 ? p[5] : p[4]) + dpp_mov<0xB1>(b0 ? p[4] : p[5]);
+    // lane bit 1 (partner l^2): quad totals; value index 2*b1 + b0 in c0, 4 + b0 in c1
+    float c0 = (b1 ? a1 : a0) + dpp_mov<0x4E>(b1 ? a0 : a1);
+    float c1 = a2 + dpp_mov<0x4E>(a2);
+    // the four quads of a row of 16 lanes: rotate by 4 and by 8
+    c0 += dpp_mov<0x124>(c0); c0 += dpp_mov<0x128>(c0);
+    c1 += dpp_mov<0x124>(c1); c1 += dpp_mov<0x128>(c1);
+    float m = b2 ? c1 : c0;
+    // the four rows: v_permlane16_swap / v_permlane32_swap of (m, m) give {even-row copy, odd-row copy}
+    // (elements are copied to scalars first: __builtin_bit_cast applied directly to `r.y` reads element 0 with this compiler)
+    n2v_u32x2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    unsigned lo = r.x, hi = r.y;
+    m = __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
+    r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    lo = r.x; hi = r.y;
+    return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
+}
+
 template <int VEC, int NV>
 struct NegSet {
     int32_t tv;                 // lanes 0..4: the five targets (lane form, for the any-match test)
@@ -528,6 +577,8 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 
     float *dummy = A.dummy + (size_t)gw * RW;        // this wave's private sink / source for predicated-off row traffic
     unsigned long long npairs = 0;
+    PROF_DECL;
+    PROF_START();
     for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
         const int32_t *walk = A.walks + wl * len;
         for (int k = lane; k < len; k += WAVE) tok[k] = walk[k];
@@ -561,15 +612,41 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
             for (int k = 0; k < NS; ++k) { XB[k] = XA[k]; uB[k] = uA[k]; UTv[k] = A.UT[XB[k]]; KTv[k] = A.KT[XB[k]]; }
         };
-        auto stage_fin = [&](int p) {
+        // ... and the "special" mask of centre p: bit ai is set when the (centre, context) pair of slot ai cannot take the
+        // all-targets-independent fast path -- a target equals the centre word (TrainModel skips it), a target was drawn twice
+        // (the second use must see the first update), or a target also occurs in one of the previous two slots (this slot's rows
+        // were requested before those slots' updates were stored, so the slow path fetches them again).  One lane per slot,
+        // once per centre; at n = 1M it is set for ~1e-4 of the pairs, on karate (n = 34) for nearly all.
+        auto stage_fin = [&](int p) -> uint32_t {
             int32_t *dst = negs + (p & 1) * nsamp;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int s = lane + k * WAVE;
                 if (s < nsamp) dst[s] = (uB[k] < UTv[k]) ? XB[k] : KTv[k];
             }
+            if (p >= len) return 0u;
+            const int32_t wordn = __builtin_amdgcn_readfirstlane(tok[p]);
+            bool sp = false;
+            if (lane < 2 * win) {
+                int32_t t[SGNS_NEG];
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) { t[j] = dst[lane * SGNS_NEG + j]; sp = sp || t[j] == wordn; }
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j)
+#pragma unroll
+                    for (int jp = 0; jp < j; ++jp) sp = sp || t[j] == t[jp];
+#pragma unroll
+                for (int k = 0; k < 2 * SGNS_NEG; ++k) {
+                    const int idx = (lane - 2) * SGNS_NEG + k;
+                    const int32_t u = dst[idx >= 0 ? idx : 0];
+#pragma unroll
+                    for (int j = 0; j < SGNS_NEG; ++j) sp = sp || (idx >= 0 && t[j] == u);
+                }
+            }
+            return (uint32_t)__builtin_amdgcn_ballot_w64(sp);
         };
-        stage_a(0); stage_b(); stage_fin(0);
+        stage_a(0); stage_b();
+        uint32_t spec_next = stage_fin(0);
         stage_a(1);
 
         // --- cache: enter token q (directory now, row through `rowE` -> LDS by the caller), leave token q
@@ -589,6 +666,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 
         for (int pos = 0; pos < len; ++pos) {
             const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
+            uint32_t spec_cur = spec_next;
             // token pos+R enters
             float rowE[NV][VEC]; int sE = -1;
             if (pos + R < len) {
@@ -642,6 +720,12 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 }
                 unsigned long long m_proc = __builtin_amdgcn_ballot_w64(valid), m_iss = m_proc;
                 npairs += (unsigned long long)__builtin_popcountll(m_proc);
+                {   // the slots after ai in flight are ai+1, ai+2 only if the valid contexts are contiguous (always, but for padded walks)
+                    const unsigned long long lowm = (1ull << win) - 1ull;
+                    const unsigned long long mai = (m_proc & lowm) | ((m_proc >> (win + 1)) << win);
+                    const unsigned long long sh = mai ? (mai >> __builtin_ctzll(mai)) : 0ull;
+                    if (sh & (sh + 1ull)) spec_cur = 0xFFFFFFFFu;
+                }
 
                 NegSet<VEC, NV> q0, q1, q2;          // three register sets rotate: processed now / next / the one after
                 auto issue = [&](NegSet<VEC, NV> &Q) __attribute__((always_inline)) {
@@ -667,9 +751,11 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 
                 // one (centre, context) pair: C holds its negative rows, P1 the next pair's (in flight), P2 is free
                 auto step = [&](NegSet<VEC, NV> &C, NegSet<VEC, NV> &P1, NegSet<VEC, NV> &P2) __attribute__((always_inline)) {
+                    PROF_LAP(0);                                     // outside the pair steps (per-centre work, loop control)
                     const int a = (int)__builtin_ctzll(m_proc);
                     m_proc &= m_proc - 1;
                     issue(P2);
+                    PROF_LAP(1);                                     // issue of the prefetch
 
                     const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[pos - win + a]);
                     const unsigned long long chit = __builtin_amdgcn_ballot_w64(slot_node == ctx);
@@ -687,75 +773,94 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
                         for (int k = 0; k < VEC; ++k) neu[c][k] = 0.f;
-                    {   // positive target (label 1), row lives in registers
-                        float part = 0.f;
+                    const int ai_c = a < win ? a : a - 1;
+                    PROF_LAP(2);                                     // context lookup + LDS read (includes its lgkmcnt wait)
+                    PROF_WAIT_VM(10);
+                    PROF_LAP(3);                                     // waiting for this pair's rows (two younger prefetches may stay in flight)
+                    if (!((spec_cur >> ai_c) & 1u)) {
+                        // fast path: the six targets are distinct rows and none is the centre word -> six independent updates
+                        float part[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) part[j] = 0.f;
 #pragma unroll
                         for (int c = 0; c < NV; ++c)
 #pragma unroll
-                            for (int k = 0; k < VEC; ++k) part += xc[c][k] * yp[c][k];
-                        const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+                            for (int k = 0; k < VEC; ++k) {
+                                part[0] = fmaf(xc[c][k], yp[c][k], part[0]);
 #pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) { neu[c][k] += g * yp[c][k]; yp[c][k] += g * xc[c][k]; }
-                    }
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) {
-                        const bool skip = C.tgt[j] == word || C.tgt[j] < 0;  // TrainModel: `if (Target == Word) continue` (predicated: g = 0, row -> dummy)
-#pragma unroll
-                        for (int jp = 0; jp < j; ++jp)                       // a target drawn twice sees the first update
-                            if (C.tgt[jp] == C.tgt[j]) {
-#pragma unroll
-                                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                    for (int k = 0; k < VEC; ++k) C.y[j][c][k] = C.y[jp][c][k];
+                                for (int j = 0; j < SGNS_NEG; ++j) part[j + 1] = fmaf(xc[c][k], C.y[j][c][k], part[j + 1]);
                             }
-                        float part = 0.f;
+                        const float f = wave_sum6(part, lane);
+                        const float gl = sgns_grad(f, (lane & 7) == 0 ? 1.0f : 0.0f, alpha);     // lanes 0..5: g of target 0..5
+                        float g[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) g[j] = bcast_lane(gl, j);
 #pragma unroll
                         for (int c = 0; c < NV; ++c)
 #pragma unroll
-                            for (int k = 0; k < VEC; ++k) part += xc[c][k] * C.y[j][c][k];
-                        float g = sgns_grad(wave_sum(part), 0.0f, alpha);
-                        g = skip ? 0.f : g;
+                            for (int k = 0; k < VEC; ++k) {
+                                neu[c][k] = fmaf(g[0], yp[c][k], neu[c][k]);
+                                yp[c][k] = fmaf(g[0], xc[c][k], yp[c][k]);
+                            }
 #pragma unroll
-                        for (int c = 0; c < NV; ++c)
+                        for (int j = 0; j < SGNS_NEG; ++j) {
 #pragma unroll
-                            for (int k = 0; k < VEC; ++k) { neu[c][k] += g * C.y[j][c][k]; C.y[j][c][k] += g * xc[c][k]; }
-                        g_st(skip ? dummy : A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) {
+                                    neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
+                                    C.y[j][c][k] = fmaf(g[j + 1], xc[c][k], C.y[j][c][k]);
+                                }
+                            g_st(A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                        }
+                    } else {
+                        // slow path (exact sequential semantics): the rows may have been requested before an update of the same row by
+                        // one of the two previous pairs was stored -- fetch them again (program order after those stores)
+#pragma unroll
+                        for (int j = 0; j < SGNS_NEG; ++j) g_ld(C.tgt[j] < 0 ? dummy : A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                        {   // positive target (label 1), row lives in registers
+                            float part = 0.f;
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) part = fmaf(xc[c][k], yp[c][k], part);
+                            const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) { neu[c][k] = fmaf(g, yp[c][k], neu[c][k]); yp[c][k] = fmaf(g, xc[c][k], yp[c][k]); }
+                        }
+#pragma unroll
+                        for (int j = 0; j < SGNS_NEG; ++j) {
+                            const bool skip = C.tgt[j] == word || C.tgt[j] < 0;  // TrainModel: `if (Target == Word) continue` (predicated: g = 0, row -> dummy)
+#pragma unroll
+                            for (int jp = 0; jp < j; ++jp)                       // a target drawn twice sees the first update
+                                if (C.tgt[jp] == C.tgt[j]) {
+#pragma unroll
+                                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                        for (int k = 0; k < VEC; ++k) C.y[j][c][k] = C.y[jp][c][k];
+                                }
+                            float part = 0.f;
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) part = fmaf(xc[c][k], C.y[j][c][k], part);
+                            float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+                            g = skip ? 0.f : g;
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) { neu[c][k] = fmaf(g, C.y[j][c][k], neu[c][k]); C.y[j][c][k] = fmaf(g, xc[c][k], C.y[j][c][k]); }
+                            g_st(skip ? dummy : A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                        }
                     }
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
                         for (int k = 0; k < VEC; ++k) xc[c][k] += neu[c][k];
                     if (ALLC || chit) lds_st(lrow, xc); else g_st(pc, xc);
-
-                    // P1/P2's rows were requested before the stores above: a target of theirs that was just updated
-                    // takes the updated row from registers (rare; keeps the exact sequential semantics)
-                    bool same = false;
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j)
-                        if (C.tgt[j] != word) same = same || P1.tv == C.tgt[j] || P2.tv == C.tgt[j];
-                    if (__builtin_amdgcn_ballot_w64(same)) {
-#pragma unroll
-                        for (int j = 0; j < SGNS_NEG; ++j) {
-                            if (C.tgt[j] == word) continue;
-#pragma unroll
-                            for (int jp = 0; jp < SGNS_NEG; ++jp) {
-                                if (P1.tgt[jp] == C.tgt[j]) {
-#pragma unroll
-                                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                        for (int k = 0; k < VEC; ++k) P1.y[jp][c][k] = C.y[j][c][k];
-                                }
-                                if (P2.tgt[jp] == C.tgt[j]) {
-#pragma unroll
-                                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                        for (int k = 0; k < VEC; ++k) P2.y[jp][c][k] = C.y[j][c][k];
-                                }
-                            }
-                        }
-                    }
+                    PROF_LAP(4);                                     // arithmetic + stores
                 };
                 while (true) {
                     if (!m_proc) break;
@@ -782,7 +887,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 if constexpr (DELTA) lds_st(rowsO + (size_t)sE * RW, rowE);
             }
 
-            stage_fin(pos + 1);
+            spec_next = stage_fin(pos + 1);
             if (sX >= 0) {
                 float l[NV][VEC];
                 lds_ld(rowsL + (size_t)sX * RW, l);
@@ -824,6 +929,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
+#ifdef GEMHIP_SGNS_PROFILE
+    PROF_LAP(0);
+    if (lane == 0 && A.prof) for (int k = 0; k < 8; ++k) atomicAdd(A.prof + k, prof_acc[k]);
+#endif
 }
 
 // OPT-IN variant (flag GEMHIP_N2V_SHARED_NEGATIVES): the five negative targets are drawn ONCE PER CENTRE WORD and shared
@@ -902,12 +1011,12 @@ __global__ __launch_bounds__(256) void sgns_shared_kernel(SgnsArgs A)
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) part += xc[c][v] * yp[c][v];
+                        for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yp[c][v], part);
                     const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yp[c][v]; yp[c][v] += g * xc[c][v]; }
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yp[c][v], neu[c][v]); yp[c][v] = fmaf(g, xc[c][v], yp[c][v]); }
                 }
 #pragma unroll
                 for (int j = 0; j < SGNS_NEG; ++j) {
@@ -916,12 +1025,12 @@ __global__ __launch_bounds__(256) void sgns_shared_kernel(SgnsArgs A)
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) part += xc[c][v] * yn[j][c][v];
+                        for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yn[j][c][v], part);
                     const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yn[j][c][v]; yn[j][c][v] += g * xc[c][v]; }
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
                 }
 #pragma unroll
                 for (int c = 0; c < NV; ++c) {
@@ -1196,12 +1305,12 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
 #pragma unroll
             for (int c = 0; c < NV; ++c)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) part += xc[c][v] * yp[c][v];
+                for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yp[c][v], part);
             const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
 #pragma unroll
             for (int c = 0; c < NV; ++c)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yp[c][v]; yp[c][v] += g * xc[c][v]; }
+                for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yp[c][v], neu[c][v]); yp[c][v] = fmaf(g, xc[c][v], yp[c][v]); }
         }
 #pragma unroll
         for (int j = 0; j < SGNS_NEG; ++j) {
@@ -1218,12 +1327,12 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
 #pragma unroll
             for (int c = 0; c < NV; ++c)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) part += xc[c][v] * yn[j][c][v];
+                for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yn[j][c][v], part);
             const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
 #pragma unroll
             for (int c = 0; c < NV; ++c)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) { neu[c][v] += g * yn[j][c][v]; yn[j][c][v] += g * xc[c][v]; }
+                for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
             float *pn = A.SynNeg + (int64_t)tgt[j] * d;
 #pragma unroll
             for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
@@ -1748,7 +1857,10 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
         if (!deterministic) {
             delta = mode != 0;
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(delta) + 512)));
-            waves = std::min<int64_t>(std::min<int64_t>(hog_cap, 256 * per_cu), walk_hi - walk_lo);
+            // a wavefront of this kernel holds 2R+1 more rows (the window) than sgns_kernel's ~8: same bound on the fraction of the
+            // table that is open at any time (1/16), hence proportionally fewer concurrent wavefronts on small graphs
+            const int64_t hog_win = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
+            waves = std::min<int64_t>(std::min<int64_t>(hog_win, 256 * per_cu), walk_hi - walk_lo);
             if (waves == 1 && mode < 0) delta = false;
         }
         const size_t lds = lds_bytes(delta);
@@ -1762,16 +1874,32 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             h->dummy_bytes = need;
         }
         A.dummy = h->d_dummy;
+        A.prof = nullptr;
+#ifdef GEMHIP_SGNS_PROFILE
+        static unsigned long long *d_prof = nullptr;
+        if (!d_prof) GEMHIP_CHECK(hipMalloc(&d_prof, 64));
+        GEMHIP_CHECK(hipMemset(d_prof, 0, 64));
+        A.prof = d_prof;
+#endif
         sgns_fn fn = delta ? pick_sgns_win<true>(h->d) : pick_sgns_win<false>(h->d);
         GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
         fn(A, (int)waves, 64, lds, (hipStream_t)stream);
         GEMHIP_CHECK(hipGetLastError());
+#ifdef GEMHIP_SGNS_PROFILE
+        {
+            unsigned long long hp[8];
+            GEMHIP_CHECK(hipDeviceSynchronize());
+            GEMHIP_CHECK(hipMemcpy(hp, A.prof, 64, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[sgns profile] waves=%lld cycles: outside=%llu issue=%llu ctx_lds=%llu wait_rows=%llu compute_store=%llu\n", (long long)waves, hp[0], hp[1],
+                    hp[2], hp[3], hp[4]);
+        }
+#endif
         return GEMHIP_OK;
     }
 
     const size_t per_wave = (size_t)(h->walk_len + 2 * window * SGNS_NEG) * sizeof(int32_t);
     int blocks, threads;
-    A.cache_radius = 0; A.dummy = nullptr;
+    A.cache_radius = 0; A.dummy = nullptr; A.prof = nullptr;
     if (deterministic) { blocks = 1; threads = 64; A.nwaves = 1; }
     else {
         threads = 256;
@@ -1786,6 +1914,31 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
     fn(A, blocks, threads, lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+namespace {
+__global__ void wave_sum6_test_kernel(const float *in, float *out)
+{
+    const int lane = lane_id();
+    float p[6];
+    for (int k = 0; k < 6; ++k) p[k] = in[lane * 6 + k];
+    out[lane] = wave_sum6(p, lane);
+}
+}  // namespace
+
+// Building block exposed for its own parity test: in[64][6] partial sums of one wavefront -> out[64], lane l receiving the
+// wave total of value (l & 4) ? 4 + (l & 1) : (l & 3).
+extern "C" int gemhip_test_wave_sum6(const float *in_host, float *out_host)
+{
+    GEMHIP_REQUIRE(in_host && out_host, "test_wave_sum6: NULL argument");
+    float *d = nullptr;
+    GEMHIP_CHECK(hipMalloc(&d, (64 * 6 + 64) * sizeof(float)));
+    hipError_t e = hipMemcpy(d, in_host, 64 * 6 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(wave_sum6_test_kernel, dim3(1), dim3(64), 0, 0, d, d + 64 * 6); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(out_host, d + 64 * 6, 64 * sizeof(float), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(GEMHIP_E_HIP, "test_wave_sum6: %s", hipGetErrorString(e));
     return GEMHIP_OK;
 }
 

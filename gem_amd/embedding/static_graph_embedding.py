@@ -60,9 +60,10 @@ class StaticGraphEmbedding(object):
             self._X = X
         elif self._X is None:
             raise ValueError("Embedding not learned yet")
+        # node_l is accepted and IGNORED, exactly like static_graph_embedding.py:48-65: the reference base class
+        # reconstructs over all rows of the X it is given (evaluateStaticGraphReconstruction forwards node_l next to an
+        # X the caller may already have sampled; only SDNE's override uses it)
         Xu = np.asarray(self._X, dtype=np.float64)
-        if node_l is not None:
-            Xu = Xu[np.asarray(node_l)]
         adj = np.array(self._pair_matrix(Xu), dtype=np.float64)
         np.fill_diagonal(adj, 0.0)
         return adj

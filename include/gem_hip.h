@@ -62,6 +62,14 @@ int gemhip_synchronize(void *stream);
  * written.  The device schedule reproduces that order exactly (level-scheduled
  * rows + double-buffered table) -- results differ from the fp32
  * CPU loop only by dot-product summation order.
+ *
+ * PRECONDITION (checked; GEMHIP_E_INVALID otherwise): every firing edge
+ * (dst > src) reads a row that, in file order, has had either all or none of
+ * its updates of the sweep -- always true when a source's edges are contiguous
+ * (what graph.edges() and saveGraphToEdgeListTxt produce).  gf.cpp:152-164
+ * processes an arbitrary file strictly in file order; a list such as
+ * (1,2),(0,1),(1,3), where row 0 must see row 1 between its two updates, needs
+ * a third version of a row and is rejected rather than silently regrouped.
  */
 typedef struct gemhip_gf_plan *gemhip_gf_plan_t;
 
@@ -184,6 +192,9 @@ int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves);
  * (-1 = auto = min(window, 10); 0 = off); delta_writeback: a row leaves the window as `row_now + (working - loaded)`
  * so that concurrent wavefronts' updates survive (1), or is written back as is (0); -1 = auto (1 unless one wavefront trains). */
 int gemhip_sgns_set_window_cache(gemhip_n2v_t h, int32_t radius, int32_t delta_writeback);
+/* Building block of the SGNS kernel, exposed for its own parity test: in[64][6] per-lane partial sums -> out[64], lane l
+ * receiving the wave total of value (l & 4) ? 4 + (l & 1) : (l & 3). */
+int gemhip_test_wave_sum6(const float *in_host, float *out_host);
 int gemhip_sgns_set_tables(gemhip_n2v_t h, const float *SynPos_host, const float *SynNeg_host);
 int gemhip_sgns_get_tables(gemhip_n2v_t h, float *SynPos_host, float *SynNeg_host);
 /* TrainModel over LOCAL walks [walk_lo, walk_hi) for epoch `epoch` of `epochs`.

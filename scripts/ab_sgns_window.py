@@ -25,7 +25,8 @@ L = _hip.lib()
 m = b.num_start_nodes(); b.walks(1.0, 1.0, r, 80, 20260923, 11, 0, m * r); b.vocab(); b.build_unigram()
 sample = np.random.RandomState(0).choice(n, size=256, replace=False)
 out = []
-for rep in range(2):
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+for rep in range(reps):
     for name, flags, R, delta, mw in variants:
         _hip.check(L.gemhip_sgns_set_window_cache(b.h, R if R > 0 else -1, delta))
         _hip.check(L.gemhip_n2v_set_max_waves(b.h, mw))

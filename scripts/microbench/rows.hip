@@ -1,0 +1,196 @@
+// Random-row traffic ceilings on gfx950 for the SGNS access pattern: 512-byte rows of a 512 MB table, picked at random,
+// read and/or written by one wavefront per row with different instruction forms.  Prints one JSON line per variant.
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/rows scripts/microbench/rows.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t hash32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
+
+enum { M_LOAD = 1, M_STORE = 2 };
+// FORM: 0 = sc1 8 B/lane (one row per instruction), 1 = plain 8 B/lane, 2 = sc1 16 B/lane with two rows per instruction (half-wave
+// each), 3 = plain 16 B two rows per instruction, 4 = nt 8 B, 5 = atomic add f32 (2 per lane per row) for the store side + sc1 8 B loads
+template <int FORM, int MODE, int U>
+__global__ __launch_bounds__(64) void rows_kernel(float *T, uint32_t nrows, int iters, float *sink)
+{
+    const int lane = threadIdx.x;
+    const uint32_t wave = blockIdx.x;
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        uint32_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = (uint32_t)(((uint64_t)hash32(wave * 0x9E3779B9u + it * U + u + 1) * nrows) >> 32);
+        if constexpr (FORM == 0 || FORM == 1 || FORM == 4 || FORM == 5) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float *p = T + (size_t)r[u] * 128 + lane * 2;
+                if constexpr (MODE & M_LOAD) {
+                    if constexpr (FORM == 0 || FORM == 5) { unsigned long long t = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v[u].x = __builtin_bit_cast(float, (unsigned)t); v[u].y = __builtin_bit_cast(float, (unsigned)(t >> 32)); }
+                    else if constexpr (FORM == 4) { v[u].x = __builtin_nontemporal_load(p); v[u].y = __builtin_nontemporal_load(p + 1); }
+                    else v[u] = *reinterpret_cast<float2 *>(p);
+                } else v[u] = make_float2((float)it, (float)lane);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc += v[u].x;
+                v[u].x += 1.0f; v[u].y -= 1.0f;
+                float *p = T + (size_t)r[u] * 128 + lane * 2;
+                if constexpr (MODE & M_STORE) {
+                    if constexpr (FORM == 0) { unsigned long long t = (unsigned long long)__builtin_bit_cast(unsigned, v[u].x) | ((unsigned long long)__builtin_bit_cast(unsigned, v[u].y) << 32); __hip_atomic_store((gu64 *)p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    else if constexpr (FORM == 4) { __builtin_nontemporal_store(v[u].x, p); __builtin_nontemporal_store(v[u].y, p + 1); }
+                    else if constexpr (FORM == 5) { __hip_atomic_fetch_add(p, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(p + 1, -1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    else *reinterpret_cast<float2 *>(p) = v[u];
+                }
+            }
+        } else {
+            // two rows per instruction: lanes 0-31 row r[2k], lanes 32-63 row r[2k+1], 16 B per lane
+            static_assert(U % 2 == 0, "U even");
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(T, 0, (int)0x7fffffff, 0x00020000);
+            u32x4v v[U / 2];
+            const int half = lane >> 5, l = lane & 31;
+#pragma unroll
+            for (int u = 0; u < U / 2; ++u) {
+                const uint32_t row = half ? r[2 * u + 1] : r[2 * u];
+                const int off = (int)(row * 512u + l * 16u);
+                if constexpr (MODE & M_LOAD) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, FORM == 2 ? 16 : 0);
+                else v[u] = u32x4v{(unsigned)it, (unsigned)lane, 0u, 1u};
+            }
+#pragma unroll
+            for (int u = 0; u < U / 2; ++u) {
+                acc += __builtin_bit_cast(float, v[u].x);
+                v[u].x += 1u;
+                const uint32_t row = half ? r[2 * u + 1] : r[2 * u];
+                const int off = (int)(row * 512u + l * 16u);
+                if constexpr (MODE & M_STORE) __builtin_amdgcn_raw_buffer_store_b128(v[u], rs, off, 0, FORM == 2 ? 16 : 0);
+            }
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+template <int FORM, int MODE, int U>
+void run(const char *name, float *T, uint32_t nrows, float *sink, int waves_per_cu)
+{
+    const int waves = 256 * waves_per_cu;
+    const int iters = 20000 / U;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((rows_kernel<FORM, MODE, U>), dim3(waves), dim3(64), 0, 0, T, nrows, iters / 10, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL((rows_kernel<FORM, MODE, U>), dim3(waves), dim3(64), 0, 0, T, nrows, iters, sink);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
+    const double rows = (double)waves * iters * U;
+    const double xfers = rows * (((MODE & M_LOAD) ? 1 : 0) + ((MODE & M_STORE) ? 1 : 0));
+    printf("{\"variant\": \"%s\", \"rows_in_flight\": %d, \"waves_per_cu\": %d, \"ms\": %.3f, \"Mrows_per_s\": %.1f, \"TBps\": %.3f}\n", name, U, waves_per_cu, ms,
+           rows / ms / 1e3, xfers * 512.0 / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
+
+// Software-pipelined read-modify-write like the SGNS kernel: the U rows of iteration it+D are requested before the U rows of
+// iteration it are written back (D = 0: load, wait, store).  sc1 8-byte accesses.
+template <int D, int U>
+__global__ __launch_bounds__(64) void rows_pipe_kernel(float *T, uint32_t nrows, int iters, float *sink)
+{
+    const int lane = threadIdx.x;
+    const uint32_t wave = blockIdx.x;
+    float2 v[D + 1][U];
+    auto rowof = [&](int it, int u) { return (uint32_t)(((uint64_t)hash32(wave * 0x9E3779B9u + it * U + u + 1) * nrows) >> 32); };
+    auto ld = [&](int it, float2 (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float *p = T + (size_t)rowof(it, u) * 128 + lane * 2;
+            unsigned long long t = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x[u].x = __builtin_bit_cast(float, (unsigned)t); x[u].y = __builtin_bit_cast(float, (unsigned)(t >> 32));
+        }
+    };
+    auto st = [&](int it, float2 (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float *p = T + (size_t)rowof(it, u) * 128 + lane * 2;
+            x[u].x += 1.0f; x[u].y -= 1.0f;
+            unsigned long long t = (unsigned long long)__builtin_bit_cast(unsigned, x[u].x) | ((unsigned long long)__builtin_bit_cast(unsigned, x[u].y) << 32);
+            __hip_atomic_store((gu64 *)p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    static_assert(D <= 2, "D");
+    if constexpr (D == 0) {
+        for (int it = 0; it < iters; ++it) { ld(it, v[0]); st(it, v[0]); }
+    } else if constexpr (D == 1) {
+        ld(0, v[0]);
+        for (int it = 0; it < iters; it += 2) {
+            ld(it + 1, v[1]); st(it, v[0]);
+            ld(it + 2, v[0]); st(it + 1, v[1]);
+        }
+    } else {
+        ld(0, v[0]); ld(1, v[1]);
+        for (int it = 0; it < iters; it += 3) {
+            ld(it + 2, v[2]); st(it, v[0]);
+            ld(it + 3, v[0]); st(it + 1, v[1]);
+            ld(it + 4, v[1]); st(it + 2, v[2]);
+        }
+    }
+    if (v[0][0].x == 12345.678f) sink[0] = v[0][0].x;
+}
+
+template <int D, int U>
+void run_pipe(const char *name, float *T, uint32_t nrows, float *sink, int waves_per_cu)
+{
+    const int waves = 256 * waves_per_cu;
+    const int iters = 3996;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((rows_pipe_kernel<D, U>), dim3(waves), dim3(64), 0, 0, T, nrows, 396, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL((rows_pipe_kernel<D, U>), dim3(waves), dim3(64), 0, 0, T, nrows, iters, sink);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
+    const double rows = (double)waves * iters * U;
+    printf("{\"variant\": \"%s\", \"store_delay_iters\": %d, \"rows_per_iter\": %d, \"waves_per_cu\": %d, \"ms\": %.3f, \"Mrows_per_s\": %.1f, \"TBps\": %.3f}\n", name, D, U,
+           waves_per_cu, ms, rows / ms / 1e3, 2 * rows * 512.0 / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const uint32_t nrows = 2000000;       // 1 GB: SynPos + SynNeg of the headline config
+    float *T, *sink;
+    CK(hipMalloc(&T, (size_t)nrows * 512)); CK(hipMemset(T, 0, (size_t)nrows * 512)); CK(hipMalloc(&sink, 64));
+    if (argc > 1) {
+        for (int w : {6, 12}) {
+            run_pipe<0, 5>("sc1_8B_rmw_pipe", T, nrows, sink, w);
+            run_pipe<1, 5>("sc1_8B_rmw_pipe", T, nrows, sink, w);
+            run_pipe<2, 5>("sc1_8B_rmw_pipe", T, nrows, sink, w);
+            run_pipe<0, 10>("sc1_8B_rmw_pipe", T, nrows, sink, w);
+            run_pipe<1, 10>("sc1_8B_rmw_pipe", T, nrows, sink, w);
+        }
+        return 0;
+    }
+    for (int w : {4, 8, 16}) {
+        run<0, M_LOAD, 6>("sc1_8B_load", T, nrows, sink, w);
+        run<0, M_STORE, 6>("sc1_8B_store", T, nrows, sink, w);
+        run<0, M_LOAD | M_STORE, 6>("sc1_8B_rmw", T, nrows, sink, w);
+        run<1, M_LOAD, 6>("plain_8B_load", T, nrows, sink, w);
+        run<1, M_STORE, 6>("plain_8B_store", T, nrows, sink, w);
+        run<1, M_LOAD | M_STORE, 6>("plain_8B_rmw", T, nrows, sink, w);
+        run<2, M_LOAD, 6>("sc1_16B_2rows_load", T, nrows, sink, w);
+        run<2, M_STORE, 6>("sc1_16B_2rows_store", T, nrows, sink, w);
+        run<2, M_LOAD | M_STORE, 6>("sc1_16B_2rows_rmw", T, nrows, sink, w);
+        run<3, M_LOAD | M_STORE, 6>("plain_16B_2rows_rmw", T, nrows, sink, w);
+        run<4, M_LOAD | M_STORE, 6>("nt_8B_rmw", T, nrows, sink, w);
+        run<5, M_LOAD | M_STORE, 6>("sc1_8B_load_atomic_add_store", T, nrows, sink, w);
+        run<0, M_LOAD | M_STORE, 12>("sc1_8B_rmw_u12", T, nrows, sink, w);
+        run<2, M_LOAD | M_STORE, 12>("sc1_16B_2rows_rmw_u12", T, nrows, sink, w);
+    }
+    return 0;
+}

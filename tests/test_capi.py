@@ -158,3 +158,17 @@ def test_host_partial_eigensolver():
     G = np.diag(np.concatenate([np.linspace(1, 0.3, 80), 0.2 * rng.rand(210)])); E = 1e-3 * rng.randn(290, 290)
     check(G + E + E.T, 80)                                         # what a restarted Rayleigh-Ritz matrix looks like
     assert L.gemhip_sym_eig_top(4, None, 2, None, None) != 0
+
+
+def test_gf_plan_rejects_edge_orders_the_reference_loop_cannot_be_scheduled_for():
+    """gf.cpp:152-164 walks the file in order; (1,2),(0,1),(1,3) makes row 0 read row 1 between row 1's two updates, which the
+    two-table schedule cannot express: GEMHIP_E_INVALID with a message, never a silently different result (validation only:
+    the call returns before touching the device)."""
+    import ctypes as C
+    import numpy as np
+    L = _hip.lib()
+    src = np.array([1, 0, 1], np.int32); dst = np.array([2, 1, 3], np.int32)
+    plan = C.c_void_p()
+    rc = L.gemhip_gf_plan_create(4, 3, _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, 8, 0, 4, C.byref(plan))
+    assert rc == -1 and not plan.value
+    assert b'partly updated' in L.gemhip_last_error()

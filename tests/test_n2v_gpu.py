@@ -144,8 +144,8 @@ def test_sgns_deterministic_matches_oracle(gname, d, window, l, epochs, flags, r
                                                            ('karate', 16, 12, 9, -1, 0)])
 def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, delta, request):
     """The LDS-window kernel (default) and the round-1 kernel (flag 128) are the same algorithm: one wavefront in walk order gives
-    bit-identical tables when rows leave the window as they are (delta=0), whatever the cached radius; the delta write-back
-    (row_now + (working - loaded), what multi-wave launches use) differs by fp32 rounding only."""
+    the same tables up to fp32 summation order (2e-4, the bar of the oracle test), whatever the cached radius and whether rows
+    leave the window as they are (delta=0) or as row_now + (working - loaded) (what multi-wave launches use)."""
     G = request.getfixturevalue(gname)
     n, src, dst, w, _ = edge_arrays(G)
     dev = Dev(n, src, dst, w)
@@ -157,11 +157,8 @@ def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, del
     P0, N0 = dev.sgns(d, window, 1, 5, SNAP | 4 | _hip.N2V_NO_WINDOW_CACHE)
     _hip.check(dev.L.gemhip_sgns_set_window_cache(dev.h, radius, delta))
     P1, N1 = dev.sgns(d, window, 1, 5, SNAP | 4)
-    if delta == 0:
-        assert np.array_equal(P0, P1) and np.array_equal(N0, N1)
-    else:
-        for a, b in ((P0, P1), (N0, N1)):
-            assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(a).max())
+    for a, b in ((P0, P1), (N0, N1)):          # same algorithm; the fast path sums the six dot products in a different tree order
+        assert float(np.abs(a - b).max()) <= 2e-4 * float(np.abs(a).max()) + 1e-6
     dev.close()
 
 
@@ -183,6 +180,17 @@ def test_sgns_window_cache_hogwild_quality(sbm1024):
     assert res['r1'][1] == res['win'][1] == res['win4'][1]
     for k in ('win', 'win4'):
         assert abs(res[k][0] - res['r1'][0]) <= 0.05 * res['r1'][0], res
+
+
+def test_wave_sum6_building_block():
+    """The six-way transposed wave reduction of the SGNS fast path: lane l gets the total of value (l&4) ? 4+(l&1) : (l&3)."""
+    rng = np.random.RandomState(3)
+    x = rng.randn(64, 6).astype(np.float32)
+    out = np.empty(64, np.float32)
+    _hip.check(_hip.lib().gemhip_test_wave_sum6(_hip.ptr(x, C.c_float), _hip.ptr(out, C.c_float)))
+    tot = x.astype(np.float64).sum(axis=0)
+    idx = np.where(np.arange(64) & 4, 4 + (np.arange(64) & 1), np.arange(64) & 3)
+    assert np.allclose(out, tot[idx], rtol=0, atol=2e-5)
 
 
 def test_init_tables_bit_exact():
