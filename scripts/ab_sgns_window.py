@@ -2,7 +2,7 @@
 time per launch, algorithmic TB/s, and the reconstruction MAP over a fixed 256-node sample for every variant.
     python scripts/ab_sgns_window.py [r] [nodes] [edges] [blocks]
 Variants: (label, flags, radius, delta, max_waves)."""
-import sys, time, json, ctypes as C
+import os, sys, time, json, ctypes as C
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from gem_amd import _hip, multi_gpu
@@ -12,7 +12,7 @@ r = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 edges = int(sys.argv[3]) if len(sys.argv) > 3 else 10000000
 blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 100
-variants = [('r1_kernel', 11 | 128, 0, -1, 0), ('win_R10_delta', 11, 10, 1, 0), ('win_R10_overwrite', 11, 10, 0, 0),
+variants = [('r1_kernel', 11 | 128, 0, -1, 0), ('duo_delta', 11, 10, 1, 0, 1), ('duo_overwrite', 11, 10, 0, 0, 1), ('win_R10_delta', 11, 10, 1, 0), ('win_R10_overwrite', 11, 10, 0, 0),
             ('win_R7_delta', 11, 7, 1, 0), ('win_R5_delta', 11, 5, 1, 0), ('win_R10_delta_w1024', 11, 10, 1, 1024)]
 if len(sys.argv) > 5:
     keep = sys.argv[5].split(',')
@@ -27,7 +27,9 @@ sample = np.random.RandomState(0).choice(n, size=256, replace=False)
 out = []
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 for rep in range(reps):
-    for name, flags, R, delta, mw in variants:
+    for v in variants:
+        name, flags, R, delta, mw = v[:5]
+        os.environ['GEMHIP_SGNS_DUO'] = '1' if len(v) > 5 else '0'
         _hip.check(L.gemhip_sgns_set_window_cache(b.h, R if R > 0 else -1, delta))
         _hip.check(L.gemhip_n2v_set_max_waves(b.h, mw))
         b.init_tables(20260923); b.pairs(reset=True)

@@ -12,7 +12,7 @@ for f in files:
     for row in csv.DictReader(open(f)):
         k = row.get('Kernel_Name', '')
         if kern in k:
-            short = k.split('(')[0][-60:]
+            short = k[:70]
             tot[(short, row['Counter_Name'])] += float(row['Counter_Value'])
             cnt[short].add(row.get('Dispatch_Id', ''))
 for (k, c), v in sorted(tot.items()):

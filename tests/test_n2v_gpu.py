@@ -142,10 +142,12 @@ def test_sgns_deterministic_matches_oracle(gname, d, window, l, epochs, flags, r
                                                            ('sbm1024', 128, 10, 40, -1, 0), ('sbm1024', 128, 10, 40, 4, 0),
                                                            ('sbm1024', 128, 10, 40, -1, 1), ('karate', 256, 5, 20, 5, 1),
                                                            ('karate', 16, 12, 9, -1, 0)])
-def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, delta, request):
+@pytest.mark.parametrize('duo', [0, 1])
+def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, delta, duo, request, monkeypatch):
     """The LDS-window kernel (default) and the round-1 kernel (flag 128) are the same algorithm: one wavefront in walk order gives
     the same tables up to fp32 summation order (2e-4, the bar of the oracle test), whatever the cached radius and whether rows
     leave the window as they are (delta=0) or as row_now + (working - loaded) (what multi-wave launches use)."""
+    monkeypatch.setenv('GEMHIP_SGNS_DUO', str(duo))        # 1: trainer + helper wavefronts (applies when the whole window is cached)
     G = request.getfixturevalue(gname)
     n, src, dst, w, _ = edge_arrays(G)
     dev = Dev(n, src, dst, w)
