@@ -10,6 +10,9 @@ that is already resident in HBM when the timed region starts:
               BASELINE.json quotes its metric on this graph (configs[3]); edges/sec =
               graph.number_of_edges() / wall of the pass.
     gf        one SGD sweep over all edges of the same SBM, d=128; edges/sec = edges x sweeps / wall.
+With no --workload the headline workload (node2vec) is timed first and the other two BASELINE configurations follow in the
+same process -- GF on SBM 10k/100k with examples/run_sbm.py:66's eta/lambda (configs[1]) and on the 1M/10M graph, HOPE on SBM
+100k/1M (configs[2]) -- each with its own timed region, roofline and cpu_baseline under "workloads" of the one JSON line.
 For N>1 launch with torch.distributed.run (one rank per GPU, RCCL).  Both paths shard by SOURCE /
 START NODE (gem_amd/multi_gpu.py; node2vec additionally partitions its tables over the ranks): total work is
 fixed => "scaling": "strong".
@@ -42,16 +45,18 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achieva
 
 def pmc_traffic(kernel, key):
     """HBM bytes per unit measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/*_pmc_traffic.json,
-    corrected as MI355X_MICROARCH.md prescribes); bench.py scales it to the units one launch processes."""
-    best = None
+    corrected as MI355X_MICROARCH.md prescribes); bench.py scales it to the units one launch processes.  Returns (value, source):
+    the figure is REPLAYED from the newest committed profile, not measured in this run."""
+    best, src = None, None
     pdir = os.path.join(ROOT, 'profiles')
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if f.endswith('_pmc_traffic.json'):
             try:
                 best = json.load(open(os.path.join(pdir, f)))[kernel][key]
+                src = 'profiles/%s (separate rocprofv3 --pmc passes of the same kernel, replayed per unit; not measured in this run)' % f
             except (KeyError, ValueError):
                 pass
-    return best
+    return best, src
 
 
 def log(*a):
@@ -77,9 +82,10 @@ class GFWorkload(object):
     default_steps, default_warmup = 50, 5
 
     def __init__(self, args, rank, world, comm):
-        self.name = '%s%dk_%dk_gf_d%d' % (args.graph, args.nodes // 1000, args.edges // 1000, args.d)
+        self.name = '%s%dk_%dk_gf_d%d_eta%g_regu%g' % (args.graph, args.nodes // 1000, args.edges // 1000, args.d, args.gf_eta, args.gf_regu)
         self.world, self.d = world, args.d
-        self.eta, self.regu = 1e-2, 1e-2      # "trainable" setting; arithmetic per edge identical to run_sbm.py's
+        # default: the "trainable" setting; --gf-eta 1e-4 --gf-regu 1.0 is examples/run_sbm.py:66's (same arithmetic per edge)
+        self.eta, self.regu = args.gf_eta, args.gf_regu
         g = make_graph(args)
         self.n_edges = g.number_of_edges()
         n, src, dst, w, _ = edge_arrays(g)
@@ -111,9 +117,9 @@ class GFWorkload(object):
         algo = self.b.algo_bytes / self.b.levels        # 1548 B x updates
         compulsory = (self.b.rows * 2 * 4 * self.d + self.b.updates * (4 * self.d + 8)) / self.b.levels
         ach = algo / avg_s / 1e9
-        per_upd = pmc_traffic(self.kernel, 'traffic_bytes_per_update')
+        per_upd, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_update')
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': None if per_upd is None else per_upd * self.b.updates / self.b.levels,
+                'traffic': None if per_upd is None else per_upd * self.b.updates / self.b.levels, 'traffic_source': tsrc,
                 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
                 'note': 'algorithmic = 1548 B/update (X_i r+w, X_j r per update); the kernel keeps X_i in registers for a whole row, '
                         'so its compulsory HBM bytes are %.3g per launch = %.0f GB/s' % (compulsory, compulsory / avg_s / 1e9)}
@@ -128,6 +134,15 @@ class GFWorkload(object):
         return {'value': self.n_edges * sweeps / el, 'unit': self.unit, 'cores': 1, 'kind': 'port',
                 'sample': '%d sweeps of the same %d-edge graph, oracle/gf_oracle.c (gf.cpp:152-164 restated; the reference loop is '
                           'single-threaded)' % (sweeps, self.n_edges)}
+
+    def reset_counters(self):
+        if self.world > 1:
+            self.job.comm_seconds(reset=True)
+
+    def phase_split(self, steps):
+        comm = self.job.comm_seconds(reset=False)
+        return {'exchange_seconds_per_sweep': comm / steps, 'exchange': 'halo all-to-all' if self.job.halo else 'all-gather',
+                'halo_rows_per_rank': self.job.halo_rows}
 
     def check(self):
         assert bool(torch.isfinite(self.last).all()), 'non-finite embedding'
@@ -174,6 +189,13 @@ class N2VWorkload(object):
     def units_per_step(self):
         return self.n_edges
 
+    def phase_split(self, steps):
+        ph = self.job.phase_seconds() if hasattr(self.job, 'phase_seconds') else None
+        if not ph:
+            return None
+        return {'last_step_seconds': ph, 'note': 'HIP events of the last pass on this rank: training rounds and SynNeg ring shifts are serial on the '
+                'training stream; pair emission + all-to-all run one episode ahead on a side stream (overlapped)'}
+
     def roofline(self, dev_ms_total, steps):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in self.evs)
@@ -183,37 +205,57 @@ class N2VWorkload(object):
         algo = (14 * 4 * self.args.d + 24) * pairs / launches       # 14*4d B per (centre,context) pair + ids
         ach = algo / avg_s / 1e9
         tokens = (self.job.hi - self.job.lo) * self.args.walk_len
-        per_pair = pmc_traffic(self.kernel, 'traffic_bytes_per_pair')
+        per_pair, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_pair')
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': None if per_pair is None else per_pair * pairs / launches, 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
+                'traffic': None if per_pair is None else per_pair * pairs / launches, 'traffic_source': tsrc, 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
                 'pairs_per_launch': pairs / launches, 'tokens_per_launch': tokens,
                 'sgns_fraction_of_step': ms / dev_ms_total,
                 'note': 'algorithmic = 7168+24 B per (centre,context) pair at d=128 (SynPos r+w, 6 x SynNeg r+w); the kernel keeps the '
                         'positive SynNeg row in registers across a centre\'s contexts (12/14 of that reaches memory)'}
 
     def cpu_baseline(self, budget_s=25.0):
-        """The real reference binary (oracle/_ref/node2vec = gem/c_exe/node2vec) on a bounded sample: a
-        2048-node SBM of the same density, same r/l/k/d, all host cores (how GEM runs it).
-        SGNS cost is linear in tokens, so edges/s carries over (tokens/edge identical)."""
+        """The real reference binary (oracle/_ref/node2vec = gem/c_exe/node2vec) on a bounded sample: a 2048-node SBM of the same
+        density and block size, same r/l/k/d, run twice -- on all host cores (how GEM runs it: racy Hogwild, its MAP collapses) and
+        on ONE thread (race-free: the quality the reference is meant to have).  SGNS cost is linear in tokens, so edges/s carries
+        over to the full graph (tokens/edge identical).  `value` is the all-cores rate; both rates and both MAPs are reported."""
         import oracle
-        from gem_amd.utils import graph_util
+        from gem_amd.embedding.node2vec import node2vec
+        from gem_amd.evaluation import reconstruction as gr
         a = self.args
-        n_s = 2048            # SNAP needs ~11 s for 1024 nodes on 8 cores (SURVEY 6): keep the sample ~20-30 s
+        n_s = 2048
         gs = sbm_graph(n_s, n_s * (a.edges // a.nodes), max(1, n_s // (a.nodes // a.blocks)), seed=7)
         cores = min(os.cpu_count() or 1, 16)    # SNAP's dynamic OpenMP loop gets SLOWER beyond a few threads on small graphs
+        model = node2vec(d=a.d, max_iter=1, walk_len=a.walk_len, num_walks=a.num_walks, con_size=a.window, ret_p=1, inout_p=1)
         if os.path.exists(oracle.REF_N2V):
             tmp = tempfile.mkdtemp()
             gf = os.path.join(tmp, 'g.graph')
             with open(gf, 'w') as fh:
                 fh.writelines('%d %d %f\n' % (i, j, 1.0) for i, j in zip(gs.src.tolist(), gs.dst.tolist()))
-            t = time.time()
-            subprocess.call([oracle.REF_N2V, '-i:' + gf, '-o:' + os.path.join(tmp, 'g.emb'), '-d:%d' % a.d, '-l:%d' % a.walk_len,
-                             '-r:%d' % a.num_walks, '-k:%d' % a.window, '-e:1', '-p:1.000000', '-q:1.000000', '-dr', '-w'],
-                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS=str(cores)))
-            el = time.time() - t
-            return {'value': gs.number_of_edges() / el, 'unit': self.unit, 'cores': cores, 'kind': 'reference',
+            runs = {}
+            for thr in (cores, 1):
+                emb = os.path.join(tmp, 'g%d.emb' % thr)
+                t = time.time()
+                subprocess.call([oracle.REF_N2V, '-i:' + gf, '-o:' + emb, '-d:%d' % a.d, '-l:%d' % a.walk_len,
+                                 '-r:%d' % a.num_walks, '-k:%d' % a.window, '-e:1', '-p:1.000000', '-q:1.000000', '-dr', '-w'],
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS=str(thr)))
+                el = time.time() - t
+                X = np.zeros((n_s, a.d))
+                with open(emb) as fh:
+                    fh.readline()
+                    for line in fh:
+                        tok = line.split()
+                        X[int(tok[0])] = [float(v) for v in tok[1:]]
+                runs[thr] = {'edges_per_s': gs.number_of_edges() / el, 'seconds': el, 'threads': thr,
+                             'MAP': gr.evaluateStaticGraphReconstruction(gs, model, X, None)[0]}
+            # the HIP path on the very same sample graph (outside every timed region): the MAP the baselines are to be compared with
+            mh = node2vec(d=a.d, max_iter=1, walk_len=a.walk_len, num_walks=a.num_walks, con_size=a.window, ret_p=1, inout_p=1, seed=20260923)
+            Xh = mh.learn_embedding(graph=gs, is_weighted=True, no_python=True)
+            return {'value': runs[cores]['edges_per_s'], 'unit': self.unit, 'cores': cores, 'kind': 'reference',
+                    'all_cores': runs[cores], 'single_thread_race_free': runs[1],
+                    'hip_map_same_sample': gr.evaluateStaticGraphReconstruction(gs, mh, Xh, None)[0],
                     'sample': 'gem/c_exe/node2vec (SNAP ELF) end to end incl. its text IO on an SBM with %d nodes / %d edges (same '
-                              'density, block size, d, r, l, k), %.1fs' % (n_s, gs.number_of_edges(), el)}
+                              'density, block size, d, r, l, k): %d threads %.1fs, 1 thread %.1fs; MAP = graph reconstruction over all nodes of '
+                              'the sample' % (n_s, gs.number_of_edges(), cores, runs[cores]['seconds'], runs[1]['seconds'])}
         n, src, dst, w, _ = edge_arrays(gs)
         t = time.time()
         oracle.n2v_train(n, src, dst, None, a.d, a.walk_len, 1, a.window, 1, 1.0, 1.0, 1, 11)
@@ -225,14 +267,34 @@ class N2VWorkload(object):
         assert bool(torch.isfinite(self.P).all()), 'non-finite embedding'
         assert float(self.P.abs().max()) > 1e-3
 
-    def quality(self, nsample=256):
-        """Outside the timed region: graph-reconstruction MAP of the learned table over a node sample, with the reference
-        evaluator's semantics (gem_amd/csrc/eval.hip) -- shows the timed pass really trained the embedding."""
+    def quality(self, nsample=1024):
+        """Outside the timed region: graph-reconstruction MAP of the learned table over a FIXED node sample, with the reference
+        evaluator's semantics (gem_amd/csrc/eval.hip), next to the MAP the reference binary reaches on the very same graph and
+        sample (tests/golden/n2v_ref_snap_<n>k.json, made by scripts/make_golden_n2v_scale.py: gem/c_exe/node2vec race-free)."""
         from gem_amd.evaluation import reconstruction as gr
+        a = self.args
         rng = np.random.RandomState(0)
         nodes = rng.choice(self.g.n, size=min(nsample, self.g.n), replace=False)        # uniform over all nodes, hubs included
         ap = gr.sampled_ap_gpu(self.g, None, self.P.cpu().numpy(), nodes)
-        return {'sampled_map': float(ap.mean()), 'nodes_sampled': int(len(nodes)), 'evaluator': 'metrics.computeMAP semantics on the GPU'}
+        out = {'sampled_map': float(ap.mean()), 'sampled_map_se': float(ap.std(ddof=1) / np.sqrt(len(ap))), 'nodes_sampled': int(len(nodes)),
+               'evaluator': 'metrics.computeMAP semantics on the GPU', 'reference_map': None}
+        for engine, key in (('snap', 'reference_map'), ('oracle', 'oracle_map')):
+            path = os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_%s_%dk.json' % (engine, self.g.n // 1000))
+            if a.graph == 'sbm' and os.path.exists(path):
+                ref = json.load(open(path))
+                pr = ref['params']
+                if (pr['n'], pr['edges'], pr['blocks'], pr['seed'], pr['d'], pr['walk_len'], pr['num_walks'], pr['window']) == \
+                        (a.nodes, a.edges, a.blocks, 20260923 + 4, a.d, a.walk_len, a.num_walks, a.window) and len(ref['ap']) == len(ap):
+                    out[key] = ref['MAP']
+                    out[key + '_se'] = ref['MAP_se']
+                    out[key + '_source'] = 'tests/golden/%s: %s, same graph, same %d-node sample' % (os.path.basename(path), ref['engine'], len(ap))
+                    d = ap - np.asarray(ref['ap'])
+                    out['map_minus_' + key] = float(d.mean())
+                    out['map_minus_' + key + '_se'] = float(d.std(ddof=1) / np.sqrt(len(d)))
+        if out['reference_map'] is None:
+            out['reference_map_note'] = ('no committed reference run for this graph size; the largest one is tests/golden/n2v_ref_snap_100k.json '
+                                         '(python bench.py --nodes 100000 --edges 1000000 --blocks 10 reports against it)')
+        return out
 
 
 class HopeWorkload(object):
@@ -321,46 +383,12 @@ class HopeWorkload(object):
 WORKLOADS = {'gf': GFWorkload, 'node2vec': N2VWorkload, 'hope': HopeWorkload}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None)
-    ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--workload', default=os.environ.get('GEM_BENCH_WORKLOAD', 'node2vec'), choices=sorted(WORKLOADS))
-    ap.add_argument('--nodes', type=int, default=1000000)
-    ap.add_argument('--edges', type=int, default=10000000)
-    ap.add_argument('--blocks', type=int, default=100)
-    ap.add_argument('--graph', default='sbm', choices=['sbm', 'rmat'])
-    ap.add_argument('--d', type=int, default=128)
-    ap.add_argument('--num-walks', type=int, default=10)
-    ap.add_argument('--walk-len', type=int, default=80)
-    ap.add_argument('--window', type=int, default=10)
-    ap.add_argument('--episodes', type=int, default=64, help='N>1 node2vec: episodes of the partitioned schedule')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
-
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
-    local = local % torch.cuda.device_count()      # (lets the N>1 code path be exercised on a 1-GPU box with GEM_BENCH_BACKEND=gloo)
-    torch.cuda.set_device(local)
-    _hip.check(_hip.lib().gemhip_set_device(local))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = os.environ.get('GEM_BENCH_BACKEND', 'nccl')          # "nccl" is RCCL on ROCm
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        log('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world))
-
-    comm = multi_gpu.TorchComm(world)
-    wl = WORKLOADS[args.workload](args, rank, world, comm)
-    K = args.steps if args.steps is not None else wl.default_steps
-    W = args.warmup if args.warmup is not None else wl.default_warmup
+def time_workload(name, args, rank, world, comm, K=None, W=None, with_cpu=True):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
+    Returns (result dict on rank 0 else None, workload)."""
+    wl = WORKLOADS[name](args, rank, world, comm)
+    K = K if K is not None else wl.default_steps
+    W = W if W is not None else wl.default_warmup
 
     def barrier():
         if world > 1:
@@ -390,22 +418,88 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
+    if rank != 0:
+        return None, wl
+    out = {
+        'metric': wl.metric, 'value': wl.units_per_step() * K / el, 'unit': wl.unit, 'n_gpus': world, 'steps': K, 'warmup': W,
+        'ms_per_step': el * 1e3 / K, 'higher_is_better': True,
+        'scaling': 'weak' if (world == 1 or name == 'hope') else 'strong',
+        'vs_baseline': None, 'dtype': wl.dtype, 'data': 'synthetic',
+        'config': {'workload': wl.name, 'nodes': args.nodes, 'directed_edges': wl.n_edges, 'd': args.d,
+                   'sharding': 'source-node x%d' % world},
+    }
+    if world > 1:
+        out['config']['world_size_seen'] = dist.get_world_size()
+        if hasattr(wl, 'phase_split'):
+            out['phases'] = wl.phase_split(K)
+    if hasattr(wl, 'quality'):
+        out['quality'] = wl.quality()
+    if world == 1:
+        out['roofline'] = wl.roofline(dev_ms, K)
+        if with_cpu:
+            out['cpu_baseline'] = wl.cpu_baseline()
+    return out, wl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--workload', default=os.environ.get('GEM_BENCH_WORKLOAD', 'all'), choices=sorted(WORKLOADS) + ['all'],
+                    help="'all' (default) = node2vec (the headline line) followed by gf and hope under \"workloads\"")
+    ap.add_argument('--nodes', type=int, default=1000000)
+    ap.add_argument('--edges', type=int, default=10000000)
+    ap.add_argument('--blocks', type=int, default=100)
+    ap.add_argument('--graph', default='sbm', choices=['sbm', 'rmat'])
+    ap.add_argument('--d', type=int, default=128)
+    ap.add_argument('--num-walks', type=int, default=10)
+    ap.add_argument('--walk-len', type=int, default=80)
+    ap.add_argument('--window', type=int, default=10)
+    ap.add_argument('--gf-eta', type=float, default=1e-2)
+    ap.add_argument('--gf-regu', type=float, default=1e-2)
+    ap.add_argument('--episodes', type=int, default=64, help='N>1 node2vec: episodes of the partitioned schedule')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    local = local % torch.cuda.device_count()      # (lets the N>1 code path be exercised on a 1-GPU box with GEM_BENCH_BACKEND=gloo)
+    torch.cuda.set_device(local)
+    _hip.check(_hip.lib().gemhip_set_device(local))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = os.environ.get('GEM_BENCH_BACKEND', 'nccl')          # "nccl" is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.gpus != world and rank == 0:
+        log('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world))
+
+    comm = multi_gpu.TorchComm(world)
+    headline = 'node2vec' if args.workload == 'all' else args.workload
+    out, wl = time_workload(headline, args, rank, world, comm, args.steps, args.warmup, with_cpu=not args.no_cpu_baseline)
+
+    if args.workload == 'all' and world == 1 and (args.nodes, args.edges, args.graph) == (1000000, 10000000, 'sbm'):
+        # the other two BASELINE configurations, each with its own timed region (their step counts are their own defaults)
+        del wl
+        torch.cuda.empty_cache()
+        import copy
+        extra = {}
+        a2 = copy.copy(args); a2.nodes, a2.edges, a2.blocks, a2.gf_eta, a2.gf_regu = 10000, 100000, 10, 1e-4, 1.0
+        extra['gf_sbm10k_100k_run_sbm_setting'], w2 = time_workload('gf', a2, rank, world, comm, 1000, 100, with_cpu=not args.no_cpu_baseline)
+        del w2
+        extra['gf_sbm1m_10m'], w3 = time_workload('gf', copy.copy(args), rank, world, comm, None, None, with_cpu=not args.no_cpu_baseline)
+        del w3
+        torch.cuda.empty_cache()
+        extra['hope_sbm100k_1m'], w4 = time_workload('hope', copy.copy(args), rank, world, comm, None, None, with_cpu=not args.no_cpu_baseline)
+        out['workloads'] = extra
 
     if rank == 0:
-        out = {
-            'metric': wl.metric, 'value': wl.units_per_step() * K / el, 'unit': wl.unit, 'n_gpus': world, 'steps': K, 'warmup': W,
-            'ms_per_step': el * 1e3 / K, 'higher_is_better': True,
-            'scaling': 'weak' if (world == 1 or args.workload == 'hope') else 'strong',
-            'vs_baseline': None, 'dtype': wl.dtype, 'data': 'synthetic',
-            'config': {'workload': wl.name, 'nodes': args.nodes, 'directed_edges': wl.n_edges, 'd': args.d,
-                       'sharding': 'source-node x%d' % world},
-        }
-        if hasattr(wl, 'quality'):
-            out['quality'] = wl.quality()
-        if world == 1:
-            out['roofline'] = wl.roofline(dev_ms, K)
-            if not args.no_cpu_baseline:
-                out['cpu_baseline'] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -86,6 +86,7 @@ struct gemhip_n2v {
     int32_t cache_radius = -1;        // sgns_win_kernel LDS window radius: -1 auto, 0 = off (sgns_kernel)
     int32_t cache_delta = -1;         // -1 auto, 0 overwrite on leave, 1 delta write-back
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
+    unsigned long long *d_bcnt = nullptr;               // emit_pairs_bucketed: bucket sizes [64*64] + cursors [64*64]
     int32_t sgns_duo = 0;             // 1: two-wavefront (trainer + helper) kernel where it applies; 0 (default): single-wavefront window kernel
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
     // per-partition unigram tables (multi-GPU episode schedule): partition p = {v : v % parts == p}, local index v / parts
@@ -1741,6 +1742,23 @@ __global__ __launch_bounds__(256) void sgns_emit_pairs_kernel(const int32_t *__r
 // (counting sort: a count pass, an exclusive scan on the host, a fill pass).  Per workgroup an LDS histogram reserves one
 // contiguous range per bucket with ONE global atomic per bucket; lanes then claim slots with LDS atomics.  This replaces two
 // device-wide argsorts per episode in the driver.
+// exclusive prefix of the bucket sizes (<= 64*64 of them): one wavefront, 64 buckets per pass
+__global__ void bucket_prefix_kernel(const unsigned long long *__restrict__ cnt, unsigned long long *__restrict__ cur, int nb)
+{
+    const int lane = threadIdx.x;
+    unsigned long long carry = 0;
+    for (int base = 0; base < nb; base += WAVE) {
+        const unsigned long long v = base + lane < nb ? cnt[base + lane] : 0ull;
+        unsigned long long incl = v;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const unsigned long long t = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += t;
+        }
+        if (base + lane < nb) cur[base + lane] = carry + incl - v;
+        carry += __shfl(incl, WAVE - 1, WAVE);
+    }
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void sgns_bucket_pairs_kernel(const int32_t *__restrict__ walks, int64_t walk_lo, int64_t walk_hi, int32_t walk_len,
                                                                 int32_t window, int32_t epoch, int64_t walk_id_offset, uint64_t seed, int32_t parts,
@@ -2024,7 +2042,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
 {
     if (!h) return GEMHIP_OK;
     hipFree(h->d_start);
-    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy);
+    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_bcnt);
     if (h->own_counts) hipFree(h->d_counts);
     hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
@@ -2282,34 +2300,25 @@ extern "C" int gemhip_sgns_emit_pairs_bucketed(gemhip_n2v_t h, int32_t window, i
     const int64_t ntok = (walk_hi - walk_lo) * h->walk_len;
     if (ntok == 0) return GEMHIP_OK;
     hipStream_t s = (hipStream_t)stream;
-    unsigned long long *d_cnt = nullptr;
-    GEMHIP_CHECK(hipMalloc((void **)&d_cnt, nb * sizeof(unsigned long long)));
-    int rc = GEMHIP_OK;
+    // bucket sizes and cursors stay on the device (persistent buffers of the handle; the exclusive prefix is a one-block kernel):
+    // count pass -> prefix -> fill pass queue back to back, the sizes reach the host with ONE synchronisation at the end
+    if (!h->d_bcnt) GEMHIP_CHECK(hipMalloc((void **)&h->d_bcnt, 2 * 64 * 64 * sizeof(unsigned long long)));
+    unsigned long long *d_cnt = h->d_bcnt, *d_cur = h->d_bcnt + 64 * 64;
     const dim3 grid((unsigned)((ntok + 255) / 256)), blk(256);
-    std::vector<unsigned long long> cnt(nb), cur(nb);
-    hipError_t e = hipMemsetAsync(d_cnt, 0, nb * sizeof(unsigned long long), s);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL((sgns_bucket_pairs_kernel<false>), grid, blk, 0, s, h->d_walks, walk_lo, walk_hi, h->walk_len, window, epoch, h->walk_id_offset,
-                           seed, parts, d_cnt, (int2 *)nullptr, (int64_t)0);
-        e = hipMemcpyAsync(cnt.data(), d_cnt, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e == hipSuccess) {
-        unsigned long long acc = 0;
-        for (int k = 0; k < nb; ++k) { cur[k] = acc; acc += cnt[k]; counts_host[k] = (int64_t)cnt[k]; }
-        if ((int64_t)acc > cap) rc = fail(GEMHIP_E_INVALID, "sgns_emit_pairs_bucketed: %llu pairs exceed the buffer capacity %lld", acc, (long long)cap);
-        else {
-            e = hipMemcpyAsync(d_cnt, cur.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL((sgns_bucket_pairs_kernel<true>), grid, blk, 0, s, h->d_walks, walk_lo, walk_hi, h->walk_len, window, epoch,
-                                   h->walk_id_offset, seed, parts, d_cnt, (int2 *)d_pairs, cap);
-                e = hipStreamSynchronize(s);          // `cur` is a host buffer; d_cnt is freed below
-            }
-        }
-    }
-    hipFree(d_cnt);
-    if (e != hipSuccess) return fail(GEMHIP_E_HIP, "sgns_emit_pairs_bucketed: %s", hipGetErrorString(e));
-    return rc;
+    std::vector<unsigned long long> cnt(nb);
+    GEMHIP_CHECK(hipMemsetAsync(d_cnt, 0, nb * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((sgns_bucket_pairs_kernel<false>), grid, blk, 0, s, h->d_walks, walk_lo, walk_hi, h->walk_len, window, epoch, h->walk_id_offset,
+                       seed, parts, d_cnt, (int2 *)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, s, d_cnt, d_cur, nb);
+    hipLaunchKernelGGL((sgns_bucket_pairs_kernel<true>), grid, blk, 0, s, h->d_walks, walk_lo, walk_hi, h->walk_len, window, epoch,
+                       h->walk_id_offset, seed, parts, d_cur, (int2 *)d_pairs, cap);          // writes are bounded by `cap` inside the kernel
+    GEMHIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    GEMHIP_CHECK(hipStreamSynchronize(s));
+    GEMHIP_CHECK(hipGetLastError());
+    unsigned long long acc = 0;
+    for (int k = 0; k < nb; ++k) { acc += cnt[k]; counts_host[k] = (int64_t)cnt[k]; }
+    if ((int64_t)acc > cap) return fail(GEMHIP_E_INVALID, "sgns_emit_pairs_bucketed: %llu pairs exceed the buffer capacity %lld", acc, (long long)cap);
+    return GEMHIP_OK;
 }
 
 extern "C" int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs, int32_t neg_part, void *dSynPos_part,

@@ -63,7 +63,7 @@ class TorchComm(object):
         self.dist.all_gather_into_tensor(out, v)
         return out.view(self.world, v.numel()).cpu().tolist()
 
-    def all_to_all_rows(self, send, send_counts, recv_counts=None):
+    def all_to_all_rows(self, send, send_counts, recv_counts=None, cached=False):
         """send: [m, c] rows grouped by destination rank (send_counts[r] rows for rank r, in rank order).
         Returns the rows addressed to this rank, grouped by source rank."""
         if self.world == 1:
@@ -151,13 +151,34 @@ class GFSharded(object):
         if self.world > 1:
             if self.halo is None and self._edges is not None:
                 self._plan_halo(new.device)
+            timed = bool(getattr(new, 'is_cuda', False))
+            if timed:
+                import torch
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             if self.halo:
                 send_idx, send_counts, need_idx, need_counts = self.halo
-                recv = self.comm.all_to_all_rows(new.index_select(0, send_idx), send_counts, need_counts)
+                recv = self.comm.all_to_all_rows(new.index_select(0, send_idx), send_counts, need_counts, cached=True)
                 new.index_copy_(0, need_idx, recv)
             else:
                 self.gather(new)
+            if timed:
+                e1.record()
+                self._comm_ev = getattr(self, '_comm_ev', [])
+                self._comm_ev.append((e0, e1))
         return new
+
+    def comm_seconds(self, reset=True):
+        """Device seconds spent in the per-sweep exchange (halo all-to-all or all-gather) since the last reset."""
+        evs = getattr(self, '_comm_ev', [])
+        if not evs:
+            return 0.0
+        import torch
+        torch.cuda.synchronize()
+        t = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+        if reset:
+            self._comm_ev = []
+        return t
 
     def gather(self, table):
         """All-gather of the owned row blocks: every rank ends with the full table (in place)."""
@@ -252,6 +273,27 @@ class Node2VecPartitioned(object):
     def _alpha(self, f):
         return self.alpha0 * max(1.0 - f, 1e-4)
 
+    def _prepare(self, ep, e):
+        """Everything of episode (ep, e) that does not touch the tables: materialise the (context, word) pairs of this slice of my
+        walks grouped by (context % W, word % W) on the device, exchange the bucket sizes, route the pairs to the owners of
+        their context rows (all-to-all).  Runs one episode AHEAD of the training rounds, on its own stream, so its host round
+        trips (bucket sizes -> split sizes of the all-to-all) never stall the stream that trains."""
+        b, comm, W, g = self.b, self.comm, self.world, self.rank
+        nloc = self.hi - self.lo
+        a, z = shard_range(nloc, e, self.episodes)
+        pairs, counts = b.emit_pairs_bucketed(self.window, ep, a, z, self.seed, W)
+        cm = comm.all_gather_ints(counts, pairs.device)              # cm[src][dest * W + wpart]
+        send_counts = [sum(counts[r * W:(r + 1) * W]) for r in range(W)]
+        recv_counts = [sum(cm[src][g * W:(g + 1) * W]) for src in range(W)]
+        mine = comm.all_to_all_rows(pairs, send_counts, recv_counts)  # grouped by source rank, then by word % W
+        seg, at = [[None] * W for _ in range(W)], 0
+        for src in range(W):
+            for j in range(W):
+                ln = cm[src][g * W + j]
+                seg[src][j] = (at, at + ln)
+                at += ln
+        return mine, seg
+
     def run(self, p=1.0, q=1.0):
         import torch
         b, comm, W, g = self.b, self.comm, self.world, self.rank
@@ -260,35 +302,60 @@ class Node2VecPartitioned(object):
         comm.all_reduce_sum(counts)
         b.build_unigram_parts(W)
         P_part, N_cur, N_tmp = b.init_part_tables(self.seed, g, W)          # partition g of SynPos / SynNeg (+ a receive buffer)
-        nloc = self.hi - self.lo
         total_steps = float(self.epochs * self.episodes)
         self.pairs_trained = 0
-        for ep in range(self.epochs):
-            for e in range(self.episodes):
-                a, z = shard_range(nloc, e, self.episodes)
-                # (context, word) pairs of this slice of my walks, already grouped by (context % W, word % W) on the device
-                pairs, counts = b.emit_pairs_bucketed(self.window, ep, a, z, self.seed, W)
-                cm = comm.all_gather_ints(counts, pairs.device)              # cm[src][dest * W + wpart]
-                send_counts = [sum(counts[r * W:(r + 1) * W]) for r in range(W)]
-                recv_counts = [sum(cm[src][g * W:(g + 1) * W]) for src in range(W)]
-                mine = comm.all_to_all_rows(pairs, send_counts, recv_counts)  # grouped by source rank, then by word % W
-                seg, at = [[None] * W for _ in range(W)], 0
-                for src in range(W):
-                    for j in range(W):
-                        ln = cm[src][g * W + j]
-                        seg[src][j] = (at, at + ln)
-                        at += ln
-                step = ep * self.episodes + e
-                for s in range(W):
-                    j = (g + s) % W                                          # SynNeg partition visiting me this round
-                    parts_j = [mine[x:y] for x, y in (seg[src][j] for src in range(W)) if y > x]
-                    bucket = parts_j[0] if len(parts_j) == 1 else (torch.cat(parts_j) if parts_j else mine[:0])
-                    f0, f1 = (step + s / W) / total_steps, (step + (s + 1) / W) / total_steps
-                    b.train_pairs(bucket, j, P_part, N_cur, self._alpha(f0), self._alpha(f1), self.seed,
-                                  (step * W + g) * W + j, self.flags)
-                    self.pairs_trained += int(bucket.shape[0])
-                    N_cur, N_tmp = comm.ring_shift(N_cur, N_tmp)             # after W shifts my own partition is back
+        cuda = bool(getattr(P_part, 'is_cuda', False))
+        main = torch.cuda.current_stream() if cuda else None
+        prep = torch.cuda.Stream() if cuda else None
+        ev = lambda: torch.cuda.Event(enable_timing=True) if cuda else None
+        self._ev = {'train': [], 'shift': [], 'prep': []}
+
+        def prepare(ep, e):
+            if not cuda:
+                return self._prepare(ep, e), None
+            prep.wait_stream(main)                                      # (walks / tables of the first call; a no-op later)
+            with torch.cuda.stream(prep):
+                e0 = ev(); e0.record()
+                out = self._prepare(ep, e)
+                out[0].record_stream(main)
+                e1 = ev(); e1.record()
+            self._ev['prep'].append((e0, e1))
+            return out, e1
+
+        order = [(ep, e) for ep in range(self.epochs) for e in range(self.episodes)]
+        nxt = prepare(*order[0])
+        for k, (ep, e) in enumerate(order):
+            (mine, seg), ready = nxt
+            if ready is not None:
+                main.wait_event(ready)
+            step = ep * self.episodes + e
+            for s in range(W):
+                j = (g + s) % W                                          # SynNeg partition visiting me this round
+                parts_j = [mine[x:y] for x, y in (seg[src][j] for src in range(W)) if y > x]
+                bucket = parts_j[0] if len(parts_j) == 1 else (torch.cat(parts_j) if parts_j else mine[:0])
+                f0, f1 = (step + s / W) / total_steps, (step + (s + 1) / W) / total_steps
+                t0, t1, t2 = ev(), ev(), ev()
+                if cuda: t0.record()
+                b.train_pairs(bucket, j, P_part, N_cur, self._alpha(f0), self._alpha(f1), self.seed,
+                              (step * W + g) * W + j, self.flags)
+                if cuda: t1.record()
+                self.pairs_trained += int(bucket.shape[0])
+                N_cur, N_tmp = comm.ring_shift(N_cur, N_tmp)             # after W shifts my own partition is back
+                if cuda:
+                    t2.record()
+                    self._ev['train'].append((t0, t1)); self._ev['shift'].append((t1, t2))
+            # the next episode's pairs are emitted and routed while the rounds queued above run
+            nxt = prepare(*order[k + 1]) if k + 1 < len(order) else None
         return assemble_partitions(P_part, comm, W, self.n)
+
+    def phase_seconds(self):
+        """Device seconds of the last run() by phase (HIP events): training rounds, ring shifts of the SynNeg partitions (on the
+        training stream), pair emission + all-to-all (on the side stream, overlapped with training)."""
+        if not getattr(self, '_ev', None) or not self._ev['train']:
+            return None
+        import torch
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) * 1e-3 for k, v in self._ev.items()}
 
 
 class HipBackendN2V(object):

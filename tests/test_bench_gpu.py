@@ -1,0 +1,61 @@
+"""GPU tier: the N>1 path of bench.py end to end (two ranks sharing the one GPU of the test box over gloo -- everything but RCCL
+itself: sharding, halo / pair exchange, partition ring, max-over-ranks timing, the JSON line), and node2vec parity at scale
+against the reference binary's own result on the same graph (tests/golden/n2v_ref_snap_100k.json)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gem_amd.embedding.node2vec import node2vec
+from gem_amd.evaluation import reconstruction as gr
+from gem_amd.graph import sbm_graph
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize('workload,extra', [('gf', ['--steps', '4', '--warmup', '1']),
+                                            ('node2vec', ['--steps', '1', '--warmup', '0', '--episodes', '4'])])
+def test_two_rank_bench_line(workload, extra):
+    env = dict(os.environ, GEM_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', workload,
+           '--nodes', '16384', '--edges', '163840', '--blocks', '8'] + extra
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    j = json.loads(line)
+    assert j['n_gpus'] == 2 and j['config']['world_size_seen'] == 2 and j['scaling'] == 'strong'
+    assert j['value'] > 0 and j['unit'] == 'edges/s' and j['data'] == 'synthetic'
+    assert j.get('phases'), 'the N>1 line must carry the train/exchange split'
+    if workload == 'node2vec':
+        assert j['quality']['sampled_map'] > 0.5          # the partitioned schedule trains a real embedding (1 rank reaches ~0.93 here)
+        ph = j['phases']['last_step_seconds']
+        assert ph['train'] > 0 and ph['shift'] >= 0 and ph['prep'] > 0
+
+
+def test_node2vec_map_at_100k_within_one_percent_of_the_reference_binary():
+    """north_star: MAP within 1 % of the reference.  gem/c_exe/node2vec (race-free, OMP_NUM_THREADS=1: 57 minutes of CPU) on
+    SBM 100k/1M gives MAP 0.9127 over a fixed 1024-node sample; the HIP path on the same graph is scored on the same nodes
+    with the same evaluator semantics.  Per-node AP differences are paired, so the comparison is tighter than either s.e."""
+    ref = json.load(open(golden_path('n2v_ref_snap_100k.json')))
+    pr = ref['params']
+    g = sbm_graph(pr['n'], pr['edges'], pr['blocks'], pr['seed'])
+    nodes = np.random.RandomState(0).choice(g.n, size=len(ref['ap']), replace=False)
+    m = node2vec(d=pr['d'], max_iter=1, walk_len=pr['walk_len'], num_walks=pr['num_walks'], con_size=pr['window'], ret_p=1, inout_p=1,
+                 seed=20260923)
+    X = m.learn_embedding(graph=g, is_weighted=True, no_python=True)
+    ap = gr.sampled_ap_gpu(g, None, X, nodes)
+    assert abs(ap.mean() - ref['MAP']) <= 0.01 * ref['MAP'], (ap.mean(), ref['MAP'])
+    orc = json.load(open(golden_path('n2v_ref_oracle_100k.json')))           # the sequential restatement lands on the binary as well
+    assert abs(orc['MAP'] - ref['MAP']) <= 0.01 * ref['MAP']
