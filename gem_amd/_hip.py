@@ -178,3 +178,13 @@ def as_i32(a):
 
 def as_f32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def warn_if_unconverged(stats, tol, max_restarts, what):
+    """The block-Krylov solver returns its best Ritz pairs when the restart budget runs out; scipy's svds / eigs would raise
+    ArpackNoConvergence there.  Keep GEM's "returns an embedding" behaviour but say so."""
+    import warnings
+    if stats.get('restarts', 0) >= max_restarts and stats.get('last_sigma_change', 0.0) >= tol:
+        warnings.warn('%s: not converged after %d restarts (last relative change of the wanted values %.2e >= tol %.1e, Ritz residual %.2e); '
+                      'raise max_restarts or tol' % (what, int(stats['restarts']), stats['last_sigma_change'], tol, stats.get('ritz_residual', float('nan'))),
+                      RuntimeWarning, stacklevel=3)

@@ -836,8 +836,16 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
     float *Vall = nullptr, *Ball = nullptr, *T0 = nullptr, *T1 = nullptr, *W0 = nullptr, *Tmp = nullptr;
     auto dalloc = [&](float **p, size_t cols) { HOPE_TRY(H, hipMalloc((void **)p, (size_t)n * cols * sizeof(float))); if (!H.err) HOPE_TRY(H, hipMemset(*p, 0, (size_t)n * cols * sizeof(float))); };
     dalloc(&Vall, ldm); dalloc(&Ball, ldm); dalloc(&T0, ldb); dalloc(&T1, ldb); dalloc(&W0, ldb); dalloc(&Tmp, ldm);
-    auto cleanup = [&]() { hipFree(Vall); hipFree(Ball); hipFree(T0); hipFree(T1); hipFree(W0); hipFree(Tmp); };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    auto cleanup = [&]() {          // also on the error paths: buffers and the four timing events
+        hipFree(Vall); hipFree(Ball); hipFree(T0); hipFree(T1); hipFree(W0); hipFree(Tmp);
+        Vall = Ball = T0 = T1 = W0 = Tmp = nullptr;
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+        if (H.sp0) hipEventDestroy(H.sp0);
+        if (H.sp1) hipEventDestroy(H.sp1);
+        ev0 = ev1 = nullptr; H.sp0 = H.sp1 = nullptr;
+    };
     if (!H.err) { HOPE_TRY(H, hipEventCreate(&ev0)); HOPE_TRY(H, hipEventCreate(&ev1)); HOPE_TRY(H, hipEventCreate(&H.sp0)); HOPE_TRY(H, hipEventCreate(&H.sp1)); H.time_spmm = (stats != nullptr); }
     if (H.err) { cleanup(); return H.err; }
     hipEventRecord(ev0, H.s);
@@ -1018,10 +1026,6 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
         stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = terms; stats[4] = mc; stats[5] = restarts_done;
         stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual; stats[11] = H.spmm_ms * 1e-3;
     }
-    if (ev0) hipEventDestroy(ev0);
-    if (ev1) hipEventDestroy(ev1);
-    if (H.sp0) hipEventDestroy(H.sp0);
-    if (H.sp1) hipEventDestroy(H.sp1);
     cleanup();
     return H.err;
 }

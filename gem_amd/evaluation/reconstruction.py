@@ -141,8 +141,11 @@ def sampled_ap_gpu(graph, graph_embedding, X, nodes, is_undirected=True):
     if name == 'hope_gsvd':                                   # hope.py:43-44: X[i, :k] . X[j, k:]
         k = d // 2
         A = np.ascontiguousarray(X[:, :k], dtype=np.float32); B = np.ascontiguousarray(X[:, k:2 * k], dtype=np.float32)
-    else:                                                     # gf.py:103-104 / node2vec.py:56-57: X[i] . X[j]
+    elif name in ('', 'graph_factor_sgd', 'node2vec_rw'):     # gf.py:103-104 / node2vec.py:56-57: X[i] . X[j]
         A = np.ascontiguousarray(X, dtype=np.float32); B = None
+    else:                                                     # lap.py / lle.py score by exp(-||x_i - x_j||^2): not an inner product
+        raise NotImplementedError('sampled_ap_gpu scores inner-product methods (GF, node2vec, HOPE); %r defines get_edge_weight '
+                                  'differently -- use evaluateStaticGraphReconstruction' % name)
     nodes = np.ascontiguousarray(nodes, dtype=np.int32)
     ap = np.zeros(len(nodes))
     _hip.require_device()

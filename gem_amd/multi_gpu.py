@@ -125,6 +125,20 @@ class GFSharded(object):
         self.r0 = rank * self.block
         self.r1 = min(self.r0 + self.block, n)
         self._edges = None if (src is None or world == 1) else (src, dst)
+        if world > 1 and src is not None:
+            # a rank's plan reads every row of ANOTHER rank from the previous sweep's table; that equals the single-GPU (and the
+            # reference's) sweep only when no firing edge reads a row that the reference has already updated in the same sweep,
+            # i.e. when sources are first visited in ascending id order (levels == 1 for the unsharded plan)
+            import numpy as np
+            s_, d_ = np.asarray(src), np.asarray(dst)
+            fire = d_ > s_
+            first = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+            np.minimum.at(first, s_[fire], np.nonzero(fire)[0])
+            fs = first[np.unique(s_[fire])]
+            if np.any(np.diff(fs) < 0):
+                raise ValueError('GFSharded needs the firing sources in ascending id order (graph.edges() of a graph whose nodes were '
+                                 'inserted in id order); other visiting orders make rows of other ranks "already updated" inside a sweep '
+                                 'and would need a halo exchange per level')
         self.halo = None                                 # planned at the first sweep (needs the tables' device)
         self.halo_rows = None
 
