@@ -25,6 +25,7 @@
 // HBM traffic per sweep (algorithmic, d=128): 512 B read + 512 B write per active
 // row, 512 B gather + 8 B (col,w) per update.
 #include "common.hpp"
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -35,6 +36,8 @@ struct gemhip_gf_plan {
     int64_t n = 0, d = 0, nrows = 0, nupd = 0;
     int device = 0;
     std::vector<int64_t> level_off;   // rows of level L are [level_off[L], level_off[L+1])
+    std::vector<int64_t> level_hubs;  // ... of which the first level_hubs[L] are hub rows (gf_hub_kernel)
+    hipStream_t hub_stream = nullptr; hipEvent_t hub_fork = nullptr, hub_join = nullptr;
     int32_t *d_rows = nullptr;        // row ids in processing order (sorted by level, then reference order)
     int64_t *d_ptr = nullptr;         // CSR offsets over d_rows
     uint32_t *d_col = nullptr;        // neighbour id | (1u<<31 if that neighbour is read from X_new)
@@ -49,6 +52,7 @@ namespace {
 constexpr int GF_BLOCK = 256;              // 4 waves, one row per wave
 constexpr int GF_WAVES = GF_BLOCK / WAVE;
 constexpr int GF_PREFETCH = 4;             // neighbour rows in flight per wave
+constexpr int GF_HUB_EDGES = 1024;         // rows with at least this many firing edges get a workgroup (gf_hub_kernel)
 constexpr int GF_PREFETCH_DEEP = 16;       // ... on full 64-edge chunks of long (hub) rows, divided by the registers a row needs
 
 template <int VEC> struct vec_t;
@@ -65,6 +69,27 @@ __device__ __forceinline__ void load_row(const float *__restrict__ p, int d, int
     } else {
         v[0] = idx < d ? p[idx] : 0.f;
     }
+}
+
+// One edge update X_i -= eta * (regu * X_i - (w_ij - X_i.X_j) * X_j)  (gf.cpp:162-163).  Shared by the wave-per-row kernel and the hub
+// kernel: the same expressions are contracted the same way, so both produce bit-identical rows.
+template <int VEC, int NV>
+__device__ __forceinline__ void gf_apply_edge(float (&xi)[NV][VEC], const float (&xj)[NV][VEC], float wij, float eta, float regu)
+{
+    // explicit fused / rounded operations: the compiler may not choose between mul+add and fma (or packed forms) differently per kernel
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) part = fmaf(xi[q][v], xj[q][v], part);
+    const float coef = wij - wave_sum(part);        // (w_ij - X_i.X_j)
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float t = fmaf(-coef, xj[q][v], __fmul_rn(regu, xi[q][v]));     // regu * X_i - coef * X_j
+            xi[q][v] = fmaf(-eta, t, xi[q][v]);
+        }
 }
 
 // Apply the updates of up to 64 edges of one row (columns/weights in lane registers cj/wj), U neighbour rows in flight.
@@ -84,22 +109,8 @@ __device__ __forceinline__ void gf_chunk(float (&xi)[NV][VEC], uint32_t cj, floa
             for (int q = 0; q < NV; ++q) load_row<VEC>(pj, d, lane, q, xj[u][q]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (k + u < cnt) {
-                float part = 0.f;
-#pragma unroll
-                for (int q = 0; q < NV; ++q)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) part += xi[q][v] * xj[u][q][v];
-                const float dot = wave_sum(part);
-                const float coef = bcast_lane(wj, k + u) - dot;        // (w_ij - X_i.X_j)
-#pragma unroll
-                for (int q = 0; q < NV; ++q)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v)
-                        xi[q][v] -= eta * (regu * xi[q][v] - coef * xj[u][q][v]);   // gf.cpp:162-163
-            }
-        }
+        for (int u = 0; u < U; ++u)
+            if (k + u < cnt) gf_apply_edge<VEC, NV>(xi, xj[u], bcast_lane(wj, k + u), eta, regu);
     }
 }
 
@@ -154,6 +165,128 @@ void launch_sweep(const gemhip_gf_plan *p, int64_t row0, int64_t nrows, const fl
     const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
     hipLaunchKernelGGL((gf_sweep_kernel<VEC, NV>), dim3((unsigned)grid), dim3(GF_BLOCK), 0, s, p->d_rows, p->d_ptr, p->d_col,
                        p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu);
+}
+
+// Hub rows (power-law graphs).  The updates of one row are one dependent chain (exact Gauss-Seidel): a wave that also fetches its
+// neighbour rows pays a memory latency per batch on top of the chain (130 ns per update measured).  Here a row with >= GF_HUB_EDGES firing
+// edges gets a whole workgroup: wavefronts 1-3 stream the neighbour rows (and weights) of successive batches through an LDS ring, wave 0
+// does nothing but apply them, in edge order, with the very same gf_apply_edge -- bit-identical to the wave-per-row kernel.
+typedef __attribute__((address_space(3))) volatile int32_t gf_lds_vi32;
+__device__ __forceinline__ int32_t gf_flag_ld(const int32_t *p) { return *(gf_lds_vi32 *)p; }
+__device__ __forceinline__ void gf_flag_st(int32_t *p, int32_t v) { *(gf_lds_vi32 *)p = v; }
+
+template <int VEC, int NV>
+__global__ __launch_bounds__(256) void gf_hub_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
+                                                     const uint32_t *__restrict__ col, const float *__restrict__ w, const float *Xold,
+                                                     float *Xnew, int64_t row0, int d, float eta, float regu)
+{
+    constexpr int RW = NV * VEC * WAVE;              // floats of one staged row
+    constexpr int B = NV >= 8 ? 2 : 16 / NV;         // edges per batch
+    constexpr int NBATCH = 4;                        // ring depth in batches (32 KB of rows)
+    constexpr int G = B >= 4 ? 4 : B;                // rows the consumer moves LDS -> registers at a time
+    __shared__ __attribute__((aligned(16))) float ring[NBATCH * B * RW];
+    __shared__ float wring[NBATCH * 16];
+    __shared__ int32_t ready[NBATCH];
+    __shared__ int32_t done;
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int64_t r = row0 + blockIdx.x;
+    const int32_t i = rows[r];
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    const int nb = (int)((e1 - e0 + B - 1) / B);
+    if (threadIdx.x == 0) done = 0;
+    if (threadIdx.x < NBATCH) ready[threadIdx.x] = 0;
+    __syncthreads();
+    if (wave == 0) {
+        float xi[NV][VEC];
+        const float *pi = Xold + (int64_t)i * d;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) load_row<VEC>(pi, d, lane, c, xi[c]);
+        auto lds_row = [&](const float *row, float (&v)[NV][VEC]) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[q][k] = row[(q * WAVE + lane) * VEC + k];
+        };
+        for (int t = 0; t < nb; ++t) {
+            const int sb = t % NBATCH;
+            while (gf_flag_ld(&ready[sb]) != t + 1) __builtin_amdgcn_s_sleep(0);
+            asm volatile("" ::: "memory");
+            const int cnt = (int)((e1 - (e0 + (int64_t)t * B)) < B ? (e1 - (e0 + (int64_t)t * B)) : B);
+            const float wv = wring[sb * 16 + (lane & 15)];
+            const float *base = ring + (size_t)sb * B * RW;
+            float buf[2][G][NV][VEC];
+#pragma unroll
+            for (int u = 0; u < G; ++u) lds_row(base + (size_t)u * RW, buf[0][u]);
+#pragma unroll
+            for (int g = 0; g < B / G; ++g) {
+                if (g + 1 < B / G) {
+#pragma unroll
+                    for (int u = 0; u < G; ++u) lds_row(base + (size_t)((g + 1) * G + u) * RW, buf[(g + 1) & 1][u]);
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u)
+                    if (g * G + u < cnt) gf_apply_edge<VEC, NV>(xi, buf[g & 1][u], bcast_lane(wv, g * G + u), eta, regu);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) gf_flag_st(&done, t + 1);
+        }
+        float *po = Xnew + (int64_t)i * d;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int idx = (c * WAVE + lane) * VEC;
+            if (idx < d) {
+                if constexpr (VEC == 2) *reinterpret_cast<float2 *>(po + idx) = make_float2(xi[c][0], xi[c][1]);
+                else po[idx] = xi[c][0];
+            }
+        }
+    } else {
+        for (int t = wave - 1; t < nb; t += 3) {
+            const int sb = t % NBATCH;
+            while (gf_flag_ld(&done) < t - NBATCH + 1) __builtin_amdgcn_s_sleep(1);     // the batch that used this ring segment is consumed
+            asm volatile("" ::: "memory");
+            const int64_t eb = e0 + (int64_t)t * B;
+            const int cnt = (int)((e1 - eb) < B ? (e1 - eb) : B);
+            const uint32_t cj = lane < cnt ? col[eb + lane] : 0u;
+            const float wj = lane < cnt ? w[eb + lane] : 0.f;
+            float xj[B][NV][VEC];
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const int kk = u < cnt ? u : cnt - 1;
+                const uint32_t c = bcast_lane(cj, kk);
+                const float *pj = ((c >> 31) ? Xnew : Xold) + (int64_t)(c & 0x7fffffffu) * d;
+#pragma unroll
+                for (int q = 0; q < NV; ++q) load_row<VEC>(pj, d, lane, q, xj[u][q]);
+            }
+            float *base = ring + (size_t)sb * B * RW;
+#pragma unroll
+            for (int u = 0; u < B; ++u)
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) base[(size_t)u * RW + (q * WAVE + lane) * VEC + k] = xj[u][q][k];
+            if (lane < 16) wring[sb * 16 + lane] = wj;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) gf_flag_st(&ready[sb], t + 1);
+        }
+    }
+}
+
+template <int VEC, int NV>
+void launch_hub(const gemhip_gf_plan *p, int64_t row0, int64_t nhub, const float *Xold, float *Xnew, float eta, float regu, hipStream_t s)
+{
+    hipLaunchKernelGGL((gf_hub_kernel<VEC, NV>), dim3((unsigned)nhub), dim3(256), 0, s, p->d_rows, p->d_ptr, p->d_col, p->d_w, Xold, Xnew, row0,
+                       (int)p->d, eta, regu);
+}
+using hub_fn = void (*)(const gemhip_gf_plan *, int64_t, int64_t, const float *, float *, float, float, hipStream_t);
+hub_fn pick_hub(int d)
+{
+    if (d % 2 == 0) {
+        const int nv = (d + 127) / 128;
+        return nv <= 1 ? launch_hub<2, 1> : nv <= 2 ? launch_hub<2, 2> : nv <= 4 ? launch_hub<2, 4> : nv <= 8 ? launch_hub<2, 8> : nullptr;
+    }
+    const int nv = (d + 63) / 64;
+    return nv <= 1 ? launch_hub<1, 1> : nv <= 2 ? launch_hub<1, 2> : nv <= 4 ? launch_hub<1, 4> : nv <= 8 ? launch_hub<1, 8> : nullptr;
 }
 
 using sweep_fn = void (*)(const gemhip_gf_plan *, int64_t, int64_t, const float *, float *, float, float, hipStream_t);
@@ -305,14 +438,20 @@ extern "C" int gemhip_gf_plan_create(int64_t n, int64_t m, const int32_t *src, c
     std::vector<int64_t> lvl_cnt(nlevels + 1, 0);
     for (int64_t r = 0; r < nrows; ++r) ++lvl_cnt[level[r] + 1];
     for (int32_t l = 0; l < nlevels; ++l) lvl_cnt[l + 1] += lvl_cnt[l];
+    std::vector<int64_t> level_hubs;
     std::vector<int32_t> rows_sorted(nrows);
     std::vector<int64_t> ptr_sorted(nrows + 1, 0);
     std::vector<uint32_t> col_sorted(nupd);
     std::vector<float> w_sorted(nupd);
     {
+        // inside a level the rows are independent: hub rows (gf_hub_kernel) first, the others keep the reference's visiting order
         std::vector<int64_t> at(lvl_cnt.begin(), lvl_cnt.end() - 1);
         std::vector<int64_t> newpos(nrows);
-        for (int64_t r = 0; r < nrows; ++r) newpos[r] = at[level[r]]++;
+        level_hubs.assign(nlevels, 0);
+        const bool hubs_on = getenv("GEMHIP_GF_NO_HUB_KERNEL") == nullptr;
+        const int64_t hub_t = getenv("GEMHIP_GF_HUB_EDGES") ? std::max(1, atoi(getenv("GEMHIP_GF_HUB_EDGES"))) : GF_HUB_EDGES;   // (tests lower it)
+        for (int64_t r = 0; r < nrows; ++r) if (hubs_on && off[r + 1] - off[r] >= hub_t) { newpos[r] = at[level[r]]++; ++level_hubs[level[r]]; }
+        for (int64_t r = 0; r < nrows; ++r) if (!(hubs_on && off[r + 1] - off[r] >= hub_t)) newpos[r] = at[level[r]]++;
         std::vector<int64_t> inv(nrows);
         for (int64_t r = 0; r < nrows; ++r) inv[newpos[r]] = r;
         for (int64_t s = 0; s < nrows; ++s) {
@@ -327,6 +466,7 @@ extern "C" int gemhip_gf_plan_create(int64_t n, int64_t m, const int32_t *src, c
     auto *p = new gemhip_gf_plan();
     p->n = n; p->d = d; p->nrows = nrows; p->nupd = nupd;
     p->level_off.assign(lvl_cnt.begin(), lvl_cnt.end());
+    p->level_hubs = level_hubs;
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail(GEMHIP_E_HIP, "gf_plan_create: no HIP device"); }
     auto up = [&](void **dp, const void *hp, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dp, bytes ? bytes : 16);
@@ -349,6 +489,7 @@ extern "C" int gemhip_gf_plan_destroy(gemhip_gf_plan_t p)
 {
     if (!p) return GEMHIP_OK;
     hipFree(p->d_rows); hipFree(p->d_ptr); hipFree(p->d_col); hipFree(p->d_w);
+    if (p->hub_stream) { hipStreamSynchronize(p->hub_stream); hipStreamDestroy(p->hub_stream); hipEventDestroy(p->hub_fork); hipEventDestroy(p->hub_join); }
     if (p->own_X) { hipFree(p->X[0]); hipFree(p->X[1]); }
     delete p;
     return GEMHIP_OK;
@@ -410,7 +551,20 @@ extern "C" int gemhip_gf_plan_sweeps(gemhip_gf_plan_t p, int32_t nsweeps, float 
         float *Xnew = p->X[p->cur ^ 1];
         for (int l = 0; l < nlevels; ++l) {
             const int64_t r0 = p->level_off[l], nr = p->level_off[l + 1] - r0;
-            if (nr > 0) fn(p, r0, nr, Xold, Xnew, eta, regu, s);
+            const int64_t nh = l < (int)p->level_hubs.size() ? p->level_hubs[l] : 0;
+            if (nh > 0) {                              // hub rows of this level on a side stream, next to the wave-per-row kernel
+                if (!p->hub_stream) {
+                    GEMHIP_CHECK(hipStreamCreateWithFlags(&p->hub_stream, hipStreamNonBlocking));
+                    GEMHIP_CHECK(hipEventCreateWithFlags(&p->hub_fork, hipEventDisableTiming));
+                    GEMHIP_CHECK(hipEventCreateWithFlags(&p->hub_join, hipEventDisableTiming));
+                }
+                GEMHIP_CHECK(hipEventRecord(p->hub_fork, s));
+                GEMHIP_CHECK(hipStreamWaitEvent(p->hub_stream, p->hub_fork, 0));
+                pick_hub((int)p->d)(p, r0, nh, Xold, Xnew, eta, regu, p->hub_stream);
+                GEMHIP_CHECK(hipEventRecord(p->hub_join, p->hub_stream));
+            }
+            if (nr - nh > 0) fn(p, r0 + nh, nr - nh, Xold, Xnew, eta, regu, s);
+            if (nh > 0) GEMHIP_CHECK(hipStreamWaitEvent(s, p->hub_join, 0));
         }
         p->cur ^= 1;
     }

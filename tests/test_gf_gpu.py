@@ -179,3 +179,21 @@ def test_device_init_option_trains_like_the_numpy_init(sbm1024):
     a = GraphFactorization(d=32, max_iter=2, eta=0.02, regu=0.01, seed=3, device_init=True).learn_embedding(graph=sbm1024)
     b = GraphFactorization(d=32, max_iter=2, eta=0.02, regu=0.01, seed=3, device_init=True).learn_embedding(graph=sbm1024)
     assert np.array_equal(a, b)                                   # seeded and deterministic
+
+
+@pytest.mark.parametrize('d', [2, 7, 128, 256, 1024])
+def test_hub_kernel_is_bit_identical_to_the_wave_per_row_kernel(d, sbm1024, karate, monkeypatch):
+    """Rows with many firing edges get a workgroup (producers stream neighbour rows through LDS, one wavefront applies the chain):
+    same gf_apply_edge in the same order, so the tables are bit-identical to the wave-per-row kernel's.  The threshold is lowered
+    so that most rows of the test graphs take the hub kernel (partial batches, multi-level schedules, every row layout)."""
+    for G, sweeps in ((sbm1024, 3), (karate, 5)):
+        n, src, dst, w, _ = edge_arrays(G)
+        np.random.seed(3)
+        X0 = (0.01 * np.random.randn(n, d)).astype(np.float32)
+        out = {}
+        for tag, env in (('hub', {'GEMHIP_GF_HUB_EDGES': '3'}), ('plain', {'GEMHIP_GF_NO_HUB_KERNEL': '1'})):
+            monkeypatch.delenv('GEMHIP_GF_HUB_EDGES', raising=False); monkeypatch.delenv('GEMHIP_GF_NO_HUB_KERNEL', raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            out[tag] = hip_train(n, src, dst, w, d, 0.01, 0.01, sweeps, X0)[0]
+        assert np.array_equal(out['hub'], out['plain'])
