@@ -149,7 +149,7 @@ class GFWorkload(object):
 
 
 class N2VWorkload(object):
-    metric, unit, dtype, kernel = 'edges/sec', 'edges/s', 'f32', 'sgns_kernel'
+    metric, unit, dtype, kernel = 'edges/sec', 'edges/s', 'f32', 'sgns_win_kernel'
     default_steps, default_warmup = 2, 1
 
     def __init__(self, args, rank, world, comm):

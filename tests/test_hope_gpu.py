@@ -117,3 +117,17 @@ def test_baseline_config_properties():
     assert np.allclose(np.einsum('ij,ij->j', U, SVall), s, rtol=2e-4)
     # 32 planted communities -> 32 singular values above the bulk edge
     assert s[k - 32] > 1.15 * s[k - 33]
+
+
+def test_all_64_singular_values_at_baseline_config_vs_arpack():
+    """BASELINE configs[2] (SBM 100k/1M, d=128, beta=0.01): hope.py:33 would return svds(S, k=64).  The CPU answer -- ARPACK on the
+    implicit Katz-series operator, tol 1e-9, 76 s (scripts/make_golden_hope_sigma.py; the dense S needs 80 GB) -- is committed as
+    tests/golden/hope_sigma_sbm100k.json; every one of the 64 singular values of the HIP solve agrees to 1e-4 relative."""
+    ref = json.load(open(golden_path('hope_sigma_sbm100k.json')))
+    pr = ref['params']
+    g = sbm_graph(pr['n'], pr['edges'], pr['blocks'], pr['seed'])
+    m = HOPE(d=pr['d'], beta=pr['beta'])
+    m.learn_embedding(graph=g, is_weighted=True, no_python=True)
+    s_ref = np.asarray(ref['sigma_ascending'])
+    rel = np.abs(np.asarray(m._sigma) / s_ref - 1.0)
+    assert rel.max() <= 1e-4, (rel.max(), int(rel.argmax()))
