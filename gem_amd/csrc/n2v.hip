@@ -17,6 +17,7 @@
 // counts and alias tables bit for bit.
 #include "common.hpp"
 #include <vector>
+#include <cstring>
 #include <cmath>
 #include <algorithm>
 
@@ -77,6 +78,7 @@ struct gemhip_n2v {
     int32_t *d_counts = nullptr;
     float *d_UT = nullptr;
     int32_t *d_KT = nullptr;
+    uint2 *d_UK = nullptr;             // {bits of UT[i], KT[i]} interleaved: one 8-byte gather instead of two 4-byte gathers
     bool unigram_ready = false;
     // embeddings
     int32_t d = 0;
@@ -86,6 +88,7 @@ struct gemhip_n2v {
     int32_t cache_radius = -1;        // sgns_win_kernel LDS window radius: -1 auto, 0 = off (sgns_kernel)
     int32_t cache_delta = -1;         // -1 auto, 0 overwrite on leave, 1 delta write-back
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
+    float *d_oscr = nullptr; size_t oscr_bytes = 0;     // sgns_win_kernel<OSCR>: as-loaded copies of cached rows
     unsigned long long *d_bcnt = nullptr;               // emit_pairs_bucketed: bucket sizes [64*64] + cursors [64*64]
     int32_t sgns_duo = 0;             // 1: two-wavefront (trainer + helper) kernel where it applies; 0 (default): single-wavefront window kernel
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
@@ -297,9 +300,10 @@ __device__ __forceinline__ void st_row_wide(__amdgpu_buffer_rsrc_t rs, int64_t r
 struct SgnsArgs {
     const int32_t *walks; int64_t walk_lo, walk_hi; int32_t walk_len; int32_t window;
     float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
-    const float *UT; const int32_t *KT; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
+    const float *UT; const int32_t *KT; const uint2 *UK; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
     float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs;
     float *dummy;               // sgns_win_kernel: nwaves rows, never read for their value
+    float *oscr;                // sgns_win_kernel<OSCR>: per wave (2R+2) rows, the as-loaded copies of its cached rows
     unsigned long long *prof;   // GEMHIP_SGNS_PROFILE builds only: per-phase cycle sums (s_memtime)
     int32_t cache_radius;       // sgns_win_kernel: tokens within this many positions of the centre keep their SynPos row in LDS
 };
@@ -538,8 +542,8 @@ struct NegSet {
 // With both, the pair loop has a STATIC number of memory operations per pair (skipped targets and exhausted prefetch slots
 // go to a per-wave dummy row instead of branching), which is what lets the compiler keep two pairs' rows in flight with
 // counted s_waitcnt vmcnt(N) instead of draining to vmcnt(0) at every control-flow merge.
-template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC>
-__global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
+template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC, bool OSCR>      // OSCR: the as-loaded copies of the delta write-back live in a per-wave global scratch
+__global__ __launch_bounds__(64, OSCR ? 3 : 1) void sgns_win_kernel(SgnsArgs A)      // area instead of LDS (half the LDS per wave -> twice the resident wavefronts)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     constexpr int RW = NV * VEC * WAVE;              // floats per cached row (row padded to the wave's footprint)
@@ -553,7 +557,8 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     int32_t *tok = lds;
     int32_t *negs = tok + len;                       // [2][nsamp]
     float *rowsL = reinterpret_cast<float *>(lds + ((len + 2 * nsamp + 3) & ~3));
-    float *rowsO = rowsL + (size_t)(S + 1) * RW;     // DELTA only; slot S of rowsL stages a context row that is not cached
+    float *rowsO = rowsL + (size_t)(S + 1) * RW;     // DELTA && !OSCR only; slot S of rowsL stages a context row that is not cached
+    float *oscr = OSCR ? A.oscr + (size_t)gw * (S + 1) * RW : nullptr;
 
     auto lds_ld = [&](const float *row, float (&v)[NV][VEC]) {
 #pragma unroll
@@ -578,6 +583,12 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     };
 
     float *dummy = A.dummy + (size_t)gw * RW;        // this wave's private sink / source for predicated-off row traffic
+    auto o_st = [&](int slot, const float (&v)[NV][VEC]) {            // the row as loaded (delta write-back)
+        if constexpr (OSCR) g_st(oscr + (size_t)slot * RW, v); else lds_st(rowsO + (size_t)slot * RW, v);
+    };
+    auto o_ld = [&](int slot, float (&v)[NV][VEC]) {
+        if constexpr (OSCR) g_ld(oscr + (size_t)slot * RW, v); else lds_ld(rowsO + (size_t)slot * RW, v);
+    };
     unsigned long long npairs = 0;
     PROF_DECL;
     PROF_START();
@@ -593,26 +604,42 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 
         // --- negative-target pipeline: stage A (table slot -> X) for centre p, stage B (UT[X], KT[X]), finalize -> LDS
         int32_t XA[NS], XB[NS], KTv[NS]; float uA[NS], uB[NS], UTv[NS];
+        // Only the samples of contexts the centre will train on are drawn: the window shrink b of centre p is itself a Philox draw, the
+        // draws are counter-based (skipping one changes no other), and the 2 x 3 uncoalesced table gathers per centre turned out to be what
+        // caps the kernel (scripts/microbench/rows.hip "mix": 6.2 -> 4.5 G rows/s with them) -- 45 % of the slots are never used.
+        bool liveA[NS], liveB[NS];
         auto stage_a = [&](int p) {
+            int bp = 0;
+            if (p < len) {
+                const u32x4 rwp = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
+                bp = (int)(rwp.x % (uint32_t)win);
+            }
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int s = lane + k * WAVE;
-                XA[k] = 0; uA[k] = 0.f;
+                XA[k] = 0; uA[k] = 0.f; liveA[k] = false;
                 if (p < len && s < nsamp) {
                     const int ai = s / SGNS_NEG;
                     const int a = ai < win ? ai : ai + 1;
-                    const int j = s - ai * SGNS_NEG + 1;
-                    const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p | ((uint32_t)a << 16),
-                                                   (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
-                    const uint32_t slot = mulhi_range(rn.x, A.n);
-                    XA[k] = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
-                    uA[k] = u01(rn.y);
+                    const int cp = p - win + a;
+                    if (a >= bp && a < 2 * win + 1 - bp && cp >= 0 && cp < len) {
+                        liveA[k] = true;
+                        const int j = s - ai * SGNS_NEG + 1;
+                        const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p | ((uint32_t)a << 16),
+                                                       (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
+                        const uint32_t slot = mulhi_range(rn.x, A.n);
+                        XA[k] = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
+                        uA[k] = u01(rn.y);
+                    }
                 }
             }
         };
         auto stage_b = [&]() {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) { XB[k] = XA[k]; uB[k] = uA[k]; UTv[k] = A.UT[XB[k]]; KTv[k] = A.KT[XB[k]]; }
+            for (int k = 0; k < NS; ++k) {
+                XB[k] = XA[k]; uB[k] = uA[k]; liveB[k] = liveA[k]; UTv[k] = 2.f; KTv[k] = 0;
+                if (liveB[k]) { const uint2 uk = A.UK[XB[k]]; UTv[k] = __builtin_bit_cast(float, uk.x); KTv[k] = (int32_t)uk.y; }   // one 8-byte gather
+            }
         };
         // ... and the "special" mask of centre p: bit ai is set when the (centre, context) pair of slot ai cannot take the
         // all-targets-independent fast path -- a target equals the centre word (TrainModel skips it), a target was drawn twice
@@ -662,7 +689,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             float r[NV][VEC];
             g_ld(A.SynPos + (int64_t)v * d, r);
             lds_st(rowsL + (size_t)s * RW, r);
-            if constexpr (DELTA) lds_st(rowsO + (size_t)s * RW, r);
+            if constexpr (DELTA) o_st(s, r);
             if (lane == s) { slot_node = v; slot_ref = 1; }
         }
 
@@ -684,7 +711,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 }
             }
             // token pos-R leaves after this centre: when it is the last holder of its slot, fetch the row as it is NOW
-            float rowG[NV][VEC]; int sX = -1; int32_t vX = -1;
+            float rowG[NV][VEC], rowO[NV][VEC]; int sX = -1; int32_t vX = -1;
             if (pos - R >= 0) {
                 vX = __builtin_amdgcn_readfirstlane(tok[pos - R]);
                 if (vX >= 0) {
@@ -694,6 +721,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     if (refc == 0) {
                         sX = s;
                         if constexpr (DELTA) g_ld(A.SynPos + (int64_t)vX * d, rowG);
+                        if constexpr (DELTA && OSCR) o_ld(s, rowO);          // requested a whole centre before it is needed
                     }
                 }
             }
@@ -748,7 +776,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 
                 if (sE >= 0) {               // the entering row has landed by now (requested before everything above)
                     lds_st(rowsL + (size_t)sE * RW, rowE);
-                    if constexpr (DELTA) lds_st(rowsO + (size_t)sE * RW, rowE);
+                    if constexpr (DELTA) o_st(sE, rowE);
                 }
 
                 // one (centre, context) pair: C holds its negative rows, P1 the next pair's (in flight), P2 is free
@@ -886,7 +914,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 g_st(pp, yp);
             } else if (sE >= 0) {
                 lds_st(rowsL + (size_t)sE * RW, rowE);
-                if constexpr (DELTA) lds_st(rowsO + (size_t)sE * RW, rowE);
+                if constexpr (DELTA) o_st(sE, rowE);
             }
 
             spec_next = stage_fin(pos + 1);
@@ -894,12 +922,11 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 float l[NV][VEC];
                 lds_ld(rowsL + (size_t)sX * RW, l);
                 if constexpr (DELTA) {
-                    float o[NV][VEC];
-                    lds_ld(rowsO + (size_t)sX * RW, o);
+                    if constexpr (!OSCR) o_ld(sX, rowO);
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) l[c][k] = rowG[c][k] + (l[c][k] - o[c][k]);
+                        for (int k = 0; k < VEC; ++k) l[c][k] = rowG[c][k] + (l[c][k] - rowO[c][k]);
                 }
                 g_st(A.SynPos + (int64_t)vX * d, l);
                 if (lane == sX) slot_node = -1;
@@ -918,7 +945,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             lds_ld(rowsL + (size_t)s * RW, l);
             if constexpr (DELTA) {
                 float o[NV][VEC], g[NV][VEC];
-                lds_ld(rowsO + (size_t)s * RW, o);
+                o_ld(s, o);
                 g_ld(A.SynPos + (int64_t)v * d, g);
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
@@ -1635,10 +1662,13 @@ template <int VEC, int NV, bool DELTA>
 void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
 {
     const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window;
-    if (full && allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true>), dim3(blocks), dim3(threads), lds, s, A);
-    else if (full) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, false>), dim3(blocks), dim3(threads), lds, s, A);
-    else if (allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, true>), dim3(blocks), dim3(threads), lds, s, A);
-    else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, false>), dim3(blocks), dim3(threads), lds, s, A);
+    if constexpr (DELTA) {
+        if (full && allc && A.oscr) { hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, true, true, true, true>), dim3(blocks), dim3(threads), lds, s, A); return; }
+    }
+    if (full && allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true, false>), dim3(blocks), dim3(threads), lds, s, A);
+    else if (full) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, false, false>), dim3(blocks), dim3(threads), lds, s, A);
+    else if (allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, true, false>), dim3(blocks), dim3(threads), lds, s, A);
+    else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, false, false>), dim3(blocks), dim3(threads), lds, s, A);
 }
 template <bool DELTA>
 sgns_fn pick_sgns_win(int d)
@@ -2042,9 +2072,9 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
 {
     if (!h) return GEMHIP_OK;
     hipFree(h->d_start);
-    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_bcnt);
+    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_bcnt); hipFree(h->d_oscr);
     if (h->own_counts) hipFree(h->d_counts);
-    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp);
+    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
     delete h;
     return GEMHIP_OK;
@@ -2237,6 +2267,12 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
     if (!h->d_KT) GEMHIP_CHECK(hipMalloc((void **)&h->d_KT, n * sizeof(int32_t)));
     GEMHIP_CHECK(hipMemcpy(h->d_UT, Uf.data(), n * sizeof(float), hipMemcpyHostToDevice));
     GEMHIP_CHECK(hipMemcpy(h->d_KT, K.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    {
+        std::vector<uint2> UK((size_t)n);
+        for (int64_t i = 0; i < n; ++i) { uint32_t ub; memcpy(&ub, &Uf[i], 4); UK[i] = make_uint2(ub, (uint32_t)K[i]); }
+        if (!h->d_UK) GEMHIP_CHECK(hipMalloc((void **)&h->d_UK, n * sizeof(uint2)));
+        GEMHIP_CHECK(hipMemcpy(h->d_UK, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+    }
     h->unigram_ready = true;
     if (counts_out) std::copy(cnt.begin(), cnt.end(), counts_out);
     if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
@@ -2414,8 +2450,9 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.alpha0 = alpha0; A.denom = (int64_t)epochs * tokens_total + 1;
     // the kernel computes t = token_offset + wl*walk_len + pos with wl the LOCAL walk index
     A.token_offset = token_offset; A.walk_id_offset = h->walk_id_offset; A.epoch = epoch;
-    A.UT = h->d_UT; A.KT = h->d_KT; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
+    A.UT = h->d_UT; A.KT = h->d_KT; A.UK = h->d_UK; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
+    A.dummy = nullptr; A.oscr = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1;
     const bool deterministic = (flags & 4) != 0;
     // Hogwild concurrency.  Each in-flight wavefront has ~7 embedding rows open (read-modify-write) at any
     // time; when (waves x 7) approaches n, concurrent writers overwrite each other's updates and the
@@ -2481,18 +2518,33 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
         }
         int64_t waves = 1;
         bool delta = false;
+        int oscr_on = 0;                                 // A/B (GEMHIP_SGNS_OSCR=1): as-loaded copies in global scratch instead of LDS -> 12 instead of 6 wavefronts per CU; measured 1-5 % slower
+        if (const char *e = getenv("GEMHIP_SGNS_OSCR")) oscr_on = atoi(e);
+        const bool oscr = oscr_on != 0 && !deterministic && mode != 0 && R >= window && rw == h->d;
         if (!deterministic) {
             delta = mode != 0;
-            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(delta) + 512)));
+            const size_t lds_w = oscr ? lds_bytes(false) : lds_bytes(delta);
+            const int64_t vgpr_cap = oscr ? 12 : 8;      // 170 / 183 VGPRs: 3 / 2 wavefronts per SIMD
+            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(vgpr_cap, (int64_t)(160 * 1024) / (int64_t)(lds_w + 512)));
             // a wavefront of this kernel holds 2R+1 more rows (the window) than sgns_kernel's ~8: same bound on the fraction of the
             // table that is open at any time (1/16), hence proportionally fewer concurrent wavefronts on small graphs
             const int64_t hog_win = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
             waves = std::min<int64_t>(std::min<int64_t>(hog_win, 256 * per_cu), walk_hi - walk_lo);
             if (waves == 1 && mode < 0) delta = false;
         }
-        const size_t lds = lds_bytes(delta);
+        const bool use_oscr = oscr && delta;
+        const size_t lds = use_oscr ? lds_bytes(false) : lds_bytes(delta);
         GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for the LDS window (%zu bytes)", lds);
-        A.nwaves = (int32_t)waves; A.cache_radius = R;
+        A.nwaves = (int32_t)waves; A.cache_radius = R; A.oscr = nullptr;
+        if (use_oscr) {
+            const size_t need_o = (size_t)waves * (2 * R + 2) * rw * sizeof(float);
+            if (need_o > h->oscr_bytes) {
+                if (h->d_oscr) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_oscr); h->d_oscr = nullptr; h->oscr_bytes = 0; }
+                GEMHIP_CHECK(hipMalloc(&h->d_oscr, need_o));
+                h->oscr_bytes = need_o;
+            }
+            A.oscr = h->d_oscr;
+        }
         const size_t need = (size_t)waves * rw * sizeof(float);
         if (need > h->dummy_bytes) {
             if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
@@ -2526,7 +2578,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
 
     const size_t per_wave = (size_t)(h->walk_len + 2 * window * SGNS_NEG) * sizeof(int32_t);
     int blocks, threads;
-    A.cache_radius = 0; A.dummy = nullptr; A.prof = nullptr;
+    A.cache_radius = 0; A.dummy = nullptr; A.prof = nullptr; A.oscr = nullptr;
     if (deterministic) { blocks = 1; threads = 64; A.nwaves = 1; }
     else {
         threads = 256;

@@ -12,7 +12,7 @@ r = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 edges = int(sys.argv[3]) if len(sys.argv) > 3 else 10000000
 blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 100
-variants = [('r1_kernel', 11 | 128, 0, -1, 0), ('duo_delta', 11, 10, 1, 0, 1), ('duo_overwrite', 11, 10, 0, 0, 1), ('win_R10_delta', 11, 10, 1, 0), ('win_R10_overwrite', 11, 10, 0, 0),
+variants = [('win_R10_delta_oscr', 11, 10, 1, 0, 0, '1'), ('r1_kernel', 11 | 128, 0, -1, 0), ('duo_delta', 11, 10, 1, 0, 1), ('duo_overwrite', 11, 10, 0, 0, 1), ('win_R10_delta', 11, 10, 1, 0), ('win_R10_overwrite', 11, 10, 0, 0),
             ('win_R7_delta', 11, 7, 1, 0), ('win_R5_delta', 11, 5, 1, 0), ('win_R10_delta_w1024', 11, 10, 1, 1024)]
 if len(sys.argv) > 5:
     keep = sys.argv[5].split(',')
@@ -29,7 +29,8 @@ reps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 for rep in range(reps):
     for v in variants:
         name, flags, R, delta, mw = v[:5]
-        os.environ['GEMHIP_SGNS_DUO'] = '1' if len(v) > 5 else '0'
+        os.environ['GEMHIP_SGNS_DUO'] = '1' if (len(v) > 5 and v[5]) else '0'
+        os.environ['GEMHIP_SGNS_OSCR'] = v[6] if len(v) > 6 else '0'
         _hip.check(L.gemhip_sgns_set_window_cache(b.h, R if R > 0 else -1, delta))
         _hip.check(L.gemhip_n2v_set_max_waves(b.h, mw))
         b.init_tables(20260923); b.pairs(reset=True)

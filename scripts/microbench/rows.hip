@@ -161,11 +161,89 @@ void run_pipe(const char *name, float *T, uint32_t nrows, float *sink, int waves
     fflush(stdout);
 }
 
+// The SGNS memory stream with its side ingredients, one at a time: per iteration 5 rows read-modify-written (loads two iterations ahead),
+// optionally NG uncoalesced 4-byte gathers per lane from an 8 MB table every 11th iteration (the unigram-table lookups of a centre),
+// optionally a dependent ALU chain of ALU fma per iteration (instruction-issue time between memory operations).
+template <int NG, int ALU>
+__global__ __launch_bounds__(64) void rows_mix_kernel(float *T, uint32_t nrows, const int *G, uint32_t gmask, int iters, float *sink)
+{
+    constexpr int U = 5;
+    const int lane = threadIdx.x;
+    const uint32_t wave = blockIdx.x;
+    float2 v[3][U];
+    float acc = 0.f;
+    auto rowof = [&](int it, int u) { return (uint32_t)(((uint64_t)hash32(wave * 0x9E3779B9u + it * U + u + 1) * nrows) >> 32); };
+    auto ld = [&](int it, float2 (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float *p = T + (size_t)rowof(it, u) * 128 + lane * 2;
+            unsigned long long t = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x[u].x = __builtin_bit_cast(float, (unsigned)t); x[u].y = __builtin_bit_cast(float, (unsigned)(t >> 32));
+        }
+    };
+    auto work = [&](int it, float2 (&x)[U]) {
+        if constexpr (NG > 0) {
+            if (it % 11 == 0) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc += (float)G[hash32(wave * 77u + it * 64u + lane + g * 1315423911u) & gmask];
+            }
+        }
+        float c = x[0].x;
+#pragma unroll 1
+        for (int k = 0; k < ALU; ++k) c = fmaf(c, 1.0000001f, 1e-9f);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float *p = T + (size_t)rowof(it, u) * 128 + lane * 2;
+            x[u].x += c * 1e-30f; x[u].y -= 1.0f;
+            unsigned long long t = (unsigned long long)__builtin_bit_cast(unsigned, x[u].x) | ((unsigned long long)__builtin_bit_cast(unsigned, x[u].y) << 32);
+            __hip_atomic_store((gu64 *)p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    ld(0, v[0]); ld(1, v[1]);
+    for (int it = 0; it < iters; it += 3) {
+        ld(it + 2, v[2]); work(it, v[0]);
+        ld(it + 3, v[0]); work(it + 1, v[1]);
+        ld(it + 4, v[1]); work(it + 2, v[2]);
+    }
+    if (acc + v[0][0].x == 12345.678f) sink[0] = acc;
+}
+
+template <int NG, int ALU>
+void run_mix(const char *name, float *T, uint32_t nrows, const int *G, float *sink, int waves_per_cu)
+{
+    const int waves = 256 * waves_per_cu;
+    const int iters = 3996;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((rows_mix_kernel<NG, ALU>), dim3(waves), dim3(64), 0, 0, T, nrows, G, (1u << 21) - 1u, 396, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL((rows_mix_kernel<NG, ALU>), dim3(waves), dim3(64), 0, 0, T, nrows, G, (1u << 21) - 1u, iters, sink);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
+    const double rows = (double)waves * iters * 5;
+    printf("{\"variant\": \"%s\", \"gathers_per_11_iters\": %d, \"alu_chain\": %d, \"waves_per_cu\": %d, \"ms\": %.3f, \"Mrows_per_s\": %.1f, \"TBps\": %.3f, \"ns_per_iter_per_wave\": %.1f}\n",
+           name, NG, ALU, waves_per_cu, ms, rows / ms / 1e3, 2 * rows * 512.0 / (ms * 1e-3) / 1e12, ms * 1e6 / iters);
+    fflush(stdout);
+}
+
 int main(int argc, char **argv)
 {
     const uint32_t nrows = 2000000;       // 1 GB: SynPos + SynNeg of the headline config
     float *T, *sink;
     CK(hipMalloc(&T, (size_t)nrows * 512)); CK(hipMemset(T, 0, (size_t)nrows * 512)); CK(hipMalloc(&sink, 64));
+    if (argc > 1 && argv[1][0] == 'm') {
+        int *G; CK(hipMalloc(&G, (size_t)(1u << 21) * 4)); CK(hipMemset(G, 0, (size_t)(1u << 21) * 4));
+        for (int w : {6, 12}) {
+            run_mix<0, 0>("mix", T, nrows, G, sink, w);
+            run_mix<6, 0>("mix", T, nrows, G, sink, w);
+            run_mix<0, 100>("mix", T, nrows, G, sink, w);
+            run_mix<0, 200>("mix", T, nrows, G, sink, w);
+            run_mix<0, 400>("mix", T, nrows, G, sink, w);
+            run_mix<6, 200>("mix", T, nrows, G, sink, w);
+        }
+        return 0;
+    }
     if (argc > 1) {
         for (int w : {6, 12}) {
             run_pipe<0, 5>("sc1_8B_rmw_pipe", T, nrows, sink, w);
