@@ -227,11 +227,102 @@ void run_mix(const char *name, float *T, uint32_t nrows, const int *G, float *si
     fflush(stdout);
 }
 
+// Same question in the request-bound regime (with the table gathers): do 16-byte-per-lane accesses that move TWO rows per instruction
+// (lanes 0-31 one row, 32-63 another) relieve the pipeline compared with 8-byte-per-lane accesses (one row per instruction)?  6 rows per iteration.
+template <bool WIDE, int NG>
+__global__ __launch_bounds__(64) void rows_mix6_kernel(float *T, uint32_t nrows, const int *G, uint32_t gmask, int iters, float *sink)
+{
+    constexpr int U = 6;
+    const int lane = threadIdx.x;
+    const uint32_t wave = blockIdx.x;
+    float acc = 0.f;
+    auto rowof = [&](int it, int u) { return (uint32_t)(((uint64_t)hash32(wave * 0x9E3779B9u + it * U + u + 1) * nrows) >> 32); };
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(T, 0, (int)0x7fffffff, 0x00020000);
+    const int half = lane >> 5, l = lane & 31;
+    struct Set { float2 n[U]; u32x4v w[U / 2]; };
+    Set v[3];
+    auto ld = [&](int it, Set &x) {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int u = 0; u < U / 2; ++u) {
+                const uint32_t row = half ? rowof(it, 2 * u + 1) : rowof(it, 2 * u);
+                x.w[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(row * 512u + l * 16u), 0, 16);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float *p = T + (size_t)rowof(it, u) * 128 + lane * 2;
+                unsigned long long t = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x.n[u].x = __builtin_bit_cast(float, (unsigned)t); x.n[u].y = __builtin_bit_cast(float, (unsigned)(t >> 32));
+            }
+        }
+    };
+    auto work = [&](int it, Set &x) {
+        if constexpr (NG > 0) {
+            if (it % 11 == 0) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc += (float)G[hash32(wave * 77u + it * 64u + lane + g * 1315423911u) & gmask];
+            }
+        }
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int u = 0; u < U / 2; ++u) {
+                const uint32_t row = half ? rowof(it, 2 * u + 1) : rowof(it, 2 * u);
+                x.w[u].x += 1u;
+                __builtin_amdgcn_raw_buffer_store_b128(x.w[u], rs, (int)(row * 512u + l * 16u), 0, 16);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float *p = T + (size_t)rowof(it, u) * 128 + lane * 2;
+                x.n[u].x += 1.0f;
+                unsigned long long t = (unsigned long long)__builtin_bit_cast(unsigned, x.n[u].x) | ((unsigned long long)__builtin_bit_cast(unsigned, x.n[u].y) << 32);
+                __hip_atomic_store((gu64 *)p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    ld(0, v[0]); ld(1, v[1]);
+    for (int it = 0; it < iters; it += 3) {
+        ld(it + 2, v[2]); work(it, v[0]);
+        ld(it + 3, v[0]); work(it + 1, v[1]);
+        ld(it + 4, v[1]); work(it + 2, v[2]);
+    }
+    if (acc + v[0].n[0].x + __builtin_bit_cast(float, v[0].w[0].x) == 12345.678f) sink[0] = acc;
+}
+
+template <bool WIDE, int NG>
+void run_mix6(float *T, uint32_t nrows, const int *G, float *sink, int waves_per_cu)
+{
+    const int waves = 256 * waves_per_cu;
+    const int iters = 3996;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((rows_mix6_kernel<WIDE, NG>), dim3(waves), dim3(64), 0, 0, T, nrows, G, (1u << 21) - 1u, 396, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL((rows_mix6_kernel<WIDE, NG>), dim3(waves), dim3(64), 0, 0, T, nrows, G, (1u << 21) - 1u, iters, sink);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
+    const double rows = (double)waves * iters * 6;
+    printf("{\"variant\": \"mix6\", \"form\": \"%s\", \"gathers_per_11_iters\": %d, \"waves_per_cu\": %d, \"ms\": %.3f, \"Mrows_per_s\": %.1f, \"TBps\": %.3f}\n",
+           WIDE ? "sc1 16 B/lane, two rows per instruction" : "sc1 8 B/lane, one row per instruction", NG, waves_per_cu, ms, rows / ms / 1e3, 2 * rows * 512.0 / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
 int main(int argc, char **argv)
 {
     const uint32_t nrows = 2000000;       // 1 GB: SynPos + SynNeg of the headline config
     float *T, *sink;
     CK(hipMalloc(&T, (size_t)nrows * 512)); CK(hipMemset(T, 0, (size_t)nrows * 512)); CK(hipMalloc(&sink, 64));
+    if (argc > 1 && argv[1][0] == 'w') {
+        int *G; CK(hipMalloc(&G, (size_t)(1u << 21) * 4)); CK(hipMemset(G, 0, (size_t)(1u << 21) * 4));
+        for (int w : {6, 12}) {
+            run_mix6<false, 0>(T, nrows, G, sink, w); run_mix6<true, 0>(T, nrows, G, sink, w);
+            run_mix6<false, 2>(T, nrows, G, sink, w); run_mix6<true, 2>(T, nrows, G, sink, w);
+            run_mix6<false, 6>(T, nrows, G, sink, w); run_mix6<true, 6>(T, nrows, G, sink, w);
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'm') {
         int *G; CK(hipMalloc(&G, (size_t)(1u << 21) * 4)); CK(hipMemset(G, 0, (size_t)(1u << 21) * 4));
         for (int w : {6, 12}) {
