@@ -102,10 +102,24 @@ class GFWorkload(object):
         log('[rank %d] GF plan: rows %d updates %d levels %d' % (rank, self.b.rows, self.b.updates, self.b.levels))
 
     def step(self):
-        self.last = self.job.sweep(self.eta, self.regu)
+        if self.world > 1:
+            self.last = self.job.sweep(self.eta, self.regu)
+            return
+        # one GPU: sweeps are handed to the library in batches of 64, the way GraphFactorization.learn_embedding hands it max_iter of them
+        # (gemhip_gf_plan_sweeps replays a captured hipGraph on launch-bound graphs); every counted sweep runs inside the timed region
+        self.pending = getattr(self, 'pending', 0) + 1
+        if self.pending == 64:
+            self._flush()
+
+    def _flush(self):
+        if getattr(self, 'pending', 0):
+            self.last = self.b.sweeps(self.pending, self.eta, self.regu)
+            self.pending = 0
 
     def finish(self):
         """End of a training run (inside the timed region): every rank assembles the full table."""
+        if self.world == 1:
+            self._flush()
         self.last = self.job.gather(self.last)
 
     def units_per_step(self):

@@ -224,6 +224,13 @@ class HipBackendGF(object):
         self.cur ^= 1
         return self.X[self.cur]
 
+    def sweeps(self, k, eta, regu):
+        """k sweeps in one call (launch-bound graphs replay a captured hipGraph of 16 sweeps)."""
+        s = self.torch.cuda.current_stream().cuda_stream
+        _hip.check(self.L.gemhip_gf_plan_sweeps(self.plan, k, eta, regu, C.c_void_p(s)))
+        self.cur ^= (k & 1)
+        return self.X[self.cur]
+
     def close(self):
         _hip.check(self.L.gemhip_gf_plan_destroy(self.plan))
 
