@@ -53,17 +53,27 @@ class TorchComm(object):
         else:
             full.copy_(own)
 
-    def all_gather_ints(self, values, device):
+    def side_group(self):
+        """A second process group (its own RCCL communicator and stream) for collectives that run AHEAD of the training stream
+        (Node2VecPartitioned._prepare): torch serialises all collectives of one group on one internal stream in issue order, so on
+        the default group the next episode's all-to-all would queue behind this episode's ring shifts and lose the overlap."""
+        if self.world == 1:
+            return None
+        if getattr(self, '_side', None) is None:
+            self._side = self.dist.new_group(ranks=list(range(self.world)))
+        return self._side
+
+    def all_gather_ints(self, values, device, group=None):
         """Every rank's list of ints -> [world][len(values)] nested list (tiny control message)."""
         if self.world == 1:
             return [list(values)]
         import torch
         v = torch.as_tensor(list(values), dtype=torch.int64, device=device)
         out = torch.empty(self.world * v.numel(), dtype=torch.int64, device=device)
-        self.dist.all_gather_into_tensor(out, v)
+        self.dist.all_gather_into_tensor(out, v, group=group)
         return out.view(self.world, v.numel()).cpu().tolist()
 
-    def all_to_all_rows(self, send, send_counts, recv_counts=None, cached=False):
+    def all_to_all_rows(self, send, send_counts, recv_counts=None, cached=False, group=None):
         """send: [m, c] rows grouped by destination rank (send_counts[r] rows for rank r, in rank order).
         Returns the rows addressed to this rank, grouped by source rank."""
         if self.world == 1:
@@ -72,12 +82,12 @@ class TorchComm(object):
         dist = self.dist
         rank = dist.get_rank()
         if recv_counts is None:
-            recv_counts = [row[rank] for row in self.all_gather_ints(send_counts, send.device)]
+            recv_counts = [row[rank] for row in self.all_gather_ints(send_counts, send.device, group=group)]
         recv_counts = [int(x) for x in recv_counts]
         send_counts = [int(x) for x in send_counts]
         out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         if dist.get_backend() == 'nccl':
-            dist.all_to_all_single(out, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts)
+            dist.all_to_all_single(out, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
             return out
         ops, so, ro = [], 0, 0
         keep = []
@@ -88,9 +98,9 @@ class TorchComm(object):
             else:
                 if a:
                     t = send[so:so + a].contiguous(); keep.append(t)
-                    ops.append(dist.P2POp(dist.isend, t, r))
+                    ops.append(dist.P2POp(dist.isend, t, r, group=group))
                 if b:
-                    ops.append(dist.P2POp(dist.irecv, out[ro:ro + b], r))
+                    ops.append(dist.P2POp(dist.irecv, out[ro:ro + b], r, group=group))
             so += a; ro += b
         if ops:
             for w in dist.batch_isend_irecv(ops):
@@ -303,10 +313,12 @@ class Node2VecPartitioned(object):
         nloc = self.hi - self.lo
         a, z = shard_range(nloc, e, self.episodes)
         pairs, counts = b.emit_pairs_bucketed(self.window, ep, a, z, self.seed, W)
-        cm = comm.all_gather_ints(counts, pairs.device)              # cm[src][dest * W + wpart]
+        side = comm.side_group() if hasattr(comm, 'side_group') else None
+        kw = {'group': side} if side is not None else {}
+        cm = comm.all_gather_ints(counts, pairs.device, **kw)        # cm[src][dest * W + wpart]
         send_counts = [sum(counts[r * W:(r + 1) * W]) for r in range(W)]
         recv_counts = [sum(cm[src][g * W:(g + 1) * W]) for src in range(W)]
-        mine = comm.all_to_all_rows(pairs, send_counts, recv_counts)  # grouped by source rank, then by word % W
+        mine = comm.all_to_all_rows(pairs, send_counts, recv_counts, **kw)  # grouped by source rank, then by word % W
         seg, at = [[None] * W for _ in range(W)], 0
         for src in range(W):
             for j in range(W):
