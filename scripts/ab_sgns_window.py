@@ -13,7 +13,7 @@ nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 edges = int(sys.argv[3]) if len(sys.argv) > 3 else 10000000
 blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 variants = [('win_R10_delta_oscr', 11, 10, 1, 0, 0, '1'), ('r1_kernel', 11 | 128, 0, -1, 0), ('duo_delta', 11, 10, 1, 0, 1), ('duo_overwrite', 11, 10, 0, 0, 1), ('win_R10_delta', 11, 10, 1, 0), ('win_R10_overwrite', 11, 10, 0, 0),
-            ('win_R7_delta', 11, 7, 1, 0), ('win_R5_delta', 11, 5, 1, 0), ('win_R10_delta_w1024', 11, 10, 1, 1024)]
+            ('win_R7_delta', 11, 7, 1, 0), ('win_R5_delta', 11, 5, 1, 0), ('win_R10_delta_w1024', 11, 10, 1, 1024), ('win_w400', 11, 10, 1, 400), ('win_w800', 11, 10, 1, 800), ('win_w1536', 11, 10, 1, 1536), ('r1_w800', 11 | 128, 0, -1, 800)]
 if len(sys.argv) > 5:
     keep = sys.argv[5].split(',')
     variants = [v for v in variants if v[0] in keep]
@@ -23,7 +23,7 @@ row_ptr, col, ww = to_csr(n, src, dst, w)
 b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, 128)
 L = _hip.lib()
 m = b.num_start_nodes(); b.walks(1.0, 1.0, r, 80, 20260923, 11, 0, m * r); b.vocab(); b.build_unigram()
-sample = np.random.RandomState(0).choice(n, size=256, replace=False)
+sample = np.random.RandomState(0).choice(n, size=min(1024, n), replace=False)
 out = []
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 for rep in range(reps):
