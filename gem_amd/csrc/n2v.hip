@@ -1935,42 +1935,84 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
         for (int c = 0; c < NV; ++c)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) neu[c][v] = 0.f;
-        {
-            float part = 0.f;
-#pragma unroll
-            for (int c = 0; c < NV; ++c)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yp[c][v], part);
-            const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
-#pragma unroll
-            for (int c = 0; c < NV; ++c)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yp[c][v], neu[c][v]); yp[c][v] = fmaf(g, xc[c][v], yp[c][v]); }
-        }
+        // the six targets of a pair are independent unless one repeats or equals the centre word: then one transposed reduction gives the six
+        // dot products and the sigmoid runs once, lane-parallel (wave_sum6, as in sgns_win_kernel); otherwise TrainModel's sequential order
+        bool special = false;
 #pragma unroll
         for (int j = 0; j < SGNS_NEG; ++j) {
-            if (tgt[j] == word_l) continue;
+            special = special || tgt[j] == word_l;
 #pragma unroll
-            for (int jp = 0; jp < j; ++jp)
-                if (tgt[jp] == tgt[j] && tgt[jp] != word_l) {
+            for (int jp = 0; jp < j; ++jp) special = special || tgt[jp] == tgt[j];
+        }
+        if (!special && !(A.flags & 256)) {            // (flag 256: A/B switch, sequential order for every pair)
+            float part[6];
 #pragma unroll
-                    for (int c = 0; c < NV; ++c)
+            for (int j = 0; j < 6; ++j) part[j] = 0.f;
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) yn[j][c][v] = yn[jp][c][v];
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    part[0] = fmaf(xc[c][v], yp[c][v], part[0]);
+#pragma unroll
+                    for (int j = 0; j < SGNS_NEG; ++j) part[j + 1] = fmaf(xc[c][v], yn[j][c][v], part[j + 1]);
                 }
-            float part = 0.f;
+            const float f = wave_sum6(part, lane);
+            const float gl = sgns_grad_fast(f, (lane & 7) == 0 ? 1.0f : 0.0f, alpha);
+            float g[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) g[j] = bcast_lane(gl, j);
 #pragma unroll
             for (int c = 0; c < NV; ++c)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yn[j][c][v], part);
-            const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+                for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g[0], yp[c][v], neu[c][v]); yp[c][v] = fmaf(g[0], xc[c][v], yp[c][v]); }
 #pragma unroll
-            for (int c = 0; c < NV; ++c)
+            for (int j = 0; j < SGNS_NEG; ++j) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
-            float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+                for (int c = 0; c < NV; ++c)
 #pragma unroll
-            for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+                    for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g[j + 1], yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g[j + 1], xc[c][v], yn[j][c][v]); }
+                float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+            }
+        } else {
+            {
+                float part = 0.f;
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yp[c][v], part);
+                const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yp[c][v], neu[c][v]); yp[c][v] = fmaf(g, xc[c][v], yp[c][v]); }
+            }
+#pragma unroll
+            for (int j = 0; j < SGNS_NEG; ++j) {
+                if (tgt[j] == word_l) continue;
+#pragma unroll
+                for (int jp = 0; jp < j; ++jp)
+                    if (tgt[jp] == tgt[j] && tgt[jp] != word_l) {
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) yn[j][c][v] = yn[jp][c][v];
+                    }
+                float part = 0.f;
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yn[j][c][v], part);
+                const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
+                float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
