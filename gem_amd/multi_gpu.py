@@ -313,7 +313,12 @@ class Node2VecPartitioned(object):
         nloc = self.hi - self.lo
         a, z = shard_range(nloc, e, self.episodes)
         pairs, counts = b.emit_pairs_bucketed(self.window, ep, a, z, self.seed, W)
-        side = comm.side_group() if hasattr(comm, 'side_group') else None
+        # GEM_N2V_SIDE_GROUP=1: route these look-ahead collectives through a second process group so that they overlap the training rounds
+        # (on the default group torch serialises them behind this episode's ring shifts: correct by construction, ~5-10 % of an episode
+        # at N=8).  Off by default: two RCCL communicators progressing concurrently next to a kernel that fills the GPU is the one
+        # configuration this round could not exercise (no multi-GPU box), and a hang there would cost the whole scaling run.
+        import os
+        side = comm.side_group() if (hasattr(comm, 'side_group') and os.environ.get('GEM_N2V_SIDE_GROUP') == '1') else None
         kw = {'group': side} if side is not None else {}
         cm = comm.all_gather_ints(counts, pairs.device, **kw)        # cm[src][dest * W + wpart]
         send_counts = [sum(counts[r * W:(r + 1) * W]) for r in range(W)]
