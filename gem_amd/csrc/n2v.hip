@@ -2583,11 +2583,11 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(vgpr_cap, (int64_t)(160 * 1024) / (int64_t)(lds_w + 512)));
             // a wavefront of this kernel holds 2R+1 more rows (the window) than sgns_kernel's ~8: same bound on the fraction of the
             // table that is open at any time (1/16), hence proportionally fewer concurrent wavefronts on small graphs
-            // ... measured both ways: SBM-1024 (d=16) loses 3.5 % MAP at 8 wavefronts (n/128) and nothing at 2 (n/464); SBM 100k (d=128) keeps its
-            // MAP within 0.1 % of the race-free reference binary at n/128 = 781 wavefronts and loses 0.3 % at 1536 (scripts/ab_sgns_window.py,
-            // profiles/r02_ab_sgns_window_100k.json) -- so the tighter bound applies to small graphs only
+            // ... measured both ways: SBM-1024 (d=16) loses 3.5 % MAP at 8 wavefronts (n/128) and nothing at 2 (n/464); at d=128, SBM 16k / 32k /
+            // 100k keep their MAP at n/128 wavefronts (0.9267 vs 0.9261, 0.9297 vs 0.9298, 0.9132 vs the reference binary's 0.9127) and lose
+            // 0.1-0.3 % at n/64 (scripts/ab_sgns_window.py, profiles/r02_ab_sgns_window_{16k,32k,100k}.json) -- the tighter bound is for tiny graphs
             const int64_t hog_win = h->max_waves > 0 ? h->max_waves
-                                  : h->n >= 65536 ? hog_cap : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
+                                  : h->n >= 8192 ? hog_cap : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
             waves = std::min<int64_t>(std::min<int64_t>(hog_win, 256 * per_cu), walk_hi - walk_lo);
             if (waves == 1 && mode < 0) delta = false;
         }

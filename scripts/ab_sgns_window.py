@@ -16,7 +16,8 @@ variants = [('win_R10_delta_oscr', 11, 10, 1, 0, 0, '1'), ('r1_kernel', 11 | 128
             ('win_R7_delta', 11, 7, 1, 0), ('win_R5_delta', 11, 5, 1, 0), ('win_R10_delta_w1024', 11, 10, 1, 1024), ('win_w400', 11, 10, 1, 400), ('win_w800', 11, 10, 1, 800), ('win_w1536', 11, 10, 1, 1536), ('r1_w800', 11 | 128, 0, -1, 800)]
 if len(sys.argv) > 5:
     keep = sys.argv[5].split(',')
-    variants = [v for v in variants if v[0] in keep]
+    extra = [('win_w%d' % int(k[5:]), 11, 10, 1, int(k[5:])) for k in keep if k.startswith('win_w') and k not in [v[0] for v in variants]]
+    variants = [v for v in variants + extra if v[0] in keep]
 g = sbm_graph(nodes, edges, blocks, seed=20260923 + 4)
 n, src, dst, w, _ = edge_arrays(g)
 row_ptr, col, ww = to_csr(n, src, dst, w)
