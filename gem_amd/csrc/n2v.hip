@@ -2520,7 +2520,12 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     if (const char *e = getenv("GEMHIP_SGNS_CACHE_R")) R = atoi(e);
     if (R < 0) R = 10;
     R = std::min(R, std::min(window, 31));
-    const bool win_ok = R > 0 && !(flags & (32 | 64 | GEMHIP_N2V_NO_WINDOW_CACHE)) && 2 * window * SGNS_NEG <= 2 * WAVE && h->walk_len >= 2;
+    bool win_ok = R > 0 && !(flags & (32 | 64 | GEMHIP_N2V_NO_WINDOW_CACHE)) && 2 * window * SGNS_NEG <= 2 * WAVE && h->walk_len >= 2;
+    if (win_ok) {      // the window (2R+1 rows, twice with the delta write-back) has to fit a block's LDS: wide rows / long walks fall back to sgns_kernel
+        const size_t rwb = (size_t)sgns_win_row_floats(h->d) * sizeof(float);
+        const size_t worst = (size_t)((h->walk_len + 4 * window * SGNS_NEG + 3) & ~3) * sizeof(int32_t) + (size_t)((2 * R + 1) * 2 + 1) * rwb;
+        win_ok = worst <= 64 * 1024 && (h->d % 2 == 0 ? h->d <= 512 : h->d <= 256);
+    }
     if (win_ok) {
         int mode = h->cache_delta;                       // -1 auto: delta write-back whenever other wavefronts train concurrently
         if (const char *e = getenv("GEMHIP_SGNS_CACHE_DELTA")) mode = atoi(e);

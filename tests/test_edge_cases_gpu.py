@@ -75,3 +75,14 @@ def test_bad_arguments_are_reported_not_crashed():
     assert L.gemhip_n2v_create(3, 2, _hip.ptr(rp, C.c_int64), _hip.ptr(col, C.c_int32), None, C.byref(h)) == -1
     assert L.gemhip_hope(3, 2, _hip.ptr(rp, C.c_int64), _hip.ptr(np.array([1, 0], np.int32), C.c_int32), None, 0.01, 5, 2, 3, 2, 1e-5, 1,
                          _hip.ptr(X, C.c_float), _hip.ptr(X, C.c_float), _hip.ptr(X, C.c_float), None) == -1
+
+
+@pytest.mark.parametrize('d', [384, 512])
+def test_node2vec_wide_rows_fall_back_to_the_round1_kernel(d):
+    """The LDS window of the default SGNS kernel holds 2R+1 rows (twice with the delta write-back): at d >= 384 it no longer fits a block's
+    64 KB and training runs on the round-1 kernel instead of failing."""
+    from gem_amd.graph import sbm_graph
+    g = sbm_graph(2048, 20480, 2, seed=3)
+    m = node2vec(d=d, max_iter=1, walk_len=20, num_walks=2, con_size=10, ret_p=1, inout_p=1, seed=1)
+    Y = m.learn_embedding(graph=g, is_weighted=True, no_python=True)
+    assert Y.shape == (2048, d) and np.isfinite(Y).all() and np.abs(Y).max() > 1e-4
