@@ -44,6 +44,26 @@ def test_two_rank_bench_line(workload, extra):
         assert ph['train'] > 0 and ph['shift'] >= 0 and ph['prep'] > 0
 
 
+def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference():
+    """The same comparison at BASELINE's own size (SBM 1M/10M).  The reference runs take ~7 h of CPU each
+    (scripts/make_golden_n2v_scale.py --nodes 1000000 --edges 10000000 --blocks 100 [--engine oracle]); the test uses whichever of the
+    two goldens is committed -- the binary's (tests/golden/n2v_ref_snap_1000k.json) or the sequential restatement's (..._oracle_1000k.json,
+    which lands on the binary to 0.3 % at 100k) -- and is skipped while neither is."""
+    refs = [(e, golden_path('n2v_ref_%s_1000k.json' % e)) for e in ('snap', 'oracle')]
+    refs = [(e, json.load(open(f))) for e, f in refs if os.path.exists(f)]
+    if not refs:
+        pytest.skip('no 1M/10M reference run committed yet')
+    pr = refs[0][1]['params']
+    g = sbm_graph(pr['n'], pr['edges'], pr['blocks'], pr['seed'])
+    nodes = np.random.RandomState(0).choice(g.n, size=len(refs[0][1]['ap']), replace=False)
+    m = node2vec(d=pr['d'], max_iter=1, walk_len=pr['walk_len'], num_walks=pr['num_walks'], con_size=pr['window'], ret_p=1, inout_p=1,
+                 seed=20260923)
+    X = m.learn_embedding(graph=g, is_weighted=True, no_python=True)
+    ap = gr.sampled_ap_gpu(g, None, X, nodes)
+    for engine, ref in refs:
+        assert abs(ap.mean() - ref['MAP']) <= 0.01 * ref['MAP'], (engine, ap.mean(), ref['MAP'])
+
+
 def test_node2vec_map_at_100k_within_one_percent_of_the_reference_binary():
     """north_star: MAP within 1 % of the reference.  gem/c_exe/node2vec (race-free, OMP_NUM_THREADS=1: 57 minutes of CPU) on
     SBM 100k/1M gives MAP 0.9127 over a fixed 1024-node sample; the HIP path on the same graph is scored on the same nodes
