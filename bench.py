@@ -360,6 +360,7 @@ class HopeWorkload(object):
                 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6, 'spmm_launches_per_step': launches / self.calls,
                 'avg_block_columns': bavg, 'device_seconds_per_step': self.dev_s / self.calls, 'spmm_seconds_per_step': self.spmm_s / self.calls,
                 'host_eig_seconds_per_step': self.eig_s / self.calls, 'restarts': self.stats[5], 'katz_terms': self.stats[3],
+                'solver': 'symmetric_chebyshev_filter' if self.stats[3] == 0 else 'block_krylov',
                 'note': 'algorithmic = SURVEY 8d compulsory bytes of one SpMM (8 nnz + 4(n+1) + 8 n b: the dense block is read once); the row '
                         'gathers themselves move %.3g B per launch = %.0f GB/s out of L2 / Infinity Cache (the %d MB block fits on chip); launch '
                         'time = HIP events around the back-to-back SpMM runs inside the solver' % (gather, gather / avg_s / 1e9, int(4 * self.n * bavg / 1e6))}

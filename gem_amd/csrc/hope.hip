@@ -37,7 +37,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int CPL>
 __global__ __launch_bounds__(256) void hope_spmm_kernel(int64_t n, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
                                                         const float *__restrict__ val, float alpha, const float *__restrict__ X, int ldx,
-                                                        const float *__restrict__ Wadd, int ldw, float *__restrict__ Y, int ldy, int b)
+                                                        const float *__restrict__ Wadd, int ldw, float *__restrict__ Y, int ldy, int b,
+                                                        float wa, const float *__restrict__ W2, int ldw2, float wb)
 {
     const int lane = lane_id();
     const int64_t i = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -70,7 +71,10 @@ __global__ __launch_bounds__(256) void hope_spmm_kernel(int64_t n, const int64_t
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const int cc = lane + c * WAVE;
-        if (cc < b) Y[i * ldy + cc] = alpha * acc[c] + (Wadd ? Wadd[i * ldw + cc] : 0.f);
+        if (cc >= b) continue;
+        if (!W2 && wa == 1.0f) Y[i * ldy + cc] = alpha * acc[c] + (Wadd ? Wadd[i * ldw + cc] : 0.f);
+        else                                                    // three-term recurrences: alpha A X + wa W + wb W2
+            Y[i * ldy + cc] = fmaf(alpha, acc[c], fmaf(wa, Wadd ? Wadd[i * ldw + cc] : 0.f, W2 ? wb * W2[i * ldw2 + cc] : 0.f));
     }
 }
 
@@ -211,6 +215,32 @@ __global__ void hope_randn_kernel(float *X, int64_t n, int b, int ld, uint64_t s
         const int64_t e = t * 4 + k;
         if (e < total) X[(e / b) * ld + (e % b)] = z[k];
     }
+}
+
+// val[j] = the entry of column j with the largest magnitude (the first such row on ties): the sign convention of the outputs is
+// "that entry of the left vector is positive".  One block per column; the block's rows are L2 / Infinity Cache hits.
+__global__ __launch_bounds__(256) void hope_colmax_kernel(int64_t n, const float *__restrict__ X, int ld, float *__restrict__ val)
+{
+    __shared__ float s_abs[256], s_val[256];
+    __shared__ long long s_idx[256];
+    const int j = blockIdx.x;
+    float best = -1.f, bv = 0.f; long long bi = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float v = X[i * ld + j], a = fabsf(v);
+        if (a > best) { best = a; bv = v; bi = i; }
+    }
+    s_abs[threadIdx.x] = best; s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            const float a = s_abs[threadIdx.x + st];
+            if (a > s_abs[threadIdx.x] || (a == s_abs[threadIdx.x] && s_idx[threadIdx.x + st] < s_idx[threadIdx.x])) {
+                s_abs[threadIdx.x] = a; s_val[threadIdx.x] = s_val[threadIdx.x + st]; s_idx[threadIdx.x] = s_idx[threadIdx.x + st];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) val[j] = s_val[0];
 }
 
 // ------------------------------------------------------------- host: symmetric eigensolver (fp64)
@@ -606,14 +636,15 @@ struct Hope {
 
 #define HOPE_TRY(h, x) do { if (!(h).err) { hipError_t _e = (x); if (_e != hipSuccess) { (h).err = fail(GEMHIP_E_HIP, "hope: %s: %s", #x, hipGetErrorString(_e)); } } } while (0)
 
-void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const float *Wadd, int ldw, float *Y, int ldy, int b)
+void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const float *Wadd, int ldw, float *Y, int ldy, int b,
+          float wa = 1.0f, const float *W2 = nullptr, int ldw2 = 0, float wb = 0.f)
 {
     if (H.err) return;
     const int64_t blocks = (H.n + 3) / 4;
     const dim3 grid((unsigned)((blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD)), blk(256);
     const int64_t *rp = transpose ? H.rpT : H.rp; const int32_t *ci = transpose ? H.ciT : H.ci; const float *va = transpose ? H.vaT : H.va;
     const int cpl = (b + 63) / 64;
-#define SPMM(C) hipLaunchKernelGGL((hope_spmm_kernel<C>), grid, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b)
+#define SPMM(C) hipLaunchKernelGGL((hope_spmm_kernel<C>), grid, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
     if (cpl <= 1) SPMM(1); else if (cpl <= 2) SPMM(2); else if (cpl <= 4) SPMM(4); else SPMM(8);
 #undef SPMM
     H.spmm_count += 1; H.spmm_cols += b;
@@ -1031,10 +1062,258 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
 }
 
 
+// ------------------------------------------------------------------ symmetric graphs: Chebyshev-filtered subspace iteration
+// For A = A^T the Katz operator S = sum_t (beta A)^t = f(A), f(x) = beta x / (1 - beta x), has the eigenvectors of A: singular value
+// |f(lambda)|, right vector q, left vector sign(f(lambda)) q.  The k largest |f(lambda)| sit at the two ends of A's spectrum, so the
+// series is never applied: a block of k + oversample vectors is filtered with a Chebyshev polynomial of A that is bounded on the
+// unwanted interval [-a_minus, a_plus] (|f| below the block's smallest Ritz |f|) and grows outside it (one SpMM per degree, fused
+// three-term recurrence), orthonormalised, and rotated by a (k + oversample)-sized Rayleigh-Ritz step on A.  Converged leading pairs
+// are locked and projected out.  The filter degree of a cycle is capped by the growth at the spectrum's edge (fp32: what is known to
+// ~1e-7 relative must not be amplified past the wanted directions).  Against the block-Krylov path on S^T S this needs ~7x fewer SpMM
+// columns, no n x 512 basis and no 512 x 512 projected eigenproblem (measured: DESIGN.md 3.2).
+namespace {
+
+// CholeskyQR on the column-NORMALISED Gram matrix (filtered columns differ in length by the filter's growth; an entry of the fp32
+// Gram matrix is accurate relative to the product of its two column norms, so the scaled matrix is accurate entrywise).  Falls back
+// to the scaled Gram's eigen-decomposition when a pivot is lost, dropping directions below 1e-6 relative energy.
+int orth_scaled(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, int passes)
+{
+    int keep = b;
+    for (int pass = 0; pass < passes && keep > 0 && !H.err; ++pass) {
+        std::vector<double> G, w, C, dinv(keep, 0.0);
+        gram(H, Y, ld, keep, Y, ld, keep, G);
+        if (H.err) return 0;
+        for (int i = 0; i < keep; ++i) { const double g = G[(size_t)i * keep + i]; dinv[i] = (g > 0.0 && std::isfinite(g)) ? 1.0 / std::sqrt(g) : 0.0; }
+        for (int i = 0; i < keep; ++i)
+            for (int j = 0; j < keep; ++j) G[(size_t)i * keep + j] *= dinv[i] * dinv[j];
+        for (int i = 0; i < keep; ++i) if (dinv[i] == 0.0) G[(size_t)i * keep + i] = 0.0;
+        int nk = keep;
+        if (!chol_inverse(keep, G, 1e-5, C)) {
+            sym_eig(keep, G, w);
+            const double lmax = std::max(w[keep - 1], 0.0);
+            int first = 0;
+            while (first < keep && !(w[first] > 1e-6 * lmax && w[first] > 0.0)) ++first;
+            nk = keep - first;
+            if (nk == 0) return 0;
+            C.assign((size_t)keep * nk, 0.0);
+            for (int i = 0; i < keep; ++i)
+                for (int j = 0; j < nk; ++j) C[(size_t)i * nk + j] = G[(size_t)i * keep + (keep - 1 - j)] / std::sqrt(w[keep - 1 - j]);
+        }
+        for (int i = 0; i < keep; ++i)
+            for (int j = 0; j < nk; ++j) C[(size_t)i * nk + j] *= dinv[i];
+        tsgemm(H, Y, ld, keep, C, nk, 1.0f, nullptr, 0, Tmp, ldt);
+        HOPE_TRY(H, hipMemcpy2DAsync(Y, (size_t)ld * sizeof(float), Tmp, (size_t)ldt * sizeof(float), (size_t)nk * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
+        keep = nk;
+    }
+    return keep;
+}
+
+// V[:, :cols] <- T_m((A - c I) / e) V[:, :cols]   (Chebyshev polynomial of the first kind; F[0..2]: n x cols scratch, leading dimension ldf).
+// Q[:, :nl] (locked eigenvectors) is projected out of the two live terms of the recurrence every q degrees: what the locked directions
+// regain through their residuals and through rounding grows by the filter's edge growth per degree, q keeps that below ~1e3.
+void cheb_filter(Hope &H, float *V, int ldv, int cols, int m, double c, double e, float *const F[3], int ldf, const float *Q, int ldq, int nl, int q)
+{
+    if (H.err || cols == 0 || m < 1) return;
+    int i1 = 0, i0 = -1;                                                                                           // F[i1] = Y_j, F[i0] = Y_{j-1} (-1: V)
+    { SpmmTimer timer(H); spmm(H, false, (float)(1.0 / e), V, ldv, V, ldv, F[0], ldf, cols, (float)(-c / e)); }   // Y1 = (A V - c V) / e
+    int j = 2;
+    while (j <= m && !H.err) {
+        if (nl > 0 && q > 0 && (j - 1) % q == 0) {
+            if (i0 < 0) project_out(H, Q, ldq, nl, V, ldv, cols); else project_out(H, Q, ldq, nl, F[i0], ldf, cols);
+            project_out(H, Q, ldq, nl, F[i1], ldf, cols);
+        }
+        SpmmTimer timer(H);
+        do {
+            int i2 = 0;
+            while (i2 == i1 || i2 == i0) ++i2;
+            const float *y0 = i0 < 0 ? V : F[i0];
+            spmm(H, false, (float)(2.0 / e), F[i1], ldf, F[i1], ldf, F[i2], ldf, cols, (float)(-2.0 * c / e), y0, i0 < 0 ? ldv : ldf, -1.0f);   // Y_{j+1} = 2 (A - c) Y_j / e - Y_{j-1}
+            i0 = i1; i1 = i2; ++j;
+        } while (j <= m && !(nl > 0 && q > 0 && (j - 1) % q == 0));
+    }
+    HOPE_TRY(H, hipMemcpy2DAsync(V, (size_t)ldv * sizeof(float), F[i1], (size_t)ldf * sizeof(float), (size_t)cols * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
+}
+
+}  // namespace
+
+// Returns H.err; *fell_back = true when the iteration broke down or did not converge in max_cycles (the caller then runs the
+// general block-Krylov solver); outputs are only written on success.
+static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t max_cycles, float tol, uint64_t seed, double br,
+                          float *U_sqrtS, float *V_sqrtS, float *sigma, double *stats, bool *fell_back)
+{
+    *fell_back = false;
+    const double beta = H.beta;
+    auto fk = [&](double x) { return beta * x / (1.0 - beta * x); };
+    const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
+    const int ldv = (b + 31) / 32 * 32;
+    const bool debug = getenv("GEMHIP_HOPE_DEBUG") != nullptr;
+    double amp = 1e4, amp0 = 1e3;
+    if (const char *e = getenv("GEMHIP_HOPE_SYM_AMP")) amp = std::max(10.0, atof(e));
+    if (const char *e = getenv("GEMHIP_HOPE_SYM_AMP0")) amp0 = std::max(10.0, atof(e));
+    int max_degree = 60;
+    if (const char *e = getenv("GEMHIP_HOPE_SYM_MAXDEG")) max_degree = std::max(2, atoi(e));
+    float *Vall = nullptr, *Bm = nullptr, *F[3] = {nullptr, nullptr, nullptr}, *Tmp = nullptr, *colv = nullptr;
+    auto dalloc = [&](float **p, size_t elems) { HOPE_TRY(H, hipMalloc((void **)p, elems * sizeof(float))); if (!H.err) HOPE_TRY(H, hipMemsetAsync(*p, 0, elems * sizeof(float), H.s)); };
+    dalloc(&Vall, (size_t)n * ldv); dalloc(&Bm, (size_t)n * ldv); dalloc(&F[0], (size_t)n * ldv); dalloc(&F[1], (size_t)n * ldv); dalloc(&F[2], (size_t)n * ldv);
+    dalloc(&Tmp, (size_t)n * ldv); dalloc(&colv, 512);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    auto cleanup = [&]() {
+        hipFree(Vall); hipFree(Bm); hipFree(F[0]); hipFree(F[1]); hipFree(F[2]); hipFree(Tmp); hipFree(colv);
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+        if (H.sp0) hipEventDestroy(H.sp0);
+        if (H.sp1) hipEventDestroy(H.sp1);
+        ev0 = ev1 = nullptr; H.sp0 = H.sp1 = nullptr;
+    };
+    if (!H.err) { HOPE_TRY(H, hipEventCreate(&ev0)); HOPE_TRY(H, hipEventCreate(&ev1)); HOPE_TRY(H, hipEventCreate(&H.sp0)); HOPE_TRY(H, hipEventCreate(&H.sp1)); H.time_spmm = (stats != nullptr); }
+    if (H.err) { cleanup(); return H.err; }
+    hipEventRecord(ev0, H.s);
+
+    const int64_t threads = (n * (int64_t)b + 3) / 4;
+    hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, H.s, Vall, n, b, ldv, seed);
+    int ma = orth_scaled(H, Vall, ldv, b, Tmp, ldv, 2), nl = 0;
+
+    const double L = br / std::fabs(beta);            // |lambda| <= L: power-iteration estimate + 10 %, capped by sqrt(max row sum x max column sum)
+    double lo = -L, hi = 0.5 * L, tau_prev = 0.0;      // first filter: damp the lower three quarters of [-L, L]
+    const double lock_tol = 0.1 * std::sqrt(std::max((double)tol, 1e-12));
+    const int b_min = std::min(b, std::max(2 * (int)oversample, 16));
+    std::vector<double> lock_lam, th, res, sig(k, 0.0), sig_old(k, 0.0);
+    double last_change = 1.0, last_residual = 1.0, degree_total = 0.0;
+    int cycles = 0;
+    bool converged = false;
+    for (int cyc = 0; cyc < max_cycles && !H.err; ++cyc) {
+        cycles = cyc + 1;
+        const double c = 0.5 * (hi + lo), e = 0.5 * (hi - lo);
+        const double tmax = std::max(L - c, c + L) / e;
+        const double rho = tmax + std::sqrt(std::max(tmax * tmax - 1.0, 0.0));
+        const int q = (int)std::max(1.0, std::floor(std::log(1e3) / std::log(std::max(rho, 1.0001))));          // in-filter deflation period
+        double rho_m = rho;                                       // growth that caps the degree: the spectrum's edge, or -- once pairs are
+        if (nl > 0 && cyc > 0 && !th.empty()) {                   // locked and deflated inside the filter -- the largest active Ritz value
+            double ta = 1.0;
+            for (double t : th) ta = std::max(ta, 1.02 * std::fabs(t - c) / e);
+            ta = std::min(ta, tmax);
+            rho_m = ta + std::sqrt(std::max(ta * ta - 1.0, 0.0));
+        }
+        const int m = (int)std::max(2.0, std::min((double)max_degree, std::floor(std::log(cyc == 0 ? amp0 : amp) / std::log(std::max(rho_m, 1.0001)))));
+        float *Va = Vall + nl;
+        cheb_filter(H, Va, ldv, ma, m, c, e, F, ldv, Vall, ldv, nl, q);
+        degree_total += m;
+        if (nl) project_out(H, Vall, ldv, nl, Va, ldv, ma);
+        int keep = orth_scaled(H, Va, ldv, ma, Tmp, ldv, 2);
+        if (nl && keep > 0) { project_out(H, Vall, ldv, nl, Va, ldv, keep); keep = orth_scaled(H, Va, ldv, keep, Tmp, ldv, 1); }
+        if (H.err) break;
+        if (nl + keep < k + 1 || keep < 2) { if (debug) fprintf(stderr, "[hope-sym] block collapsed to %d columns\n", keep); break; }
+        ma = keep;
+        // Rayleigh-Ritz on A over the active block
+        std::vector<double> Hh, ev;
+        { SpmmTimer timer(H); spmm(H, false, 1.0f, Va, ldv, nullptr, 0, Bm, ldv, ma); }
+        gram(H, Va, ldv, ma, Bm, ldv, ma, Hh);
+        if (H.err) break;
+        for (int i = 0; i < ma; ++i)
+            for (int j = i + 1; j < ma; ++j) { const double v = 0.5 * (Hh[(size_t)i * ma + j] + Hh[(size_t)j * ma + i]); Hh[(size_t)i * ma + j] = Hh[(size_t)j * ma + i] = v; }
+        sym_eig(ma, Hh, ev);                                                          // ascending; column j of Hh = eigenvector j
+        std::vector<int> order(ma);
+        for (int j = 0; j < ma; ++j) order[j] = j;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return std::fabs(fk(ev[x])) > std::fabs(fk(ev[y])); });
+        th.assign(ma, 0.0);
+        std::vector<double> C((size_t)ma * ma), Ct((size_t)ma * ma);
+        for (int j = 0; j < ma; ++j) {
+            th[j] = ev[order[j]];
+            for (int i = 0; i < ma; ++i) { C[(size_t)i * ma + j] = Hh[(size_t)i * ma + order[j]]; Ct[(size_t)i * ma + j] = -th[j] * C[(size_t)i * ma + j]; }
+        }
+        // residuals R = B C - V C diag(theta) (into F[0]), then the block becomes its Ritz vectors V C
+        tsgemm(H, Va, ldv, ma, Ct, ma, 1.0f, nullptr, 0, F[0], ldv);
+        tsgemm(H, Bm, ldv, ma, C, ma, 1.0f, F[0], ldv, F[0], ldv);
+        tsgemm(H, Va, ldv, ma, C, ma, 1.0f, nullptr, 0, Tmp, ldv);
+        HOPE_TRY(H, hipMemcpy2DAsync(Va, (size_t)ldv * sizeof(float), Tmp, (size_t)ldv * sizeof(float), (size_t)ma * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
+        std::vector<double> RR;
+        gram(H, F[0], ldv, ma, F[0], ldv, ma, RR);
+        if (H.err) break;
+        res.assign(ma, 0.0);
+        for (int j = 0; j < ma; ++j) res[j] = std::sqrt(std::max(RR[(size_t)j * ma + j], 0.0));
+        // wanted values so far: the k largest |f| over the locked eigenvalues and the active Ritz values
+        {
+            std::vector<double> all;
+            for (double l : lock_lam) all.push_back(std::fabs(fk(l)));
+            for (int j = 0; j < ma; ++j) all.push_back(std::fabs(fk(th[j])));
+            std::sort(all.begin(), all.end(), std::greater<double>());
+            for (int j = 0; j < k; ++j) sig[j] = all[j];
+        }
+        double change = 0.0;
+        for (int j = 0; j < k; ++j) change = std::max(change, std::fabs(sig[j] - sig_old[j]));
+        last_change = sig[0] > 0 ? change / sig[0] : 0.0;
+        sig_old = sig;
+        const int want = k - nl;                                                       // wanted pairs still active: the leading ones
+        double rmax = 0.0;
+        for (int j = 0; j < std::min(want, ma); ++j) rmax = std::max(rmax, res[j] / std::max(std::fabs(th[j]), 1e-3 * L));
+        last_residual = rmax;
+        if (debug)
+            fprintf(stderr, "[hope-sym] cycle %d degree %d interval [%.4f, %.4f] locked %d active %d sigma_k %.6g sigma_1 %.6g change %.3e residual %.3e\n",
+                    cyc, m, lo, hi, nl, ma, sig[k - 1], sig[0], last_change, rmax);
+        if (cyc > 0 && last_change < tol && rmax < 1e-2) { converged = true; break; }
+        int newl = 0;
+        while (newl < want - 1 && newl < ma - b_min && res[newl] < lock_tol * std::fabs(th[newl])) ++newl;
+        if (newl > 0) {                                                                // leading columns of the active block: bookkeeping only
+            for (int j = 0; j < newl; ++j) lock_lam.push_back(th[j]);
+            th.erase(th.begin(), th.begin() + newl); res.erase(res.begin(), res.begin() + newl);
+            nl += newl; ma -= newl;
+        }
+        // next filter: bounded where |f| is below the block's smallest Ritz |f| (never lowered: Ritz values approach from inside)
+        double tau = tau_prev;
+        { double tmin = 1e300; for (int j = 0; j < ma; ++j) tmin = std::min(tmin, std::fabs(fk(th[j]))); tau = std::max(tau, tmin); }
+        tau_prev = tau;
+        if (!(tau > 0.0)) { lo = -L; hi = 0.5 * L; continue; }
+        hi = std::min(tau / (std::fabs(beta) * (1.0 + tau)), 0.98 * L);
+        lo = -std::min(L, tau < 1.0 ? tau / (std::fabs(beta) * (1.0 - tau)) : L);
+        if (lo > -1e-6 * L) lo = -1e-6 * L;
+    }
+    if (!H.err && !converged) { *fell_back = true; cleanup(); return GEMHIP_OK; }
+    if (!H.err) {
+        struct Cand { double s, lam; int col; };
+        std::vector<Cand> cand;
+        for (int l = 0; l < nl; ++l) cand.push_back({std::fabs(fk(lock_lam[l])), lock_lam[l], l});
+        for (int j = 0; j < ma; ++j) cand.push_back({std::fabs(fk(th[j])), th[j], nl + j});
+        std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.s > y.s; });
+        const int mc = nl + ma;
+        // sign convention (largest-magnitude entry of each left vector positive) from the basis columns themselves
+        hipLaunchKernelGGL(hope_colmax_kernel, dim3(mc), dim3(256), 0, H.s, n, Vall, ldv, colv);
+        std::vector<float> cm(mc, 0.f);
+        HOPE_TRY(H, hipMemcpyAsync(cm.data(), colv, (size_t)mc * sizeof(float), hipMemcpyDeviceToHost, H.s));
+        HOPE_TRY(H, hipStreamSynchronize(H.s));
+        std::vector<double> Cu((size_t)mc * k, 0.0), Cv((size_t)mc * k, 0.0);
+        for (int r = 0; r < k && !H.err; ++r) {
+            const int j = k - 1 - r;                                                   // ascending sigma (svds order, hope.py:33)
+            const double s = cand[r].s, sf = fk(cand[r].lam) < 0 ? -1.0 : 1.0;          // u = sign(f(lambda)) q
+            sigma[j] = (float)s;
+            const double flip = (sf * cm[cand[r].col] < 0) ? -1.0 : 1.0;
+            Cu[(size_t)cand[r].col * k + j] = flip * sf * std::sqrt(s);
+            Cv[(size_t)cand[r].col * k + j] = flip * std::sqrt(s);
+        }
+        if (U_sqrtS) {
+            tsgemm(H, Vall, ldv, mc, Cu, k, 1.0f, nullptr, 0, Tmp, k);
+            HOPE_TRY(H, hipMemcpy(U_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        tsgemm(H, Vall, ldv, mc, Cv, k, 1.0f, nullptr, 0, Tmp, k);
+        HOPE_TRY(H, hipMemcpy(V_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    float ms = 0.f;
+    if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
+    if (stats && !H.err) {
+        stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = 0.0 /* no Katz series: f on the eigenvalues */; stats[4] = nl + ma;
+        stats[5] = cycles; stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual;
+        stats[11] = H.spmm_ms * 1e-3;
+    }
+    (void)degree_total;
+    cleanup();
+    return H.err;
+}
+
+
 struct gemhip_hope_plan {
     Hope H;
     int terms = 1;
     double br = 0.0;
+    bool symmetric = false;                          // A == A^T entry for entry (columns sorted within rows): the eigen-path applies
 };
 
 // Graph-dependent setup of the Katz operator: A and A^T in CSR on the device, number of series terms from sigma_max(A).
@@ -1058,6 +1337,19 @@ static int hope_setup(gemhip_hope_plan &P, int64_t n, int64_t nnz, const int64_t
         std::vector<int64_t> at(rpT.begin(), rpT.end() - 1);
         for (int64_t i = 0; i < n; ++i)
             for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { const int64_t q = at[col[e]]++; ciT[q] = (int32_t)i; vaT[q] = va[e]; }
+    }
+    {   // A == A^T?  Transposing A^T gives A with every row's columns ascending (stable counting sort), which is how A^T itself is
+        // stored: equal arrays => the matrices are equal (duplicates, if any, are summed by the SpMM on both sides alike).
+        bool sym = nnz > 0 && std::memcmp(rpT.data(), row_ptr, (size_t)(n + 1) * sizeof(int64_t)) == 0;
+        if (sym) {
+            std::vector<int64_t> at(row_ptr, row_ptr + n);
+            for (int64_t j = 0; j < n && sym; ++j)
+                for (int64_t e = rpT[j]; e < rpT[j + 1]; ++e) {          // entry (j, i) of A^T = entry (i, j) of A: goes to row i, next free slot
+                    const int64_t i = ciT[e], qpos = at[i]++;
+                    if (ciT[qpos] != (int32_t)j || vaT[qpos] != vaT[e]) { sym = false; break; }
+                }
+        }
+        P.symmetric = sym;
     }
     // Neumann terms from a power-iteration estimate of rho(A): bound by the max absolute row/col sum too
     double rs_max = 0.0, cs_max = 0.0;
@@ -1140,6 +1432,17 @@ extern "C" int gemhip_hope_plan_solve(gemhip_hope_plan_t P, int32_t k, int32_t o
     Hope &H = P->H;
     H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr;
     g_eig_seconds = 0.0; g_eig_calls = 0.0;
+    // Symmetric A (undirected graphs: every GEM example and the SBM benchmark): the eigen-path.  GEMHIP_HOPE_SYM=0 disables it,
+    // =1 takes it at any size; by default graphs under 16384 nodes stay on the block-Krylov solver (already milliseconds there).
+    const char *sym_env = getenv("GEMHIP_HOPE_SYM");
+    const bool sym_ok = P->symmetric && H.beta > 0.f && (int64_t)k + oversample + 1 < H.n;
+    if (sym_ok && (sym_env ? atoi(sym_env) != 0 : (H.n >= 16384 && 8 * ((int64_t)k + oversample) <= H.n))) {
+        bool fell_back = false;
+        const int rc = sym_filter_svd(H, H.n, k, oversample, std::max(40, 3 * (int)max_restarts), tol, seed, P->br, U_sqrtS, V_sqrtS, sigma, stats, &fell_back);
+        if (rc || !fell_back) return rc;
+        H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr;      // not converged: the general solver
+        g_eig_seconds = 0.0; g_eig_calls = 0.0;
+    }
     return krylov_svd(H, H.n, k, oversample, krylov_steps, max_restarts, tol, seed, P->terms, P->br, 0, U_sqrtS, V_sqrtS, sigma, stats);
 }
 

@@ -31,6 +31,7 @@ def learn(model, graph):
     model._sigma = sig.astype(np.float64)
     model._stats = dict(zip(('device_seconds', 'spmm_launches', 'spmm_columns', 'katz_terms', 'basis_columns', 'restarts',
                              'last_sigma_change', 'beta_sigma_max', 'host_eig_seconds', 'host_eig_calls', 'ritz_residual', 'spmm_seconds'), list(stats)))
+    model._stats['solver'] = 'symmetric_chebyshev_filter' if model._stats['katz_terms'] == 0 else 'block_krylov'   # hope.hip: A == A^T takes the eigen-path
     _hip.warn_if_unconverged(model._stats, float(getattr(model, '_tol', 1e-5)), int(getattr(model, '_max_restarts', 20)), 'HOPE')
     model._node_num = n
     return np.concatenate((U, V), axis=1).astype(np.float64)

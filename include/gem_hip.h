@@ -241,6 +241,12 @@ int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs,
  * basis_columns, restarts_done, last_sigma_change, beta*sigma_max(A) estimate, host_eig_seconds,
  * host_eig_calls, max relative Ritz residual of the previous cycle,
  * seconds inside SpMM launches (HIP events)}.
+ * Symmetric A (A == A^T entry for entry, rows sorted by column, beta > 0, n >= 16384; GEMHIP_HOPE_SYM=0/1 forces it off/on):
+ * S = f(A), f(x) = beta x / (1 - beta x), shares A's eigenvectors, so the same triplets -- sigma = |f(lambda)|, v = q,
+ * u = sign(f(lambda)) q -- come from a Chebyshev-filtered subspace iteration on A itself (one SpMM per polynomial degree,
+ * block-sized Rayleigh-Ritz, locked pairs deflated inside the filter); krylov_steps is unused there, max_restarts bounds the
+ * cycles at max(40, 3 * max_restarts), and a run that does not converge is redone by the block-Krylov solver.  stats then
+ * carries katz_terms = 0 and restarts_done = filter cycles.
  * Returns GEMHIP_E_NOTCONVERGED when beta*sigma_max(A) >= 0.95 (Katz series too slow). */
 /* Staged form: the graph-dependent setup (A and A^T in CSR on the device, Katz series length) is done once. */
 typedef struct gemhip_hope_plan *gemhip_hope_plan_t;
