@@ -133,16 +133,27 @@ __global__ void hope_reduce1_kernel(const float *__restrict__ P, int nslabs, int
     const int c = blockIdx.y;
     if (idx >= m1 * m2) return;
     const int i = idx / m2, j = idx - i * m2;
-    double s = 0.0;
-    for (int k = c; k < nslabs; k += C) s += (double)P[k * stride + (int64_t)i * m2p + j];
-    part[(int64_t)c * m1 * m2 + idx] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;                  // four loads in flight (the loop is latency bound); fixed order: deterministic
+    const float *p = P + (int64_t)i * m2p + j;
+    int k = c;
+    for (; k + 3 * C < nslabs; k += 4 * C) {
+        s0 += (double)p[k * stride]; s1 += (double)p[(k + C) * stride]; s2 += (double)p[(k + 2 * C) * stride]; s3 += (double)p[(k + 3 * C) * stride];
+    }
+    for (; k < nslabs; k += C) s0 += (double)p[k * stride];
+    part[(int64_t)c * m1 * m2 + idx] = (s0 + s1) + (s2 + s3);
 }
 __global__ void hope_reduce2_kernel(const double *__restrict__ part, int C, int total, double *__restrict__ G, float *__restrict__ Gf)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    double s = 0.0;
-    for (int c = 0; c < C; ++c) s += part[(int64_t)c * total + idx];
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += part[(int64_t)(c + u) * total + idx];
+    }
+    for (; c < C; ++c) a[0] += part[(int64_t)c * total + idx];
+    const double s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     G[idx] = s;
     if (Gf) Gf[idx] = (float)s;                          // the rounding tsgemm() applies to host coefficients
 }
@@ -627,10 +638,17 @@ struct Hope {
     hipStream_t s = nullptr;
     double spmm_count = 0, spmm_cols = 0, eig_seconds = 0, eig_calls = 0;   // statistics
     hipEvent_t sp0 = nullptr, sp1 = nullptr; double spmm_ms = 0; bool time_spmm = false;
+    std::vector<hipEvent_t> sp_pool; size_t sp_used = 0;      // (start, stop) pairs around SpMM runs; read once at the end of a solve
+    struct CoefSlot { float *h = nullptr, *d = nullptr; size_t elems = 0; hipEvent_t done = nullptr; };
+    CoefSlot coef[8]; unsigned coef_next = 0;                // pinned staging ring for the small host matrices tsgemm() takes
+    float *ws[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t ws_elems[7] = {0, 0, 0, 0, 0, 0, 0};   // eigen-path workspace, kept across solves
     int err = 0;
     ~Hope()
     {
         hipFree(rp); hipFree(rpT); hipFree(ci); hipFree(ciT); hipFree(va); hipFree(vaT); hipFree(P); hipFree(G); hipFree(Gpart); hipFree(Csmall);
+        for (hipEvent_t e : sp_pool) hipEventDestroy(e);
+        for (CoefSlot &c : coef) { if (c.h) hipHostFree(c.h); hipFree(c.d); if (c.done) hipEventDestroy(c.done); }
+        for (float *w : ws) hipFree(w);
     }
 };
 
@@ -690,16 +708,27 @@ void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int
 void tsgemm(Hope &H, const float *X, int ldx, int m, const std::vector<double> &Ch, int b2, float alpha, const float *Src, int lds_, float *Out, int ldo)
 {
     if (H.err || b2 == 0) return;
-    std::vector<float> Cf((size_t)std::max(m, 1) * b2);
-    for (size_t i = 0; i < (size_t)m * b2; ++i) Cf[i] = (float)Ch[i];
-    if (Cf.size() > H.C_elems) { hipFree(H.Csmall); H.Csmall = nullptr; H.C_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.Csmall, Cf.size() * sizeof(float))); if (!H.err) H.C_elems = Cf.size(); }
+    // the coefficients go through a ring of pinned host / device slot pairs: no host synchronisation between the upload and the launch
+    Hope::CoefSlot &slot = H.coef[H.coef_next++ % 8];
+    const size_t need = (size_t)std::max(m, 1) * b2;
+    if (slot.done) HOPE_TRY(H, hipEventSynchronize(slot.done));          // the launch that last read this slot (eight tsgemm calls ago)
+    else HOPE_TRY(H, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (need > slot.elems && !H.err) {
+        if (slot.h) hipHostFree(slot.h);
+        hipFree(slot.d); slot.h = nullptr; slot.d = nullptr; slot.elems = 0;
+        const size_t cap = std::max<size_t>(need, 16384);
+        HOPE_TRY(H, hipHostMalloc((void **)&slot.h, cap * sizeof(float), hipHostMallocDefault));
+        HOPE_TRY(H, hipMalloc((void **)&slot.d, cap * sizeof(float)));
+        if (!H.err) slot.elems = cap;
+    }
     if (H.err) return;
-    HOPE_TRY(H, hipMemcpyAsync(H.Csmall, Cf.data(), (size_t)m * b2 * sizeof(float), hipMemcpyHostToDevice, H.s));
-    HOPE_TRY(H, hipStreamSynchronize(H.s));          // Cf is a stack-lifetime buffer
+    for (size_t i = 0; i < (size_t)m * b2; ++i) slot.h[i] = (float)Ch[i];
+    HOPE_TRY(H, hipMemcpyAsync(slot.d, slot.h, (size_t)m * b2 * sizeof(float), hipMemcpyHostToDevice, H.s));
     const int ct = (b2 + 31) / 32;
     const int64_t tiles = ((H.n + 31) / 32) * ct;
-    hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, H.Csmall, b2, b2, alpha, Src, lds_, Out,
+    hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, slot.d, b2, b2, alpha, Src, lds_, Out,
                        ldo, ct);
+    HOPE_TRY(H, hipEventRecord(slot.done, H.s));
 }
 
 // W[:, :cols] -= V[:, :m] (V[:, :m]^T W[:, :cols]) with the coefficients kept in HBM: Gram, fp64 slab reduction, fp32 rounding and
@@ -787,15 +816,25 @@ int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, doub
 // W0, T0, T1: scratch n x b with leading dimension ldt.
 struct SpmmTimer {           // HIP events around a run of back-to-back SpMM launches (nothing else is enqueued in between)
     Hope &H;
-    explicit SpmmTimer(Hope &h) : H(h) { if (H.time_spmm && !H.err) hipEventRecord(H.sp0, H.s); }
-    ~SpmmTimer()
+    size_t idx = (size_t)-1;
+    explicit SpmmTimer(Hope &h) : H(h)
     {
-        if (H.time_spmm && !H.err) {
-            hipEventRecord(H.sp1, H.s); hipEventSynchronize(H.sp1);
-            float ms = 0.f; hipEventElapsedTime(&ms, H.sp0, H.sp1); H.spmm_ms += ms;
-        }
+        if (!H.time_spmm || H.err) return;
+        while (H.sp_pool.size() < H.sp_used + 2) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return; H.sp_pool.push_back(e); }
+        idx = H.sp_used; H.sp_used += 2;
+        hipEventRecord(H.sp_pool[idx], H.s);
     }
+    ~SpmmTimer() { if (idx != (size_t)-1) hipEventRecord(H.sp_pool[idx + 1], H.s); }       // no host wait here: spmm_time_collect() reads the pairs
 };
+// after the stream has been synchronised: total time between the recorded (start, stop) pairs
+void spmm_time_collect(Hope &H)
+{
+    for (size_t i = 0; i + 1 < H.sp_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, H.sp_pool[i], H.sp_pool[i + 1]) == hipSuccess) H.spmm_ms += ms;
+    }
+    H.sp_used = 0;
+}
 
 void apply_S(Hope &H, const float *X, int ldx, int b, int terms, float *T0, float *T1, float *W0, int ldt, float *Out, int ldo)
 {
@@ -1053,6 +1092,7 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
     }
     float ms = 0.f;
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
+    if (!H.err) spmm_time_collect(H); else H.sp_used = 0;
     if (stats && !H.err) {
         stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = terms; stats[4] = mc; stats[5] = restarts_done;
         stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual; stats[11] = H.spmm_ms * 1e-3;
@@ -1066,11 +1106,12 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
 // For A = A^T the Katz operator S = sum_t (beta A)^t = f(A), f(x) = beta x / (1 - beta x), has the eigenvectors of A: singular value
 // |f(lambda)|, right vector q, left vector sign(f(lambda)) q.  The k largest |f(lambda)| sit at the two ends of A's spectrum, so the
 // series is never applied: a block of k + oversample vectors is filtered with a Chebyshev polynomial of A that is bounded on the
-// unwanted interval [-a_minus, a_plus] (|f| below the block's smallest Ritz |f|) and grows outside it (one SpMM per degree, fused
-// three-term recurrence), orthonormalised, and rotated by a (k + oversample)-sized Rayleigh-Ritz step on A.  Converged leading pairs
-// are locked and projected out.  The filter degree of a cycle is capped by the growth at the spectrum's edge (fp32: what is known to
-// ~1e-7 relative must not be amplified past the wanted directions).  Against the block-Krylov path on S^T S this needs ~7x fewer SpMM
-// columns, no n x 512 basis and no 512 x 512 projected eigenproblem (measured: DESIGN.md 3.2).
+// unwanted interval [-a_minus, a_plus] (|f| below a Ritz |f| taken from the middle of the oversampling columns) and grows outside it
+// (one SpMM per degree, fused three-term recurrence), orthonormalised, and rotated by a (k + oversample)-sized Rayleigh-Ritz step on
+// A.  Converged leading pairs are locked and projected out -- also INSIDE the filter, every few degrees -- so that the degree of a
+// cycle is capped by the growth at the largest ACTIVE Ritz value rather than at the spectrum's edge (fp32: a direction known to ~1e-7
+// relative must not be amplified past the wanted ones; 1e4 per cycle).  Against the block-Krylov path on S^T S this needs ~7x fewer
+// SpMM columns, no n x 512 basis and no 512 x 512 projected eigenproblem (measured: DESIGN.md 3.2).
 namespace {
 
 // CholeskyQR on the column-NORMALISED Gram matrix (filtered columns differ in length by the filter's growth; an entry of the fp32
@@ -1150,15 +1191,24 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
     double amp = 1e4, amp0 = 1e3;
     if (const char *e = getenv("GEMHIP_HOPE_SYM_AMP")) amp = std::max(10.0, atof(e));
     if (const char *e = getenv("GEMHIP_HOPE_SYM_AMP0")) amp0 = std::max(10.0, atof(e));
-    int max_degree = 60;
+    int max_degree = 32;                                    // measured at SBM 100k/1M: 30-32 per cycle is cheapest (scripts/ab_hope_sym.py)
     if (const char *e = getenv("GEMHIP_HOPE_SYM_MAXDEG")) max_degree = std::max(2, atoi(e));
     float *Vall = nullptr, *Bm = nullptr, *F[3] = {nullptr, nullptr, nullptr}, *Tmp = nullptr, *colv = nullptr;
-    auto dalloc = [&](float **p, size_t elems) { HOPE_TRY(H, hipMalloc((void **)p, elems * sizeof(float))); if (!H.err) HOPE_TRY(H, hipMemsetAsync(*p, 0, elems * sizeof(float), H.s)); };
-    dalloc(&Vall, (size_t)n * ldv); dalloc(&Bm, (size_t)n * ldv); dalloc(&F[0], (size_t)n * ldv); dalloc(&F[1], (size_t)n * ldv); dalloc(&F[2], (size_t)n * ldv);
-    dalloc(&Tmp, (size_t)n * ldv); dalloc(&colv, 512);
+    // workspace: seven n x ldv blocks kept in the solver state across solves (a plan is solved repeatedly; hipMalloc / hipFree of
+    // ~40 MB blocks cost more than a filter cycle)
+    auto walloc = [&](int slot, float **p, size_t elems) {
+        if (elems > H.ws_elems[slot] && !H.err) {
+            hipFree(H.ws[slot]); H.ws[slot] = nullptr; H.ws_elems[slot] = 0;
+            HOPE_TRY(H, hipMalloc((void **)&H.ws[slot], elems * sizeof(float)));
+            if (!H.err) H.ws_elems[slot] = elems;
+        }
+        *p = H.ws[slot];
+        if (!H.err) HOPE_TRY(H, hipMemsetAsync(*p, 0, elems * sizeof(float), H.s));
+    };
+    walloc(0, &Vall, (size_t)n * ldv); walloc(1, &Bm, (size_t)n * ldv); walloc(2, &F[0], (size_t)n * ldv); walloc(3, &F[1], (size_t)n * ldv);
+    walloc(4, &F[2], (size_t)n * ldv); walloc(5, &Tmp, (size_t)n * ldv); walloc(6, &colv, 512);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     auto cleanup = [&]() {
-        hipFree(Vall); hipFree(Bm); hipFree(F[0]); hipFree(F[1]); hipFree(F[2]); hipFree(Tmp); hipFree(colv);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
         if (H.sp0) hipEventDestroy(H.sp0);
@@ -1176,7 +1226,7 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
     const double L = br / std::fabs(beta);            // |lambda| <= L: power-iteration estimate + 10 %, capped by sqrt(max row sum x max column sum)
     double lo = -L, hi = 0.5 * L, tau_prev = 0.0;      // first filter: damp the lower three quarters of [-L, L]
     const double lock_tol = 0.1 * std::sqrt(std::max((double)tol, 1e-12));
-    const int b_min = std::min(b, std::max(2 * (int)oversample, 16));
+    const int b_min = std::min(b, (int)oversample + 2);      // the active block keeps its oversampling columns
     std::vector<double> lock_lam, th, res, sig(k, 0.0), sig_old(k, 0.0);
     double last_change = 1.0, last_residual = 1.0, degree_total = 0.0;
     int cycles = 0;
@@ -1198,9 +1248,13 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
         float *Va = Vall + nl;
         cheb_filter(H, Va, ldv, ma, m, c, e, F, ldv, Vall, ldv, nl, q);
         degree_total += m;
-        if (nl) project_out(H, Vall, ldv, nl, Va, ldv, ma);
-        int keep = orth_scaled(H, Va, ldv, ma, Tmp, ldv, 2);
-        if (nl && keep > 0) { project_out(H, Vall, ldv, nl, Va, ldv, keep); keep = orth_scaled(H, Va, ldv, keep, Tmp, ldv, 1); }
+        // CholeskyQR2; with locked vectors the projection is repeated between the two passes (the first pass rescales the block)
+        int keep;
+        if (nl) {
+            project_out(H, Vall, ldv, nl, Va, ldv, ma);
+            keep = orth_scaled(H, Va, ldv, ma, Tmp, ldv, 1);
+            if (keep > 0) { project_out(H, Vall, ldv, nl, Va, ldv, keep); keep = orth_scaled(H, Va, ldv, keep, Tmp, ldv, 1); }
+        } else keep = orth_scaled(H, Va, ldv, ma, Tmp, ldv, 2);
         if (H.err) break;
         if (nl + keep < k + 1 || keep < 2) { if (debug) fprintf(stderr, "[hope-sym] block collapsed to %d columns\n", keep); break; }
         ma = keep;
@@ -1258,9 +1312,12 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
             th.erase(th.begin(), th.begin() + newl); res.erase(res.begin(), res.begin() + newl);
             nl += newl; ma -= newl;
         }
-        // next filter: bounded where |f| is below the block's smallest Ritz |f| (never lowered: Ritz values approach from inside)
-        double tau = tau_prev;
-        { double tmin = 1e300; for (int j = 0; j < ma; ++j) tmin = std::min(tmin, std::fabs(fk(th[j]))); tau = std::max(tau, tmin); }
+        // next filter: bounded where |f| is below the Ritz |f| in the MIDDLE of the oversampling columns (th is sorted by |f|): the j-th
+        // Ritz |f| never exceeds the j-th true one, so no wanted value is damped, and straggling last columns cannot hold the
+        // cut-off down.  Never lowered.
+        const int want_left = k - nl;
+        const int jc = std::max(0, std::min(ma - 1, want_left + (ma - want_left) / 2 - 1));
+        const double tau = std::max(tau_prev, std::fabs(fk(th[jc])));
         tau_prev = tau;
         if (!(tau > 0.0)) { lo = -L; hi = 0.5 * L; continue; }
         hi = std::min(tau / (std::fabs(beta) * (1.0 + tau)), 0.98 * L);
@@ -1298,6 +1355,7 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
     }
     float ms = 0.f;
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
+    if (!H.err) spmm_time_collect(H); else H.sp_used = 0;
     if (stats && !H.err) {
         stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = 0.0 /* no Katz series: f on the eigenvalues */; stats[4] = nl + ma;
         stats[5] = cycles; stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual;
@@ -1430,7 +1488,7 @@ extern "C" int gemhip_hope_plan_solve(gemhip_hope_plan_t P, int32_t k, int32_t o
     GEMHIP_REQUIRE(U_sqrtS && V_sqrtS && sigma, "hope: output pointers are NULL");
     GEMHIP_REQUIRE(oversample >= 0 && krylov_steps >= 1 && max_restarts >= 0, "hope: need oversample >= 0, krylov_steps >= 1, max_restarts >= 0");
     Hope &H = P->H;
-    H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr;
+    H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr; H.sp_used = 0;
     g_eig_seconds = 0.0; g_eig_calls = 0.0;
     // Symmetric A (undirected graphs: every GEM example and the SBM benchmark): the eigen-path.  GEMHIP_HOPE_SYM=0 disables it,
     // =1 takes it at any size; by default graphs under 16384 nodes stay on the block-Krylov solver (already milliseconds there).
@@ -1440,7 +1498,7 @@ extern "C" int gemhip_hope_plan_solve(gemhip_hope_plan_t P, int32_t k, int32_t o
         bool fell_back = false;
         const int rc = sym_filter_svd(H, H.n, k, oversample, std::max(40, 3 * (int)max_restarts), tol, seed, P->br, U_sqrtS, V_sqrtS, sigma, stats, &fell_back);
         if (rc || !fell_back) return rc;
-        H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr;      // not converged: the general solver
+        H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr; H.sp_used = 0;      // not converged: the general solver
         g_eig_seconds = 0.0; g_eig_calls = 0.0;
     }
     return krylov_svd(H, H.n, k, oversample, krylov_steps, max_restarts, tol, seed, P->terms, P->br, 0, U_sqrtS, V_sqrtS, sigma, stats);
