@@ -162,3 +162,32 @@ def test_symmetric_eigen_path_agrees_with_the_block_krylov_path(monkeypatch):
     m = HOPE(d=8, beta=0.01)
     m.learn_embedding(graph=gd, is_weighted=True, no_python=True)
     assert m._stats['solver'] == 'block_krylov'
+
+
+def test_symmetric_eigen_path_two_sided_spectrum(monkeypatch):
+    """A weighted bipartite graph has the spectrum +-lambda: the k largest |f(lambda)| mix both ends (f(x) = beta x / (1 - beta x) favours
+    the positive one), and a negative eigenvalue gives u = -v.  Eigen-path (forced) against the block-Krylov path."""
+    from gem_amd.graph import EdgeListGraph
+    n = 8192
+    rs = np.random.RandomState(5)
+    a = rs.randint(0, n // 2, 60000); b = rs.randint(n // 2, n, 60000)
+    key = np.unique(a.astype(np.int64) * n + b); a = (key // n).astype(np.int32); b = (key % n).astype(np.int32)
+    w = (rs.rand(len(a)) + 0.5).astype(np.float32)
+    g = EdgeListGraph(n, np.concatenate([a, b]), np.concatenate([b, a]), np.concatenate([w, w]))
+    out = {}
+    for sym in ('0', '1'):
+        monkeypatch.setenv('GEMHIP_HOPE_SYM', sym)
+        m = HOPE(d=32, beta=0.01)
+        Y = m.learn_embedding(graph=g, is_weighted=True, no_python=True)
+        out[sym] = (Y, m._sigma.copy(), m._stats['solver'])
+    assert out['1'][2] == 'symmetric_chebyshev_filter' and out['0'][2] == 'block_krylov'
+    assert np.allclose(out['0'][1], out['1'][1], rtol=5e-5), np.abs(out['0'][1] / out['1'][1] - 1).max()
+    k = 16
+    R0 = out['0'][0][:, :k] @ out['0'][0][:, k:].T; R1 = out['1'][0][:, :k] @ out['1'][0][:, k:].T
+    assert np.linalg.norm(R0 - R1) <= 5e-3 * np.linalg.norm(R0)
+    Y = out['1'][0]
+    # Perron pair (largest sigma): u = v;  its mirror -lambda_max (second largest sigma): u = -v
+    assert np.allclose(Y[:, k - 1], Y[:, 2 * k - 1], atol=1e-6) and np.allclose(Y[:, k - 2], -Y[:, 2 * k - 2], atol=1e-6)
+    s = out['1'][1]
+    lam = s / (0.01 * (1 + s))                                   # f^-1 on the positive side
+    assert abs(s[k - 2] - 0.01 * lam[k - 1] / (1 + 0.01 * lam[k - 1])) <= 1e-5 * s[k - 2]   # |f(-lambda_max)|
