@@ -1420,28 +1420,38 @@ static int hope_setup(gemhip_hope_plan &P, int64_t n, int64_t nnz, const int64_t
         }
         for (int64_t i = 0; i < n; ++i) cs_max = std::max(cs_max, cs[i]);
     }
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "hope: no HIP device");
+    auto up = [&](void **dp, const void *hp, size_t bytes) { HOPE_TRY(H, hipMalloc(dp, std::max<size_t>(bytes, 16))); if (!H.err && bytes) HOPE_TRY(H, hipMemcpy(*dp, hp, bytes, hipMemcpyHostToDevice)); };
+    up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
+    up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
+    if (H.err) return H.err;
+
     double rho = 0.0;
-    {   // power iteration on A^T A (host, at most 40 steps): sigma_max(A) >= rho(A); converges from below, hence the margin
-        std::vector<double> x(n), y(n), z(n);
-        for (int64_t i = 0; i < n; ++i) x[i] = 1.0 + 0.37 * std::sin(12.9898 * (double)(i + 1));
-        for (int it = 0; it < 40; ++it) {
-            for (int64_t i = 0; i < n; ++i) {
-                double sacc = 0.0;
-                for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) sacc += va[e] * x[col[e]];
-                y[i] = sacc;
-            }
-            std::fill(z.begin(), z.end(), 0.0);
-            for (int64_t i = 0; i < n; ++i)
-                for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) z[col[e]] += va[e] * y[i];
-            double nx = 0.0, nz = 0.0;
-            for (int64_t i = 0; i < n; ++i) { nx += x[i] * x[i]; nz += z[i] * z[i]; }
-            if (nz == 0.0 || nx == 0.0) break;
+    {   // power iteration on A^T A with the SpMM kernel (one column; at most 40 steps): sigma_max(A) >= rho(A); converges from below,
+        // hence the margin.  X2 = [x | z] as an n x 2 block so that one Gram launch returns both norms.
+        std::vector<float> x0((size_t)n * 2, 0.f);
+        for (int64_t i = 0; i < n; ++i) x0[(size_t)i * 2] = (float)(1.0 + 0.37 * std::sin(12.9898 * (double)(i + 1)));
+        float *X2 = nullptr, *yv = nullptr;
+        up((void **)&X2, x0.data(), x0.size() * sizeof(float));
+        HOPE_TRY(H, hipMalloc((void **)&yv, (size_t)n * sizeof(float)));
+        for (int it = 0; it < 40 && !H.err; ++it) {
+            spmm(H, false, 1.0f, X2, 2, nullptr, 0, yv, 1, 1);                       // y = A x
+            spmm(H, true, 1.0f, yv, 1, nullptr, 0, X2 + 1, 2, 1);                    // z = A^T y
+            std::vector<double> G2;
+            gram(H, X2, 2, 2, X2, 2, 2, G2);
+            if (H.err) break;
+            const double nx = G2[0], nz = G2[3];
+            if (!(nz > 0.0) || !(nx > 0.0) || !std::isfinite(nz)) break;
             const double prev = rho;
             rho = std::sqrt(std::sqrt(nz / nx));
-            const double inv = 1.0 / std::sqrt(nz);
-            for (int64_t i = 0; i < n; ++i) x[i] = z[i] * inv;
-            if (it >= 4 && std::fabs(rho - prev) <= 1e-3 * rho) break;        // the 10 % margin below covers the rest
+            hipLaunchKernelGGL(hope_lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, H.s, n, 1, (float)(1.0 / std::sqrt(nz)), X2 + 1, 2, 0.f, X2 + 1, 2,
+                               0.f, X2 + 1, 2, X2, 2);                               // x = z / |z|
+            if (it >= 4 && std::fabs(rho - prev) <= 1e-3 * rho) break;                // the 10 % margin below covers the rest
         }
+        HOPE_TRY(H, hipStreamSynchronize(H.s));
+        hipFree(X2); hipFree(yv);
+        if (H.err) return H.err;
         rho = std::min(std::max(rho * 1.1, 1e-30), std::sqrt(rs_max * cs_max));
     }
     const double br = std::fabs((double)beta) * rho;
@@ -1451,14 +1461,6 @@ static int hope_setup(gemhip_hope_plan &P, int64_t n, int64_t nnz, const int64_t
     int terms = (br <= 0.0) ? 0 : (int)std::ceil(std::log(1e-8) / std::log(br));
     terms = std::max(1, std::min(terms, 400));
     P.terms = terms; P.br = br;
-
-    int devid = 0;
-    if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "hope: no HIP device");
-    auto up = [&](void **dp, const void *hp, size_t bytes) { HOPE_TRY(H, hipMalloc(dp, std::max<size_t>(bytes, 16))); if (!H.err && bytes) HOPE_TRY(H, hipMemcpy(*dp, hp, bytes, hipMemcpyHostToDevice)); };
-    up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
-    up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
-    if (H.err) return H.err;
-
     return GEMHIP_OK;
 }
 

@@ -183,11 +183,22 @@ def test_symmetric_eigen_path_two_sided_spectrum(monkeypatch):
     assert out['1'][2] == 'symmetric_chebyshev_filter' and out['0'][2] == 'block_krylov'
     assert np.allclose(out['0'][1], out['1'][1], rtol=5e-5), np.abs(out['0'][1] / out['1'][1] - 1).max()
     k = 16
-    R0 = out['0'][0][:, :k] @ out['0'][0][:, k:].T; R1 = out['1'][0][:, :k] @ out['1'][0][:, k:].T
-    assert np.linalg.norm(R0 - R1) <= 5e-3 * np.linalg.norm(R0)
     Y = out['1'][0]
+    s = out['1'][1]
+    # sigma_3 .. sigma_16 sit in the bulk edge (relative gaps ~1e-3): the individual vectors there are not determined to better than
+    # residual / gap, so the two solvers are compared on the separated pairs, and every returned triplet is checked on its own:
+    # ||S v - sigma u|| and ||S^T u - sigma v|| small, u^T S v = sigma, U and V orthonormal
+    for j in (k - 1, k - 2):
+        for half in (0, k):
+            a0, a1 = out['0'][0][:, half + j], Y[:, half + j]
+            assert np.dot(a0, a1) / (np.linalg.norm(a0) * np.linalg.norm(a1)) > 1 - 1e-5
+    A = sp.csr_matrix((g.w.astype(np.float64), (g.src, g.dst)), shape=(n, n))
+    U = Y[:, :k] / np.sqrt(s); V = Y[:, k:] / np.sqrt(s)
+    SV = katz_apply(A, 0.01, V); STU = katz_apply(A.T.tocsr(), 0.01, U)
+    assert np.linalg.norm(SV - U * s, axis=0).max() <= 1e-2 * s[0] and np.linalg.norm(STU - V * s, axis=0).max() <= 1e-2 * s[0]
+    assert np.allclose(np.einsum('ij,ij->j', U, SV), s, rtol=2e-4)
+    assert np.abs(U.T @ U - np.eye(k)).max() < 5e-5 and np.abs(V.T @ V - np.eye(k)).max() < 5e-5
     # Perron pair (largest sigma): u = v;  its mirror -lambda_max (second largest sigma): u = -v
     assert np.allclose(Y[:, k - 1], Y[:, 2 * k - 1], atol=1e-6) and np.allclose(Y[:, k - 2], -Y[:, 2 * k - 2], atol=1e-6)
-    s = out['1'][1]
     lam = s / (0.01 * (1 + s))                                   # f^-1 on the positive side
     assert abs(s[k - 2] - 0.01 * lam[k - 1] / (1 + 0.01 * lam[k - 1])) <= 1e-5 * s[k - 2]   # |f(-lambda_max)|
