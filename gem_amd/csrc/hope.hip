@@ -78,6 +78,51 @@ __global__ __launch_bounds__(256) void hope_spmm_kernel(int64_t n, const int64_t
     }
 }
 
+// Quarter-wave variant for blocks of up to 128 columns: 16 lanes per row, four rows per wavefront.  The one-row-per-wavefront kernel
+// above is bound by its dependent chain (row_ptr -> col/val -> gathers -> store: ~12 rounds of resident waves at n = 100k, each a few
+// microseconds) and leaves the lanes beyond b idle; four independent chains per wavefront cut the rounds by four.  Lane l of a group
+// owns columns l, l+16, ...: a neighbour's row is read as CPL16 64-byte segments.  Neighbours are added in edge order like above.
+template <int CPL16, int U>
+__global__ __launch_bounds__(256) void hope_spmm16_kernel(int64_t n, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                          const float *__restrict__ val, float alpha, const float *__restrict__ X, int ldx,
+                                                          const float *__restrict__ Wadd, int ldw, float *__restrict__ Y, int ldy, int b,
+                                                          float wa, const float *__restrict__ W2, int ldw2, float wb)
+{
+    const int l16 = threadIdx.x & 15;
+    const int64_t i = xcd_contiguous_block(blockIdx.x, gridDim.x) * 16 + (threadIdx.x >> 4);
+    if (i >= n) return;
+    const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
+    float acc[CPL16];
+#pragma unroll
+    for (int c = 0; c < CPL16; ++c) acc[c] = 0.f;
+    for (int64_t e = e0; e < e1; e += U) {
+        int32_t cj[U]; float vj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t ee = (e + u) < e1 ? (e + u) : (e1 - 1);
+            cj[u] = col[ee]; vj[u] = (e + u) < e1 ? val[ee] : 0.f;
+        }
+        float xr[U][CPL16];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float *px = X + (int64_t)cj[u] * ldx;
+#pragma unroll
+            for (int c = 0; c < CPL16; ++c) { const int cc = l16 + c * 16; xr[u][c] = cc < b ? px[cc] : 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < CPL16; ++c) acc[c] += vj[u] * xr[u][c];
+    }
+#pragma unroll
+    for (int c = 0; c < CPL16; ++c) {
+        const int cc = l16 + c * 16;
+        if (cc >= b) continue;
+        if (!W2 && wa == 1.0f) Y[i * ldy + cc] = alpha * acc[c] + (Wadd ? Wadd[i * ldw + cc] : 0.f);
+        else Y[i * ldy + cc] = fmaf(alpha, acc[c], fmaf(wa, Wadd ? Wadd[i * ldw + cc] : 0.f, W2 ? wb * W2[i * ldw2 + cc] : 0.f));
+    }
+}
+
 // ------------------------------------------------------- Gram  P[slab] = X^T Y  (MFMA fp32)
 // One wavefront per 32x32 output tile and row slab.  v_mfma_f32_32x32x2_f32 consumes two rows
 // per issue: lane l supplies X[r + (l>>5)][ci + (l&31)] and Y[r + (l>>5)][cj + (l&31)] -- both
@@ -661,6 +706,23 @@ void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const f
     const int64_t blocks = (H.n + 3) / 4;
     const dim3 grid((unsigned)((blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD)), blk(256);
     const int64_t *rp = transpose ? H.rpT : H.rp; const int32_t *ci = transpose ? H.ciT : H.ci; const float *va = transpose ? H.vaT : H.va;
+    static const int use16 = getenv("GEMHIP_HOPE_SPMM16") ? atoi(getenv("GEMHIP_HOPE_SPMM16")) : 1;
+    if (use16 && b <= 128) {
+        const int64_t blocks16 = (H.n + 15) / 16;
+        const dim3 grid16((unsigned)((blocks16 + NUM_XCD - 1) / NUM_XCD * NUM_XCD));
+        const int c16 = (b + 15) / 16;
+#define SPMM16(C, U) hipLaunchKernelGGL((hope_spmm16_kernel<C, U>), grid16, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
+        static const int uu = getenv("GEMHIP_HOPE_SPMM16_U") ? atoi(getenv("GEMHIP_HOPE_SPMM16_U")) : 8;     // neighbours in flight per row (measured 4 / 8 / 16: 5.5 / 5.2 / 5.8 ms of SpMM per eigen-path solve)
+        if (c16 <= 1) SPMM16(1, 8);
+        else if (c16 <= 2) { if (uu >= 16) SPMM16(2, 16); else SPMM16(2, 8); }
+        else if (c16 <= 3) { if (uu >= 16) SPMM16(3, 16); else if (uu >= 8) SPMM16(3, 8); else SPMM16(3, 4); }
+        else if (c16 <= 4) { if (uu >= 16) SPMM16(4, 16); else if (uu >= 8) SPMM16(4, 8); else SPMM16(4, 4); }
+        else if (c16 <= 5) { if (uu >= 8) SPMM16(5, 8); else SPMM16(5, 4); }
+        else if (c16 <= 6) SPMM16(6, 4); else SPMM16(8, 2);
+#undef SPMM16
+        H.spmm_count += 1; H.spmm_cols += b;
+        return;
+    }
     const int cpl = (b + 63) / 64;
 #define SPMM(C) hipLaunchKernelGGL((hope_spmm_kernel<C>), grid, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
     if (cpl <= 1) SPMM(1); else if (cpl <= 2) SPMM(2); else if (cpl <= 4) SPMM(4); else SPMM(8);

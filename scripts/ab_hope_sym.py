@@ -26,7 +26,7 @@ variants = [('block_krylov', {'GEMHIP_HOPE_SYM': '0'}), ('sym', {'GEMHIP_HOPE_SY
 s_ref = np.asarray(ref['sigma_ascending'])
 for name, env in variants:
     for kk in list(os.environ):
-        if kk.startswith('GEMHIP_HOPE_'): del os.environ[kk]
+        if kk.startswith('GEMHIP_HOPE_') and kk != 'GEMHIP_HOPE_SPMM16': del os.environ[kk]      # SPMM16 (kernel choice) is read once per process
     os.environ.update(env)
     if name == 'sym': os.environ['GEMHIP_HOPE_DEBUG'] = '1'
     ts = []
