@@ -67,7 +67,7 @@ def sym_filter_svd(A, beta, k, oversample=16, tol=1e-5, max_cycles=60, amp=1e4, 
         c, e = 0.5 * (hi + lo), 0.5 * (hi - lo)
         tmax = max(L - c, c + L) / e
         rho = tmax + np.sqrt(max(tmax * tmax - 1, 0.0))
-        q = int(max(1, np.floor(np.log(1e3) / np.log(max(rho, 1.0001)))))
+        q = int(max(1, np.floor(np.log(1e5) / np.log(max(rho, 1.0001)))))
         rho_m = rho
         if Q.shape[1] and cyc > 0 and len(th):
             ta = min(tmax, max(1.0, 1.02 * np.abs(th - c).max() / e))
