@@ -1249,12 +1249,15 @@ void cheb_filter(Hope &H, float *V, int ldv, int cols, int m, double c, double e
 
 // Returns H.err; *fell_back = true when the iteration broke down or did not converge in max_cycles (the caller then runs the
 // general block-Krylov solver); outputs are only written on success.
-static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t max_cycles, float tol, uint64_t seed, double br,
+// kind 0: the Katz map f(x) = beta x / (1 - beta x) (HOPE; two-sided, outputs U sqrt(s), V sqrt(s));  kind 1: f(x) = 1 + x on the
+// normalised adjacency D^-1/2 A D^-1/2, spectrum in [-1, 1] (Laplacian Eigenmaps: the largest eigenvalues of I + M; one-sided, outputs
+// unit eigenvectors and f).
+static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t oversample, int32_t max_cycles, float tol, uint64_t seed, double br,
                           float *U_sqrtS, float *V_sqrtS, float *sigma, double *stats, bool *fell_back)
 {
     *fell_back = false;
     const double beta = H.beta;
-    auto fk = [&](double x) { return beta * x / (1.0 - beta * x); };
+    auto fk = [&](double x) { return kind == 1 ? 1.0 + x : beta * x / (1.0 - beta * x); };
     const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
     const int ldv = (b + 31) / 32 * 32;
     const bool debug = getenv("GEMHIP_HOPE_DEBUG") != nullptr;
@@ -1293,7 +1296,7 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
     hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, H.s, Vall, n, b, ldv, seed);
     int ma = orth_scaled(H, Vall, ldv, b, Tmp, ldv, 2), nl = 0;
 
-    const double L = br / std::fabs(beta);            // |lambda| <= L: power-iteration estimate + 10 %, capped by sqrt(max row sum x max column sum)
+    const double L = kind == 1 ? 1.0001 : br / std::fabs(beta);   // |lambda| <= L: power-iteration estimate + 10 %, capped by sqrt(max row sum x max column sum)
     double lo = -L, hi = 0.5 * L, tau_prev = 0.0;      // first filter: damp the lower three quarters of [-L, L]
     const double lock_tol = 0.1 * std::sqrt(std::max((double)tol, 1e-12));
     const int b_min = std::min(b, (int)oversample + 2);      // the active block keeps its oversampling columns
@@ -1392,9 +1395,12 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
         const double tau = std::max(tau_prev, std::fabs(fk(th[jc])));
         tau_prev = tau;
         if (!(tau > 0.0)) { lo = -L; hi = 0.5 * L; continue; }
-        hi = std::min(tau / (std::fabs(beta) * (1.0 + tau)), 0.98 * L);
-        lo = -std::min(L, tau < 1.0 ? tau / (std::fabs(beta) * (1.0 - tau)) : L);
-        if (lo > -1e-6 * L) lo = -1e-6 * L;
+        if (kind == 1) { hi = std::min(tau - 1.0, 0.98 * L); lo = -L; if (hi < -0.5 * L) hi = -0.5 * L; }
+        else {
+            hi = std::min(tau / (std::fabs(beta) * (1.0 + tau)), 0.98 * L);
+            lo = -std::min(L, tau < 1.0 ? tau / (std::fabs(beta) * (1.0 - tau)) : L);
+            if (lo > -1e-6 * L) lo = -1e-6 * L;
+        }
     }
     if (!H.err && !converged) { *fell_back = true; cleanup(); return GEMHIP_OK; }
     if (!H.err) {
@@ -1416,7 +1422,7 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
             sigma[j] = (float)s;
             const double flip = (sf * cm[cand[r].col] < 0) ? -1.0 : 1.0;
             Cu[(size_t)cand[r].col * k + j] = flip * sf * std::sqrt(s);
-            Cv[(size_t)cand[r].col * k + j] = flip * std::sqrt(s);
+            Cv[(size_t)cand[r].col * k + j] = kind == 1 ? flip : flip * std::sqrt(s);
         }
         if (U_sqrtS) {
             tsgemm(H, Vall, ldv, mc, Cu, k, 1.0f, nullptr, 0, Tmp, k);
@@ -1429,7 +1435,7 @@ static int sym_filter_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
     if (!H.err) spmm_time_collect(H); else H.sp_used = 0;
     if (stats && !H.err) {
-        stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = 0.0 /* no Katz series: f on the eigenvalues */; stats[4] = nl + ma;
+        stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = kind == 1 ? -1.0 : 0.0 /* no Katz series: f on the eigenvalues (-1: the Laplacian-Eigenmaps map) */; stats[4] = nl + ma;
         stats[5] = cycles; stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual;
         stats[11] = H.spmm_ms * 1e-3;
     }
@@ -1570,7 +1576,7 @@ extern "C" int gemhip_hope_plan_solve(gemhip_hope_plan_t P, int32_t k, int32_t o
     const bool sym_ok = P->symmetric && H.beta > 0.f && (int64_t)k + oversample + 1 < H.n;
     if (sym_ok && (sym_env ? atoi(sym_env) != 0 : (H.n >= 16384 && 8 * ((int64_t)k + oversample) <= H.n))) {
         bool fell_back = false;
-        const int rc = sym_filter_svd(H, H.n, k, oversample, std::max(40, 3 * (int)max_restarts), tol, seed, P->br, U_sqrtS, V_sqrtS, sigma, stats, &fell_back);
+        const int rc = sym_filter_svd(H, 0, H.n, k, oversample, std::max(40, 3 * (int)max_restarts), tol, seed, P->br, U_sqrtS, V_sqrtS, sigma, stats, &fell_back);
         if (rc || !fell_back) return rc;
         H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr; H.sp_used = 0;      // not converged: the general solver
         g_eig_seconds = 0.0; g_eig_calls = 0.0;
@@ -1624,8 +1630,20 @@ extern "C" int gemhip_lap_eigmap(int64_t n, int64_t nnz, const int64_t *row_ptr,
     up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
     if (H.err) return H.err;
     std::vector<float> sig(k);
-    const int rc = krylov_svd(H, n, k, oversample, krylov_steps, max_restarts, tol, seed, 0, 0.0, 1, nullptr, V_out, sig.data(), stats);
-    if (rc) return rc;
+    // large graphs: the Chebyshev-filtered eigen-path of HOPE (the operator is one SpMM with a symmetric matrix); same switch
+    const char *sym_env = getenv("GEMHIP_HOPE_SYM");
+    bool done = false;
+    if ((int64_t)k + oversample + 1 < n && (sym_env ? atoi(sym_env) != 0 : (n >= 16384 && 8 * ((int64_t)k + oversample) <= n))) {
+        bool fell_back = false;
+        const int rcs = sym_filter_svd(H, 1, n, k, oversample, std::max(40, 3 * (int)max_restarts), tol, seed, 0.0, nullptr, V_out, sig.data(), stats, &fell_back);
+        if (rcs) return rcs;
+        done = !fell_back;
+        if (!done) { H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr; H.sp_used = 0; g_eig_seconds = 0.0; g_eig_calls = 0.0; }
+    }
+    if (!done) {
+        const int rc = krylov_svd(H, n, k, oversample, krylov_steps, max_restarts, tol, seed, 0, 0.0, 1, nullptr, V_out, sig.data(), stats);
+        if (rc) return rc;
+    }
     // sigma ascending = (2 - w) ascending; lap.py wants w ascending: reverse the columns
     for (int j = 0; j < k; ++j) eigvals[j] = 2.0f - sig[k - 1 - j];
     for (int64_t i = 0; i < n; ++i)

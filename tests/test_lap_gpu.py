@@ -64,3 +64,33 @@ def test_lle_karate_and_sbm(karate, sbm1024):
     assert np.allclose(m._singvals[1:], so[1:], atol=2e-6) and m._singvals[0] < 1e-3, (m._singvals, so)
     Ya = align(Y, Xo)
     assert np.abs(Ya[:, :2] - Xo[:, :2]).max() < 1e-3
+
+
+def test_eigen_path_agrees_with_block_krylov_and_scipy(monkeypatch):
+    """From 16384 nodes up Laplacian Eigenmaps runs HOPE's Chebyshev-filtered eigen-path on D^-1/2 A D^-1/2 (hope.hip sym_filter_svd,
+    kind 1).  SBM 20000/200000, d=16: eigenvalues of L_sym against scipy eigsh and against the block-Krylov path, community vectors one by
+    one, the subspace by its projector."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sla
+    from gem_amd.graph import sbm_graph
+    g = sbm_graph(20000, 200000, 8, seed=21)
+    n, src, dst, w = symmetric_arrays(g)
+    out = {}
+    for sym in ('0', '1'):
+        monkeypatch.setenv('GEMHIP_HOPE_SYM', sym)
+        m = LaplacianEigenmaps(d=16)
+        Y = m.learn_embedding(graph=g)
+        out[sym] = (Y, m._eigvals.copy(), m._stats['solver'])
+    monkeypatch.delenv('GEMHIP_HOPE_SYM')
+    m = LaplacianEigenmaps(d=16); m.learn_embedding(graph=g)
+    assert out['0'][2] == 'block_krylov' and out['1'][2] == 'symmetric_chebyshev_filter' and m._stats['solver'] == 'symmetric_chebyshev_filter'
+    A = sp.csr_matrix((np.ones(len(src)) if w is None else w.astype(np.float64), (src, dst)), shape=(n, n))
+    deg = np.asarray(A.sum(axis=1)).ravel(); dinv = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1e-300)), 0.0)
+    M = sp.diags(dinv) @ A @ sp.diags(dinv)
+    ref = 1.0 - np.sort(sla.eigsh(M, k=17, which='LA', tol=1e-10)[0])[::-1]            # eigenvalues of L_sym ascending
+    for key in ('0', '1'):
+        assert np.allclose(out[key][1], ref, atol=1e-5), (key, np.abs(out[key][1] - ref).max())
+    Y0, Y1 = out['0'][0], out['1'][0]
+    Ya = align(Y1, Y0)
+    assert np.abs(Ya[:, :7] - Y0[:, :7]).max() < 5e-4                                 # the 7 non-trivial community vectors
+    assert np.linalg.norm(Y0 @ (Y0.T @ Y1) - Y1) <= 5e-2 * np.sqrt(16)                 # same subspace
