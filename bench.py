@@ -313,7 +313,7 @@ class N2VWorkload(object):
 
 class HopeWorkload(object):
     """BASELINE configs[2]: SBM 100k nodes / 1M edges, HOPE d=128 (k=64), beta=0.01; embeddings/sec = n / wall."""
-    metric, unit, dtype, kernel = 'embeddings/sec', 'embeddings/s', 'f32', 'hope_spmm_kernel'
+    metric, unit, dtype, kernel = 'embeddings/sec', 'embeddings/s', 'f32', 'hope_spmm16_kernel'
     default_steps, default_warmup = 5, 1
 
     def __init__(self, args, rank, world, comm):
