@@ -356,7 +356,9 @@ class HopeWorkload(object):
         avg_s = self.spmm_s / launches
         ach = algo / avg_s / 1e9
         gather = (4.0 * bavg + 8.0) * self.n_edges + 8.0 * self.n * bavg
-        return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+        per_col, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_column')
+        return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                'traffic': None if per_col is None else per_col * bavg, 'traffic_source': tsrc,
                 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6, 'spmm_launches_per_step': launches / self.calls,
                 'avg_block_columns': bavg, 'device_seconds_per_step': self.dev_s / self.calls, 'spmm_seconds_per_step': self.spmm_s / self.calls,
                 'host_eig_seconds_per_step': self.eig_s / self.calls, 'restarts': self.stats[5], 'katz_terms': self.stats[3],
