@@ -169,6 +169,8 @@ class N2VWorkload(object):
     def __init__(self, args, rank, world, comm):
         self.name = '%s%dk_%dk_node2vec_d%d_r%d_l%d_k%d' % (args.graph, args.nodes // 1000, args.edges // 1000, args.d, args.num_walks,
                                                             args.walk_len, args.window)
+        if (args.ret_p, args.inout_q) != (1.0, 1.0):
+            self.name += '_p%g_q%g' % (args.ret_p, args.inout_q)
         self.args, self.rank, self.world = args, rank, world
         g = make_graph(args)
         self.g = g
@@ -198,7 +200,7 @@ class N2VWorkload(object):
         self.b.pairs(reset=True)
 
     def step(self):
-        self.P = self.job.run(1.0, 1.0)
+        self.P = self.job.run(float(self.args.ret_p), float(self.args.inout_q))
 
     def units_per_step(self):
         return self.n_edges
@@ -473,6 +475,8 @@ def main():
     ap.add_argument('--num-walks', type=int, default=10)
     ap.add_argument('--walk-len', type=int, default=80)
     ap.add_argument('--window', type=int, default=10)
+    ap.add_argument('--ret-p', type=float, default=1.0, help='node2vec return parameter p (node2vec.py:40 -p:)')
+    ap.add_argument('--inout-q', type=float, default=1.0, help='node2vec in-out parameter q (node2vec.py:41 -q:)')
     ap.add_argument('--gf-eta', type=float, default=1e-2)
     ap.add_argument('--gf-regu', type=float, default=1e-2)
     ap.add_argument('--episodes', type=int, default=64, help='N>1 node2vec: episodes of the partitioned schedule')
