@@ -169,20 +169,20 @@ void launch_sweep(const gemhip_gf_plan *p, int64_t row0, int64_t nrows, const fl
 
 // Hub rows (power-law graphs).  The updates of one row are one dependent chain (exact Gauss-Seidel): a wave that also fetches its
 // neighbour rows pays a memory latency per batch on top of the chain (130 ns per update measured).  Here a row with >= GF_HUB_EDGES firing
-// edges gets a whole workgroup: wavefronts 1-3 stream the neighbour rows (and weights) of successive batches through an LDS ring, wave 0
+// edges gets a whole workgroup: wavefronts 1-NP stream the neighbour rows (and weights) of successive batches through an LDS ring, wave 0
 // does nothing but apply them, in edge order, with the very same gf_apply_edge -- bit-identical to the wave-per-row kernel.
 typedef __attribute__((address_space(3))) volatile int32_t gf_lds_vi32;
 __device__ __forceinline__ int32_t gf_flag_ld(const int32_t *p) { return *(gf_lds_vi32 *)p; }
 __device__ __forceinline__ void gf_flag_st(int32_t *p, int32_t v) { *(gf_lds_vi32 *)p = v; }
 
-template <int VEC, int NV>
-__global__ __launch_bounds__(256) void gf_hub_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
+template <int VEC, int NV, int NP>
+__global__ __launch_bounds__((NP + 1) * 64) void gf_hub_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
                                                      const uint32_t *__restrict__ col, const float *__restrict__ w, const float *Xold,
                                                      float *Xnew, int64_t row0, int d, float eta, float regu)
 {
     constexpr int RW = NV * VEC * WAVE;              // floats of one staged row
     constexpr int B = NV >= 8 ? 2 : 16 / NV;         // edges per batch
-    constexpr int NBATCH = 4;                        // ring depth in batches (32 KB of rows)
+    constexpr int NBATCH = NP + 1;                   // ring depth in batches: one per producer wavefront + the one being consumed (8 KB of rows each)
     constexpr int G = B >= 4 ? 4 : B;                // rows the consumer moves LDS -> registers at a time
     __shared__ __attribute__((aligned(16))) float ring[NBATCH * B * RW];
     __shared__ float wring[NBATCH * 16];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void gf_hub_kernel(const int32_t *__restrict__
             }
         }
     } else {
-        for (int t = wave - 1; t < nb; t += 3) {
+        for (int t = wave - 1; t < nb; t += NP) {
             const int sb = t % NBATCH;
             while (gf_flag_ld(&done) < t - NBATCH + 1) __builtin_amdgcn_s_sleep(1);     // the batch that used this ring segment is consumed
             asm volatile("" ::: "memory");
@@ -275,8 +275,15 @@ __global__ __launch_bounds__(256) void gf_hub_kernel(const int32_t *__restrict__
 template <int VEC, int NV>
 void launch_hub(const gemhip_gf_plan *p, int64_t row0, int64_t nhub, const float *Xold, float *Xnew, float eta, float regu, hipStream_t s)
 {
-    hipLaunchKernelGGL((gf_hub_kernel<VEC, NV>), dim3((unsigned)nhub), dim3(256), 0, s, p->d_rows, p->d_ptr, p->d_col, p->d_w, Xold, Xnew, row0,
-                       (int)p->d, eta, regu);
+    // producer wavefronts per hub row: the chain's wavefront consumes a neighbour row every ~50 ns, a producer needs two loaded-HBM round
+    // trips per batch of 16 while the wave-per-row kernel saturates the memory system next to it (GEMHIP_GF_HUB_PRODUCERS=3|7 for the A/B)
+    static const int np = getenv("GEMHIP_GF_HUB_PRODUCERS") ? atoi(getenv("GEMHIP_GF_HUB_PRODUCERS")) : 7;
+    if (np >= 7)
+        hipLaunchKernelGGL((gf_hub_kernel<VEC, NV, 7>), dim3((unsigned)nhub), dim3(512), 0, s, p->d_rows, p->d_ptr, p->d_col, p->d_w, Xold, Xnew, row0,
+                           (int)p->d, eta, regu);
+    else
+        hipLaunchKernelGGL((gf_hub_kernel<VEC, NV, 3>), dim3((unsigned)nhub), dim3(256), 0, s, p->d_rows, p->d_ptr, p->d_col, p->d_w, Xold, Xnew, row0,
+                           (int)p->d, eta, regu);
 }
 using hub_fn = void (*)(const gemhip_gf_plan *, int64_t, int64_t, const float *, float *, float, float, hipStream_t);
 hub_fn pick_hub(int d)
