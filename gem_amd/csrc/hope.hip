@@ -1219,14 +1219,31 @@ int orth_scaled(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, int passe
     return keep;
 }
 
-// V[:, :cols] <- T_m((A - c I) / e) V[:, :cols]   (Chebyshev polynomial of the first kind; F[0..2]: n x cols scratch, leading dimension ldf).
+// Out = Op X for the eigen-path's operators: kind 0 / 1: Op = the CSR matrix (one SpMM); kind 2 (LLE): Op = N^T N, N = I - P, through the
+// n x cols scratch T (two SpMMs).  alpha scales Op X; (wa, W) and (wb, W2) are the optional addends of the fused epilogue.
+void apply_sym_op(Hope &H, int kind, float alpha, const float *X, int ldx, int cols, float *T, int ldt, float *Out, int ldo, float wa, const float *W,
+                  int ldw, float wb, const float *W2, int ldw2)
+{
+    if (kind != 2) { spmm(H, false, alpha, X, ldx, W, ldw, Out, ldo, cols, wa, W2, ldw2, wb); return; }
+    spmm(H, false, -1.0f, X, ldx, X, ldx, T, ldt, cols);                                        // T = X - P X
+    if (!W && !W2) { spmm(H, true, -alpha, T, ldt, T, ldt, Out, ldo, cols, alpha); return; }     // alpha (T - P^T T)
+    // alpha (T - P^T T) + wa W + wb W2: the SpMM epilogue takes two addends, so W and W2 are combined first (into Out, which the
+    // epilogue then reads and overwrites element by element)
+    hipLaunchKernelGGL(hope_lincomb_kernel, dim3((unsigned)((H.n * cols + 255) / 256)), dim3(256), 0, H.s, H.n, cols, W ? wa : 0.f, W ? W : T, W ? ldw : ldt,
+                       W2 ? wb : 0.f, W2 ? W2 : T, W2 ? ldw2 : ldt, 0.f, T, ldt, Out, ldo);
+    spmm(H, true, -alpha, T, ldt, T, ldt, Out, ldo, cols, alpha, Out, ldo, 1.0f);
+}
+
+// V[:, :cols] <- T_m((Op - c I) / e) V[:, :cols]   (Chebyshev polynomial of the first kind; F[0..2]: n x cols scratch, leading dimension ldf;
+// Ts: one more scratch block for kind 2).
 // Q[:, :nl] (locked eigenvectors) is projected out of the two live terms of the recurrence every q degrees: what the locked directions
 // regain through their residuals and through rounding grows by the filter's edge growth per degree, q keeps that below ~1e5.
-void cheb_filter(Hope &H, float *V, int ldv, int cols, int m, double c, double e, float *const F[3], int ldf, const float *Q, int ldq, int nl, int q)
+void cheb_filter(Hope &H, int kind, float *V, int ldv, int cols, int m, double c, double e, float *const F[3], int ldf, float *Ts, const float *Q, int ldq,
+                 int nl, int q)
 {
     if (H.err || cols == 0 || m < 1) return;
     int i1 = 0, i0 = -1;                                                                                           // F[i1] = Y_j, F[i0] = Y_{j-1} (-1: V)
-    { SpmmTimer timer(H); spmm(H, false, (float)(1.0 / e), V, ldv, V, ldv, F[0], ldf, cols, (float)(-c / e)); }   // Y1 = (A V - c V) / e
+    { SpmmTimer timer(H); apply_sym_op(H, kind, (float)(1.0 / e), V, ldv, cols, Ts, ldf, F[0], ldf, (float)(-c / e), V, ldv, 0.f, nullptr, 0); }   // Y1 = (Op V - c V) / e
     int j = 2;
     while (j <= m && !H.err) {
         if (nl > 0 && q > 0 && (j - 1) % q == 0) {
@@ -1238,7 +1255,7 @@ void cheb_filter(Hope &H, float *V, int ldv, int cols, int m, double c, double e
             int i2 = 0;
             while (i2 == i1 || i2 == i0) ++i2;
             const float *y0 = i0 < 0 ? V : F[i0];
-            spmm(H, false, (float)(2.0 / e), F[i1], ldf, F[i1], ldf, F[i2], ldf, cols, (float)(-2.0 * c / e), y0, i0 < 0 ? ldv : ldf, -1.0f);   // Y_{j+1} = 2 (A - c) Y_j / e - Y_{j-1}
+            apply_sym_op(H, kind, (float)(2.0 / e), F[i1], ldf, cols, Ts, ldf, F[i2], ldf, (float)(-2.0 * c / e), F[i1], ldf, -1.0f, y0, i0 < 0 ? ldv : ldf);   // Y_{j+1} = 2 (Op - c) Y_j / e - Y_{j-1}
             i0 = i1; i1 = i2; ++j;
         } while (j <= m && !(nl > 0 && q > 0 && (j - 1) % q == 0));
     }
@@ -1251,13 +1268,14 @@ void cheb_filter(Hope &H, float *V, int ldv, int cols, int m, double c, double e
 // general block-Krylov solver); outputs are only written on success.
 // kind 0: the Katz map f(x) = beta x / (1 - beta x) (HOPE; two-sided, outputs U sqrt(s), V sqrt(s));  kind 1: f(x) = 1 + x on the
 // normalised adjacency D^-1/2 A D^-1/2, spectrum in [-1, 1] (Laplacian Eigenmaps: the largest eigenvalues of I + M; one-sided, outputs
-// unit eigenvectors and f).
+// unit eigenvectors and f);  kind 2: f(x) = c - x on N^T N, N = I - P, spectrum in [0, c], c = H.beta (LLE: the SMALLEST eigenvalues;
+// one-sided at the lower end, two SpMMs per application, outputs unit eigenvectors and f).
 static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t oversample, int32_t max_cycles, float tol, uint64_t seed, double br,
                           float *U_sqrtS, float *V_sqrtS, float *sigma, double *stats, bool *fell_back)
 {
     *fell_back = false;
     const double beta = H.beta;
-    auto fk = [&](double x) { return kind == 1 ? 1.0 + x : beta * x / (1.0 - beta * x); };
+    auto fk = [&](double x) { return kind == 1 ? 1.0 + x : kind == 2 ? beta - x : beta * x / (1.0 - beta * x); };
     const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
     const int ldv = (b + 31) / 32 * 32;
     const bool debug = getenv("GEMHIP_HOPE_DEBUG") != nullptr;
@@ -1296,8 +1314,10 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
     hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, H.s, Vall, n, b, ldv, seed);
     int ma = orth_scaled(H, Vall, ldv, b, Tmp, ldv, 2), nl = 0;
 
-    const double L = kind == 1 ? 1.0001 : br / std::fabs(beta);   // |lambda| <= L: power-iteration estimate + 10 %, capped by sqrt(max row sum x max column sum)
-    double lo = -L, hi = 0.5 * L, tau_prev = 0.0;      // first filter: damp the lower three quarters of [-L, L]
+    const double L = kind == 1 ? 1.0001 : kind == 2 ? beta : br / std::fabs(beta);   // |lambda| <= L: power-iteration estimate + margin
+    const double smin = kind == 2 ? 0.0 : -L, smax = L;                // the operator's spectrum lies in [smin, smax]
+    double lo = kind == 2 ? 0.25 * L : -L, hi = kind == 2 ? L : 0.5 * L, tau_prev = 0.0;      // first filter: damp the unwanted three quarters
+    const double res_floor = kind == 2 ? 0.25 * L : 0.0;              // LLE's wanted eigenvalues start at 0: residuals relative to the scale
     const double lock_tol = 0.1 * std::sqrt(std::max((double)tol, 1e-12));
     const int b_min = std::min(b, (int)oversample + 2);      // the active block keeps its oversampling columns
     std::vector<double> lock_lam, th, res, sig(k, 0.0), sig_old(k, 0.0);
@@ -1307,7 +1327,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
     for (int cyc = 0; cyc < max_cycles && !H.err; ++cyc) {
         cycles = cyc + 1;
         const double c = 0.5 * (hi + lo), e = 0.5 * (hi - lo);
-        const double tmax = std::max(L - c, c + L) / e;
+        const double tmax = std::max(smax - c, c - smin) / e;
         const double rho = tmax + std::sqrt(std::max(tmax * tmax - 1.0, 0.0));
         // in-filter deflation period: edge growth <= 1e5 between projections (numpy mirror, SBM 100k/1M: 1e3 / 1e4 / 1e5 / 1e6 give the
         // same singular values with 50 / 34 / 26 / 16 projections per solve; at 1e8 the error grows tenfold)
@@ -1321,7 +1341,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         }
         const int m = (int)std::max(2.0, std::min((double)max_degree, std::floor(std::log(cyc == 0 ? amp0 : amp) / std::log(std::max(rho_m, 1.0001)))));
         float *Va = Vall + nl;
-        cheb_filter(H, Va, ldv, ma, m, c, e, F, ldv, Vall, ldv, nl, q);
+        cheb_filter(H, kind, Va, ldv, ma, m, c, e, F, ldv, Bm, Vall, ldv, nl, q);
         degree_total += m;
         // CholeskyQR2; with locked vectors the projection is repeated between the two passes (the first pass rescales the block)
         int keep;
@@ -1335,7 +1355,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         ma = keep;
         // Rayleigh-Ritz on A over the active block
         std::vector<double> Hh, ev;
-        { SpmmTimer timer(H); spmm(H, false, 1.0f, Va, ldv, nullptr, 0, Bm, ldv, ma); }
+        { SpmmTimer timer(H); apply_sym_op(H, kind, 1.0f, Va, ldv, ma, F[0], ldv, Bm, ldv, 1.0f, nullptr, 0, 0.f, nullptr, 0); }
         gram(H, Va, ldv, ma, Bm, ldv, ma, Hh);
         if (H.err) break;
         for (int i = 0; i < ma; ++i)
@@ -1374,14 +1394,14 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         sig_old = sig;
         const int want = k - nl;                                                       // wanted pairs still active: the leading ones
         double rmax = 0.0;
-        for (int j = 0; j < std::min(want, ma); ++j) rmax = std::max(rmax, res[j] / std::max(std::fabs(th[j]), 1e-3 * L));
+        for (int j = 0; j < std::min(want, ma); ++j) rmax = std::max(rmax, res[j] / std::max(std::max(std::fabs(th[j]), 1e-3 * L), res_floor));
         last_residual = rmax;
         if (debug)
             fprintf(stderr, "[hope-sym] cycle %d degree %d interval [%.4f, %.4f] locked %d active %d sigma_k %.6g sigma_1 %.6g change %.3e residual %.3e\n",
                     cyc, m, lo, hi, nl, ma, sig[k - 1], sig[0], last_change, rmax);
         if (cyc > 0 && last_change < tol && rmax < 1e-2) { converged = true; break; }
         int newl = 0;
-        while (newl < want - 1 && newl < ma - b_min && res[newl] < lock_tol * std::fabs(th[newl])) ++newl;
+        while (newl < want - 1 && newl < ma - b_min && res[newl] < lock_tol * std::max(std::fabs(th[newl]), res_floor)) ++newl;
         if (newl > 0) {                                                                // leading columns of the active block: bookkeeping only
             for (int j = 0; j < newl; ++j) lock_lam.push_back(th[j]);
             th.erase(th.begin(), th.begin() + newl); res.erase(res.begin(), res.begin() + newl);
@@ -1394,8 +1414,9 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         const int jc = std::max(0, std::min(ma - 1, want_left + (ma - want_left) / 2 - 1));
         const double tau = std::max(tau_prev, std::fabs(fk(th[jc])));
         tau_prev = tau;
-        if (!(tau > 0.0)) { lo = -L; hi = 0.5 * L; continue; }
-        if (kind == 1) { hi = std::min(tau - 1.0, 0.98 * L); lo = -L; if (hi < -0.5 * L) hi = -0.5 * L; }
+        if (!(tau > 0.0)) { lo = kind == 2 ? 0.25 * L : -L; hi = kind == 2 ? L : 0.5 * L; continue; }
+        if (kind == 2) { lo = std::max(beta - tau, 0.01 * L); hi = L; }
+        else if (kind == 1) { hi = std::min(tau - 1.0, 0.98 * L); lo = -L; if (hi < -0.5 * L) hi = -0.5 * L; }
         else {
             hi = std::min(tau / (std::fabs(beta) * (1.0 + tau)), 0.98 * L);
             lo = -std::min(L, tau < 1.0 ? tau / (std::fabs(beta) * (1.0 - tau)) : L);
@@ -1422,7 +1443,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
             sigma[j] = (float)s;
             const double flip = (sf * cm[cand[r].col] < 0) ? -1.0 : 1.0;
             Cu[(size_t)cand[r].col * k + j] = flip * sf * std::sqrt(s);
-            Cv[(size_t)cand[r].col * k + j] = kind == 1 ? flip : flip * std::sqrt(s);
+            Cv[(size_t)cand[r].col * k + j] = kind >= 1 ? flip : flip * std::sqrt(s);
         }
         if (U_sqrtS) {
             tsgemm(H, Vall, ldv, mc, Cu, k, 1.0f, nullptr, 0, Tmp, k);
@@ -1435,7 +1456,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
     if (!H.err) spmm_time_collect(H); else H.sp_used = 0;
     if (stats && !H.err) {
-        stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = kind == 1 ? -1.0 : 0.0 /* no Katz series: f on the eigenvalues (-1: the Laplacian-Eigenmaps map) */; stats[4] = nl + ma;
+        stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = kind >= 1 ? -(double)kind : 0.0 /* no Katz series: f on the eigenvalues (-1: the Laplacian-Eigenmaps map, -2: LLE) */; stats[4] = nl + ma;
         stats[5] = cycles; stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual;
         stats[11] = H.spmm_ms * 1e-3;
     }
@@ -1712,8 +1733,21 @@ extern "C" int gemhip_lle(int64_t n, int64_t nnz, const int64_t *row_ptr, const 
     up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
     if (H.err) return H.err;
     std::vector<float> sig(k);
-    const int rc = krylov_svd(H, n, k, oversample, krylov_steps, max_restarts, tol, seed, 0, 0.0, 1, nullptr, V_out, sig.data(), stats);
-    if (rc) return rc;
+    // large graphs: the Chebyshev-filtered eigen-path on N^T N itself (kind 2), which converges where the block-Krylov solver runs out of
+    // its restart budget (the bottom of the spectrum is clustered); same switch as HOPE and Laplacian Eigenmaps
+    const char *sym_env = getenv("GEMHIP_HOPE_SYM");
+    bool done = false;
+    if ((int64_t)k + oversample + 1 < n && (sym_env ? atoi(sym_env) != 0 : (n >= 16384 && 8 * ((int64_t)k + oversample) <= n))) {
+        bool fell_back = false;
+        const int rcs = sym_filter_svd(H, 2, n, k, oversample, std::max(40, 3 * (int)max_restarts), tol, seed, 0.0, nullptr, V_out, sig.data(), stats, &fell_back);
+        if (rcs) return rcs;
+        done = !fell_back;
+        if (!done) { H.err = 0; H.spmm_count = 0; H.spmm_cols = 0; H.spmm_ms = 0; H.sp0 = nullptr; H.sp1 = nullptr; H.sp_used = 0; g_eig_seconds = 0.0; g_eig_calls = 0.0; }
+    }
+    if (!done) {
+        const int rc = krylov_svd(H, n, k, oversample, krylov_steps, max_restarts, tol, seed, 0, 0.0, 1, nullptr, V_out, sig.data(), stats);
+        if (rc) return rc;
+    }
     // eigenvalue of c I - N^T N = c - s^2 (ascending in sig) -> s ascending means reversing the columns
     for (int j = 0; j < k; ++j) sing[j] = (float)std::sqrt(std::max(c - (double)sig[k - 1 - j], 0.0));
     for (int64_t i = 0; i < n; ++i)

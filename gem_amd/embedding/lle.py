@@ -39,6 +39,7 @@ class LocallyLinearEmbedding(StaticGraphEmbedding):
                                          int(getattr(self, '_max_restarts', 40)), float(getattr(self, '_tol', 1e-6)),
                                          int(getattr(self, '_seed', 20260923)), _hip.ptr(V, C.c_float), _hip.ptr(sv, C.c_float), stats))
         self._stats = dict(zip(('device_seconds', 'spmm_launches', 'spmm_columns', 'katz_terms', 'basis_columns', 'restarts', 'last_sigma_change', 'beta_sigma_max', 'host_eig_seconds', 'host_eig_calls', 'ritz_residual', 'spmm_seconds'), list(stats)))
+        self._stats['solver'] = 'symmetric_chebyshev_filter' if self._stats['katz_terms'] < 0 else 'block_krylov'   # hope.hip: from 16384 nodes up
         _hip.warn_if_unconverged(self._stats, float(getattr(self, '_tol', 1e-6)), int(getattr(self, '_max_restarts', 40)), 'LocallyLinearEmbedding')
         self._singvals = sv.astype(np.float64)
         self._node_num = n

@@ -266,14 +266,18 @@ int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *c
  * Input: CSR of the SYMMETRIC weighted adjacency in graph.nodes order (w NULL = unit).  The k smallest eigenpairs of
  * L_sym = I - D^-1/2 A D^-1/2 are computed as the k largest of I + D^-1/2 A D^-1/2 with the HOPE block-Krylov solver
  * (one SpMM per operator application).  V_out [n][k]: unit eigenvectors, eigvals[k] ascending (column 0 is the
- * trivial eigenvector lap.py drops with v[:, 1:]).  stats: as gemhip_hope. */
+ * trivial eigenvector lap.py drops with v[:, 1:]).  stats: as gemhip_hope.  From 16384 nodes up (GEMHIP_HOPE_SYM=0/1 forces it
+ * off/on) the Chebyshev-filtered eigen-path of gemhip_hope is used (stats katz_terms = -1), with the block-Krylov solver as
+ * the fallback when it does not converge. */
 int gemhip_lap_eigmap(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
                       int32_t k, int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol,
                       uint64_t seed, float *V_out, float *eigvals, double *stats);
 
 /* Locally Linear Embedding.  Replaces gem/embedding/lle.py:23-35: svds(I - D^-1 A, k=d+1, which='SM').
  * Input as gemhip_lap_eigmap (symmetric adjacency; rows are l1-normalised here).  sing[k]: the k smallest singular
- * values of I - P ascending; V_out [n][k]: matching right singular vectors (column 0 ~ the constant vector lle.py drops). */
+ * values of I - P ascending; V_out [n][k]: matching right singular vectors (column 0 ~ the constant vector lle.py drops).
+ * Same size switch as gemhip_lap_eigmap: the eigen-path filters N^T N, N = I - P, towards its smallest eigenvalues
+ * (stats katz_terms = -2). */
 int gemhip_lle(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, int32_t k,
                int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol, uint64_t seed,
                float *V_out, float *sing, double *stats);

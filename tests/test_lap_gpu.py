@@ -94,3 +94,41 @@ def test_eigen_path_agrees_with_block_krylov_and_scipy(monkeypatch):
     Ya = align(Y1, Y0)
     assert np.abs(Ya[:, :7] - Y0[:, :7]).max() < 5e-4                                 # the 7 non-trivial community vectors
     assert np.linalg.norm(Y0 @ (Y0.T @ Y1) - Y1) <= 5e-2 * np.sqrt(16)                 # same subspace
+
+
+def test_lle_eigen_path_at_20k(monkeypatch):
+    """From 16384 nodes up LLE runs the Chebyshev-filtered eigen-path on N^T N, N = I - D^-1 A (hope.hip sym_filter_svd kind 2: the
+    SMALLEST eigenvalues, two SpMMs per application).  SBM 20000/200000, d=16: every returned pair satisfies ||N v|| = s and
+    N^T N v = s^2 v, V is orthonormal, the constant vector comes first (s = 0), the 7 community singular values equal the ones the numpy
+    mirror of the solver converged to on the CPU (which agrees with scipy svds(which='SM') at 2000 nodes to 2e-6), and the block-Krylov
+    path, where it converges (those 8 values), gives the same numbers."""
+    import scipy.sparse as sp
+    from gem_amd.embedding.lle import LocallyLinearEmbedding
+    from gem_amd.graph import sbm_graph
+    g = sbm_graph(20000, 200000, 8, seed=21)
+    n, src, dst, w = symmetric_arrays(g)
+    out = {}
+    for sym in ('0', '1'):
+        monkeypatch.setenv('GEMHIP_HOPE_SYM', sym)
+        m = LocallyLinearEmbedding(d=16)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)            # the block-Krylov path runs out of restarts here
+            Y = m.learn_embedding(graph=g)
+        out[sym] = (Y, m._singvals.copy(), m._stats['solver'], dict(m._stats))
+    assert out['0'][2] == 'block_krylov' and out['1'][2] == 'symmetric_chebyshev_filter'
+    assert out['1'][3]['last_sigma_change'] < 1e-6                                    # converged
+    s = out['1'][1]                                                                   # d + 1 values ascending; column 0 is dropped from Y
+    mirror = np.array([0.154067107, 0.155979128, 0.165448018, 0.169363148, 0.178480677, 0.183468668, 0.186955405])
+    assert s[0] < 2e-3 and np.all(np.diff(s) >= -1e-7)
+    assert np.allclose(s[1:8], mirror, atol=2e-5), np.abs(s[1:8] - mirror).max()
+    assert np.allclose(out['0'][1][1:8], mirror, atol=2e-4)
+    A = sp.csr_matrix((np.ones(len(src)) if w is None else w.astype(np.float64), (src, dst)), shape=(n, n))
+    deg = np.asarray(np.abs(A).sum(axis=1)).ravel()
+    N = sp.identity(n) - sp.diags(np.where(deg > 0, 1.0 / np.maximum(deg, 1e-300), 0.0)) @ A
+    V = out['1'][0]                                                                   # columns 1..d
+    NV = N @ V
+    assert np.allclose(np.linalg.norm(NV, axis=0), s[1:], atol=2e-5)
+    assert np.linalg.norm(N.T @ NV - V * s[1:] ** 2, axis=0).max() < 2e-3
+    assert np.abs(V.T @ V - np.eye(16)).max() < 5e-5
+    assert np.abs(V.sum(axis=0)).max() / np.sqrt(n) < 5e-3                            # orthogonal to the dropped constant vector
