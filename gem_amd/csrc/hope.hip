@@ -1706,32 +1706,42 @@ extern "C" int gemhip_lle(int64_t n, int64_t nnz, const int64_t *row_ptr, const 
         for (int64_t i = 0; i < n; ++i)
             for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { const int64_t q = at[col[e]]++; ciT[q] = (int32_t)i; vaT[q] = va[e]; }
     }
-    // c >= sigma_max(I - P)^2: power iteration on N^T N (host), with a margin
-    double c = 4.0;
-    {
-        std::vector<double> x(n), y(n), z(n);
-        for (int64_t i = 0; i < n; ++i) x[i] = 1.0 + 0.61 * std::sin(7.31 * (double)(i + 1));
-        double est = 0.0;
-        for (int it = 0; it < 60; ++it) {
-            for (int64_t i = 0; i < n; ++i) { double sacc = 0.0; for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) sacc += va[e] * x[col[e]]; y[i] = x[i] - sacc; }
-            for (int64_t i = 0; i < n; ++i) z[i] = y[i];
-            for (int64_t i = 0; i < n; ++i) for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) z[col[e]] -= va[e] * y[i];
-            double nx = 0.0, nz = 0.0;
-            for (int64_t i = 0; i < n; ++i) { nx += x[i] * x[i]; nz += z[i] * z[i]; }
-            if (nz == 0.0 || nx == 0.0) break;
-            est = std::sqrt(nz / nx);
-            const double inv = 1.0 / std::sqrt(nz);
-            for (int64_t i = 0; i < n; ++i) x[i] = z[i] * inv;
-        }
-        if (est > 0.0) c = est * 1.05;
-    }
-    H.beta = (float)c;
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess) return fail(GEMHIP_E_HIP, "lle: no HIP device");
     auto up = [&](void **dp, const void *hp, size_t bytes) { HOPE_TRY(H, hipMalloc(dp, std::max<size_t>(bytes, 16))); if (!H.err && bytes) HOPE_TRY(H, hipMemcpy(*dp, hp, bytes, hipMemcpyHostToDevice)); };
     up((void **)&H.rp, row_ptr, (n + 1) * sizeof(int64_t)); up((void **)&H.ci, col, nnz * sizeof(int32_t)); up((void **)&H.va, va.data(), nnz * sizeof(float));
     up((void **)&H.rpT, rpT.data(), (n + 1) * sizeof(int64_t)); up((void **)&H.ciT, ciT.data(), nnz * sizeof(int32_t)); up((void **)&H.vaT, vaT.data(), nnz * sizeof(float));
     if (H.err) return H.err;
+    // c >= sigma_max(I - P)^2: power iteration on N^T N with the one-column SpMM (X2 = [x | z] so that one Gram launch gives both norms),
+    // with a margin
+    double c = 4.0;
+    {
+        std::vector<float> x0((size_t)n * 2, 0.f);
+        for (int64_t i = 0; i < n; ++i) x0[(size_t)i * 2] = (float)(1.0 + 0.61 * std::sin(7.31 * (double)(i + 1)));
+        float *X2 = nullptr, *tv = nullptr;
+        up((void **)&X2, x0.data(), x0.size() * sizeof(float));
+        HOPE_TRY(H, hipMalloc((void **)&tv, (size_t)n * sizeof(float)));
+        double est = 0.0;
+        for (int it = 0; it < 60 && !H.err; ++it) {
+            apply_sym_op(H, 2, 1.0f, X2, 2, 1, tv, 1, X2 + 1, 2, 1.0f, nullptr, 0, 0.f, nullptr, 0);        // z = N^T N x
+            std::vector<double> G2;
+            gram(H, X2, 2, 2, X2, 2, 2, G2);
+            if (H.err) break;
+            const double nx = G2[0], nz = G2[3];
+            if (!(nz > 0.0) || !(nx > 0.0) || !std::isfinite(nz)) break;
+            const double prev = est;
+            est = std::sqrt(nz / nx);
+            hipLaunchKernelGGL(hope_lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, H.s, n, 1, (float)(1.0 / std::sqrt(nz)), X2 + 1, 2, 0.f, X2 + 1, 2,
+                               0.f, X2 + 1, 2, X2, 2);                                                    // x = z / |z|
+            if (it >= 8 && std::fabs(est - prev) <= 1e-4 * est) break;                                     // the 5 % margin covers the rest
+        }
+        HOPE_TRY(H, hipStreamSynchronize(H.s));
+        hipFree(X2); hipFree(tv);
+        if (H.err) return H.err;
+        if (est > 0.0) c = est * 1.05;
+        H.spmm_count = 0; H.spmm_cols = 0;
+    }
+    H.beta = (float)c;
     std::vector<float> sig(k);
     // large graphs: the Chebyshev-filtered eigen-path on N^T N itself (kind 2), which converges where the block-Krylov solver runs out of
     // its restart budget (the bottom of the spectrum is clustered); same switch as HOPE and Laplacian Eigenmaps
