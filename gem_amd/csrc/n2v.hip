@@ -2593,7 +2593,15 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             // 0.1-0.3 % at n/64 (scripts/ab_sgns_window.py, profiles/r02_ab_sgns_window_{16k,32k,100k}.json) -- the tighter bound is for tiny graphs
             const int64_t hog_win = h->max_waves > 0 ? h->max_waves
                                   : h->n >= 8192 ? hog_cap : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
-            waves = std::min<int64_t>(std::min<int64_t>(hog_win, 256 * per_cu), walk_hi - walk_lo);
+            // ... and at the headline size the concurrency itself costs reconstruction quality against the SEQUENTIAL algorithm (same seed, same
+            // walks and negatives as oracle/n2v_oracle.c's 8.4-hour run, SBM 1M/10M, paired over the fixed 1024-node sample):
+            //   wavefronts   384      768      1024     1280     1536 (all that fit)
+            //   MAP vs seq.  -0.04 %  -0.12 %  -0.41 %  -0.75 %  -0.8 .. -1.3 % (three runs)
+            //   seconds      22.5     12.6     11.4     10.2     9.5
+            // north_star's bar is 1 %: the default stops at 1024 (4 per CU); GEMHIP_SGNS_MAX_WAVES / gemhip_n2v_set_max_waves trade it back
+            int64_t quality_cap = h->max_waves > 0 ? (int64_t)h->max_waves : 1024;
+            if (const char *e = getenv("GEMHIP_SGNS_MAX_WAVES")) quality_cap = std::max(1, atoi(e));
+            waves = std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(hog_win, quality_cap), 256 * per_cu), walk_hi - walk_lo);
             if (waves == 1 && mode < 0) delta = false;
         }
         const bool use_oscr = oscr && delta;
