@@ -31,6 +31,8 @@ ap.add_argument('--q', type=float, default=1.0)
 ap.add_argument('--sample', type=int, default=1024)
 ap.add_argument('--tag', default=None)
 ap.add_argument('--workdir', default=None)
+ap.add_argument('--save-emb', default=None, help='write the trained embedding (float32 .npy) here so a later run can re-score a bigger sample')
+ap.add_argument('--load-emb', default=None, help='skip training, score this saved embedding')
 a = ap.parse_args()
 PARAMS = dict(n=a.nodes, edges=a.edges, blocks=a.blocks, seed=a.seed, d=128, walk_len=80, num_walks=10, window=10, p=a.p, q=a.q)
 
@@ -42,7 +44,11 @@ os.makedirs(tmp, exist_ok=True)
 print('graph %d nodes %d directed edges, workdir %s' % (n, g.number_of_edges(), tmp), flush=True)
 
 t = time.time()
-if a.engine == 'snap':
+if a.load_emb:
+    X = np.load(a.load_emb)
+    prev = json.load(open(a.load_emb + '.json'))
+    el, engine = prev['seconds'], prev['engine']
+elif a.engine == 'snap':
     gf = os.path.join(tmp, 'g.graph')
     import pandas as pd
     pd.DataFrame({'s': g.src, 'd': g.dst, 'w': np.ones(len(g.src))}).to_csv(gf, sep=' ', header=False, index=False, float_format='%f')
@@ -68,6 +74,9 @@ else:
     el = time.time() - t
     engine = 'oracle/n2v_oracle.c (sequential restatement of SNAP)'
 print('trained in %.0fs' % el, flush=True)
+if a.save_emb and not a.load_emb:
+    np.save(a.save_emb, X)
+    json.dump({'seconds': el, 'engine': engine, 'params': PARAMS}, open(a.save_emb + '.json', 'w'))
 
 Xd = X.astype(np.float64)
 aps = []

@@ -23,7 +23,11 @@ def test_reference_run_karate_runs_unchanged_up_to_sdne(tmp_path):
     os.makedirs(tmp_path / 'data')
     shutil.copyfile(golden_path('karate.edgelist'), tmp_path / 'data' / 'karate.edgelist')
     shutil.copyfile(golden_path('ref_examples_run_karate.py.txt'), tmp_path / 'run_karate.py')
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''), MPLBACKEND='Agg')
+    # run_karate.py itself stays byte-identical; the run is made repeatable from OUTSIDE it: a sitecustomize.py on PYTHONPATH seeds
+    # numpy's global RNG, which is where GraphFactorization's 0.01*N(0,1) init (gf.py:92) and this backend's node2vec seed come from
+    (tmp_path / 'site').mkdir()
+    (tmp_path / 'site' / 'sitecustomize.py').write_text('import numpy as np\nnp.random.seed(7)\n')
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path / 'site'), ROOT, os.environ.get('PYTHONPATH', '')]), MPLBACKEND='Agg')
     r = subprocess.run([sys.executable, 'run_karate.py', '-node2vec', '1'], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     out = r.stdout
     blocks = re.findall(r'(\w+):\n\tTraining time: ([\d.]+)\n\tMAP: ([\d.eE+-]+) ', out)
@@ -38,7 +42,11 @@ def test_reference_run_karate_runs_unchanged_up_to_sdne(tmp_path):
     # ranking is decided by reconstructed weights of ~1e-7: the reference's golden embedding scores 0.103, a fresh reference run
     # 0.086 (tests/golden/map_ref.json), this backend 0.179 on an embedding that differs from the golden by 1e-7
     assert 0.5 * ref['karate_hope_fresh'] < maps['hope_gsvd'] < 0.3
-    # GF and node2vec are randomly initialised / sampled (the reference's own runs spread by +-0.05): bands around its goldens
-    assert 0.35 < maps['graph_factor_sgd'] < 0.75
+    # GF and node2vec are randomly initialised / sampled.  Bands from the ORACLE's distribution under run_karate.py:47,53's
+    # hyper-parameters over 200 numpy seeds (fp32 gf.cpp semantics / sequential TrainModel): GF MAP 0.484 +- 0.075 (min 0.272, max
+    # 0.608; 7.5 % of seeds fall below 0.35, the band that made round 2's GPU tier red), node2vec 0.494 +- 0.038 (min 0.362, max 0.572).
+    # GF band = mean -4.5 sd / +4 sd, node2vec = mean -5 sd / +4 sd: P(flake) < 1e-4 per assertion even UNSEEDED; with the seed above
+    # both runs are deterministic (exact Gauss-Seidel sweeps; 34 nodes train on a single wavefront) -- oracle at seed 7: GF 0.492
+    assert 0.15 < maps['graph_factor_sgd'] < 0.80
     assert 0.30 < maps['node2vec_rw'] < 0.65
     assert 0.0 < maps['lap_eigmap_svd'] < 1.0 and 0.0 < maps['lle_svd'] < 1.0
