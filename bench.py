@@ -13,7 +13,8 @@ that is already resident in HBM when the timed region starts:
 With no --workload the headline workload (node2vec) is timed first and the other two BASELINE configurations follow in the
 same process -- GF on SBM 10k/100k with examples/run_sbm.py:66's eta/lambda (configs[1]) and on the 1M/10M graph, HOPE on SBM
 100k/1M (configs[2]) -- each with its own timed region, roofline and cpu_baseline under "workloads" of the one JSON line.
-For N>1 launch with torch.distributed.run (one rank per GPU, RCCL).  Both paths shard by SOURCE /
+For N>1 either launch one rank per GPU with torch.distributed.run (what the driver does) or run plain `python bench.py --gpus N`, which
+spawns the N ranks itself; a mismatch between --gpus and WORLD_SIZE, or fewer GPUs than ranks, is an error (never a silent 1-GPU run).  Both paths shard by SOURCE /
 START NODE (gem_amd/multi_gpu.py; node2vec additionally partitions its tables over the ranks): total work is
 fixed => "scaling": "strong".
 
@@ -106,7 +107,7 @@ class GFWorkload(object):
             self.last = self.job.sweep(self.eta, self.regu)
             return
         # one GPU: sweeps are handed to the library in batches of 64, the way GraphFactorization.learn_embedding hands it max_iter of them
-        # (gemhip_gf_plan_sweeps replays a captured hipGraph on launch-bound graphs); every counted sweep runs inside the timed region
+        # (one library call = a plain launch loop: it saves the ctypes overhead per sweep, nothing else); every counted sweep runs inside the timed region
         self.pending = getattr(self, 'pending', 0) + 1
         if self.pending == 64:
             self._flush()
@@ -210,7 +211,7 @@ class N2VWorkload(object):
         if not ph:
             return None
         return {'last_step_seconds': ph, 'note': 'HIP events of the last pass on this rank: training rounds and SynNeg ring shifts are serial on the '
-                'training stream; pair emission + all-to-all run one episode ahead on a side stream (overlapped)'}
+                'training stream; pair emission + size exchange + all-to-all of the next episode run on a side stream that does not wait for the training stream'}
 
     def roofline(self, dev_ms_total, steps):
         torch.cuda.synchronize()
@@ -483,11 +484,27 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- N ranks of this very command under torch.distributed.run, one per GPU
+        # (what the driver's N>1 command does explicitly).  Never fall back to one GPU silently: fewer devices than ranks is an error
+        # unless the gloo test backend was asked for (tests/test_bench_gpu.py runs 2 ranks on the one GPU of the test box).
+        if torch.cuda.device_count() < args.gpus and os.environ.get('GEM_BENCH_BACKEND', 'nccl') == 'nccl':
+            raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible' % (args.gpus, torch.cuda.device_count()))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log('bench.py: spawning %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d '
+                         'bench.py --gpus %d), or run plain `python bench.py --gpus %d` and let it spawn the ranks' % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     local = local % torch.cuda.device_count()      # (lets the N>1 code path be exercised on a 1-GPU box with GEM_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     _hip.check(_hip.lib().gemhip_set_device(local))
@@ -498,8 +515,6 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        log('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world))
 
     comm = multi_gpu.TorchComm(world)
     headline = 'node2vec' if args.workload == 'all' else args.workload

@@ -42,6 +42,9 @@ class TorchComm(object):
             import torch.distributed as dist
             self.dist = dist
 
+    def backend(self):
+        return self.dist.get_backend() if self.world > 1 else 'none'
+
     def all_reduce_sum(self, t):
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
@@ -235,7 +238,8 @@ class HipBackendGF(object):
         return self.X[self.cur]
 
     def sweeps(self, k, eta, regu):
-        """k sweeps in one call (launch-bound graphs replay a captured hipGraph of 16 sweeps)."""
+        """k sweeps in one library call: a plain launch loop (a captured hipGraph of 16 sweeps was measured SLOWER on ROCm 7.2 -- 10.5 vs
+        8.7 us per sweep, DESIGN.md 3.1 -- and is not used); what the batch saves is the Python/ctypes overhead per sweep."""
         s = self.torch.cuda.current_stream().cuda_stream
         _hip.check(self.L.gemhip_gf_plan_sweeps(self.plan, k, eta, regu, C.c_void_p(s)))
         self.cur ^= (k & 1)
@@ -313,12 +317,15 @@ class Node2VecPartitioned(object):
         nloc = self.hi - self.lo
         a, z = shard_range(nloc, e, self.episodes)
         pairs, counts = b.emit_pairs_bucketed(self.window, ep, a, z, self.seed, W)
-        # GEM_N2V_SIDE_GROUP=1: route these look-ahead collectives through a second process group so that they overlap the training rounds
-        # (on the default group torch serialises them behind this episode's ring shifts: correct by construction, ~5-10 % of an episode
-        # at N=8).  Off by default: two RCCL communicators progressing concurrently next to a kernel that fills the GPU is the one
-        # configuration this round could not exercise (no multi-GPU box), and a hang there would cost the whole scaling run.
+        # The look-ahead collectives go through a SECOND process group (its own RCCL communicator and stream) under nccl: on the default
+        # group torch serialises every collective on one internal stream in issue order, so the size exchange -- whose result the HOST
+        # waits for -- would queue behind all W ring shifts of the episode that was just queued, and the host could not queue the next
+        # episode before this one has drained.  Every rank issues the collectives of each group in the same order, which is what two
+        # communicators need to make progress side by side.  GEM_N2V_SIDE_GROUP=0 falls back to the default group (gloo always does:
+        # its collectives run on the host anyway).
         import os
-        side = comm.side_group() if (hasattr(comm, 'side_group') and os.environ.get('GEM_N2V_SIDE_GROUP') == '1') else None
+        want = os.environ.get('GEM_N2V_SIDE_GROUP', '1' if getattr(comm, 'backend', lambda: 'gloo')() == 'nccl' else '0') == '1'
+        side = comm.side_group() if (hasattr(comm, 'side_group') and want) else None
         kw = {'group': side} if side is not None else {}
         cm = comm.all_gather_ints(counts, pairs.device, **kw)        # cm[src][dest * W + wpart]
         send_counts = [sum(counts[r * W:(r + 1) * W]) for r in range(W)]
@@ -348,10 +355,11 @@ class Node2VecPartitioned(object):
         ev = lambda: torch.cuda.Event(enable_timing=True) if cuda else None
         self._ev = {'train': [], 'shift': [], 'prep': []}
 
-        def prepare(ep, e):
+        def prepare(ep, e, first=False):
             if not cuda:
                 return self._prepare(ep, e), None
-            prep.wait_stream(main)                                      # (walks / tables of the first call; a no-op later)
+            if first:
+                prep.wait_stream(main)          # walks, vocabulary and tables are produced on `main`; nothing later on `main` feeds _prepare
             with torch.cuda.stream(prep):
                 e0 = ev(); e0.record()
                 out = self._prepare(ep, e)
@@ -361,7 +369,7 @@ class Node2VecPartitioned(object):
             return out, e1
 
         order = [(ep, e) for ep in range(self.epochs) for e in range(self.episodes)]
-        nxt = prepare(*order[0])
+        nxt = prepare(*order[0], first=True)
         for k, (ep, e) in enumerate(order):
             (mine, seg), ready = nxt
             if ready is not None:
@@ -382,13 +390,17 @@ class Node2VecPartitioned(object):
                 if cuda:
                     t2.record()
                     self._ev['train'].append((t0, t1)); self._ev['shift'].append((t1, t2))
-            # the next episode's pairs are emitted and routed while the rounds queued above run
+            # The rounds above are only QUEUED on `main` (kernel launches and P2P shifts are asynchronous).  The next episode's pairs are
+            # emitted and routed now, on `prep`, which does NOT wait for `main` (round 2 made it wait for every round just queued, so the
+            # host -- which synchronises `prep` inside _prepare to read the bucket sizes -- sat out the whole episode and `main` then idled
+            # through the exchange: no overlap at all).  The host blocks here only for the emit kernels and the size exchange.
             nxt = prepare(*order[k + 1]) if k + 1 < len(order) else None
         return assemble_partitions(P_part, comm, W, self.n)
 
     def phase_seconds(self):
-        """Device seconds of the last run() by phase (HIP events): training rounds, ring shifts of the SynNeg partitions (on the
-        training stream), pair emission + all-to-all (on the side stream, overlapped with training)."""
+        """Device seconds of the last run() by phase (HIP events): training rounds, ring shifts of the SynNeg partitions (both on the
+        training stream), pair emission + size exchange + all-to-all of the NEXT episode (side stream; issued without waiting for the
+        training stream, so it runs next to the rounds -- how much of `prep` is hidden is `train + shift + prep - wall`)."""
         if not getattr(self, '_ev', None) or not self._ev['train']:
             return None
         import torch
