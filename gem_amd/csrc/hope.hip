@@ -1277,6 +1277,9 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
     const double beta = H.beta;
     auto fk = [&](double x) { return kind == 1 ? 1.0 + x : kind == 2 ? beta - x : beta * x / (1.0 - beta * x); };
     const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
+    // the SpMM kernels carry at most 512 block columns (CPL = 8) and the column-norm scratch below holds 512 floats: a wider block must be
+    // refused here exactly as krylov_svd refuses it, not truncated silently
+    GEMHIP_REQUIRE(b <= 512, "hope: k + oversample = %d too large (max 512)", b);
     const int ldv = (b + 31) / 32 * 32;
     const bool debug = getenv("GEMHIP_HOPE_DEBUG") != nullptr;
     double amp = 1e4, amp0 = 1e3;

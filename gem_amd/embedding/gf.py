@@ -14,6 +14,13 @@ RandomState instead of numpy's global RNG); `device_init=True` draws the
 0.01*N(0,1) initial table on the GPU from a Philox stream keyed by `seed` (what
 gf.cpp:41-52 does with its own generator) -- at 1M x 128 numpy's randn alone
 costs more than 100 sweeps.
+
+Edge order.  The sweep kernel reproduces the reference's Gauss-Seidel order exactly with two table copies, which needs every
+row a firing edge READS to have had all or none of its own updates of that sweep at that point of the edge list.  That holds for
+graph.edges() of any networkx graph and for saveGraphToEdgeListTxt files (edges grouped by source) -- every call site of the
+reference -- but not for arbitrary interleaved edge lists, which gf.cpp accepts: libgem_hip.so then returns GEMHIP_E_INVALID
+(raised here as GemHipError) instead of training something else.  `regroup_edges=True` opts into regrouping such a list by source
+(first-appearance order; gem_amd.graph.group_edges_by_source) -- a different visiting order than the reference's for that file.
 """
 import ctypes as C
 
@@ -37,6 +44,9 @@ class GraphFactorization(StaticGraphEmbedding):
         if not graph:
             raise ValueError('graph needed')
         n, src, dst, w, _ = edge_arrays(graph)
+        if getattr(self, '_regroup_edges', False):
+            from gem_amd.graph import group_edges_by_source
+            src, dst, w = group_edges_by_source(src, dst, w)
         d = int(self._d)
         self._node_num = n
         seed = getattr(self, '_seed', None)

@@ -91,3 +91,16 @@ def test_wire_formats_roundtrip(tmp_path, karate):
         fh.write('3 2\n2 0.5 1.5\n0 1 2\n')
     X = graph_util.loadEmbedding(f)
     assert X.shape == (3, 2) and X[2, 1] == 1.5 and X[1, 0] == 0.0
+
+
+def test_group_edges_by_source_is_identity_on_grouped_lists_and_stable_otherwise():
+    """gf.cpp accepts any file order, libgem_hip.so only orders the exact Gauss-Seidel schedule can represent; the opt-in
+    regrouping (GraphFactorization(..., regroup_edges=True)) keeps sources in first-appearance order and every source's edges in
+    their original order."""
+    from gem_amd.graph import group_edges_by_source
+    src = np.array([3, 3, 0, 0, 2], np.int32); dst = np.array([1, 2, 3, 1, 0], np.int32); w = np.arange(5, dtype=np.float32)
+    s, d, ww = group_edges_by_source(src, dst, w)
+    assert s.tolist() == src.tolist() and d.tolist() == dst.tolist() and ww.tolist() == w.tolist()
+    src = np.array([3, 0, 3, 2, 0], np.int32); dst = np.array([1, 3, 2, 0, 1], np.int32)
+    s, d, ww = group_edges_by_source(src, dst, w)
+    assert s.tolist() == [3, 3, 0, 0, 2] and d.tolist() == [1, 2, 3, 1, 0] and ww.tolist() == [0, 2, 1, 4, 3]
