@@ -169,7 +169,6 @@ def ptr(a, ctype):
 N2V_PAD_ZERO, N2V_UNIGRAM_QUIRK, N2V_DETERMINISTIC, N2V_UNIFORM_FIRST_HOP = 1, 2, 4, 8
 N2V_SNAP_COMPAT = 11
 N2V_NO_WINDOW_CACHE = 128       # A/B switch: round-1 SGNS kernel without the LDS window of context rows
-N2V_SHARED_NEGATIVES = 64      # opt-in fast mode, not the reference's sampling (include/gem_hip.h)
 
 
 def as_i32(a):

@@ -88,9 +88,7 @@ struct gemhip_n2v {
     int32_t cache_radius = -1;        // sgns_win_kernel LDS window radius: -1 auto, 0 = off (sgns_kernel)
     int32_t cache_delta = -1;         // -1 auto, 0 overwrite on leave, 1 delta write-back
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
-    float *d_oscr = nullptr; size_t oscr_bytes = 0;     // sgns_win_kernel<OSCR>: as-loaded copies of cached rows
     unsigned long long *d_bcnt = nullptr;               // emit_pairs_bucketed: bucket sizes [64*64] + cursors [64*64]
-    int32_t sgns_duo = 0;             // 1: two-wavefront (trainer + helper) kernel where it applies; 0 (default): single-wavefront window kernel
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
     // per-partition unigram tables (multi-GPU episode schedule): partition p = {v : v % parts == p}, local index v / parts
     int32_t parts = 0;
@@ -273,37 +271,12 @@ __device__ __forceinline__ void st_row(float *p, int d, int lane, int c, const f
     }
 }
 
-// d == 128 WIDE variant (opt-in, flag 32; measured 15 % SLOWER than the 8-byte path on MI355X, kept for A/B): one embedding row is 512 B = 32 lanes x 16 B.  Lanes 0-31 move the row with ONE
-// 16-byte-per-lane sc1 buffer access (the widest, cheapest coherent access: an 8-byte sc1 store costs ~2.7x
-// per byte, MI355X_MICROARCH.md "stores of each flavour"), and two v_permlane32_swap spread it over the 64 lanes
-// as float2: lane l < 32 holds elements (4l, 4l+1), lane 32+l holds (4l+2, 4l+3).
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void ld_row_wide(__amdgpu_buffer_rsrc_t rs, int64_t row, int lane, float (&v)[2])
-{
-    u32x4v t = {0u, 0u, 0u, 0u};
-    if (lane < 32) t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((uint32_t)row * 512u + (uint32_t)lane * 16u), 0, 16 /* sc1 */);
-    const u32x2v a = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
-    const u32x2v b = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
-    v[0] = __builtin_bit_cast(float, a.x);
-    v[1] = __builtin_bit_cast(float, b.x);
-}
-__device__ __forceinline__ void st_row_wide(__amdgpu_buffer_rsrc_t rs, int64_t row, int lane, const float (&v)[2])
-{
-    const u32x2v a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, v[0]), 0u, false, false);
-    const u32x2v b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, v[1]), 0u, false, false);
-    const u32x4v o = {a.x, b.x, a.y, b.y};
-    if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(o, rs, (int)((uint32_t)row * 512u + (uint32_t)lane * 16u), 0, 16 /* sc1 */);
-}
-
 struct SgnsArgs {
     const int32_t *walks; int64_t walk_lo, walk_hi; int32_t walk_len; int32_t window;
     float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
     const float *UT; const int32_t *KT; const uint2 *UK; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
     float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs;
     float *dummy;               // sgns_win_kernel: nwaves rows, never read for their value
-    float *oscr;                // sgns_win_kernel<OSCR>: per wave (2R+2) rows, the as-loaded copies of its cached rows
     unsigned long long *prof;   // GEMHIP_SGNS_PROFILE builds only: per-phase cycle sums (s_memtime)
     int32_t cache_radius;       // sgns_win_kernel: tokens within this many positions of the centre keep their SynPos row in LDS
 };
@@ -334,12 +307,9 @@ __device__ __forceinline__ float sgns_grad_fast(float f, float label, float alph
 // stays in registers across all its contexts; per context the context row and the five
 // negative rows are fetched together (6 coalesced 4d-byte reads in flight), reduced with
 // DPP wave sums, and written back.  Hogwild across wavefronts, exactly sequential inside one.
-template <int VEC, int NV, bool WIDE>
+template <int VEC, int NV>
 __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 {
-    static_assert(!WIDE || (VEC == 2 && NV == 1), "wide path is d == 128 only");
-    __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(A.SynPos, 0, WIDE ? (int)((uint32_t)A.n * 512u) : 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(A.SynNeg, 0, WIDE ? (int)((uint32_t)A.n * 512u) : 0, 0x00020000);
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -386,10 +356,8 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 
             float yp[NV][VEC];                               // SynNeg[word]: positive target of every context of this centre
             float *pp = A.SynNeg + (int64_t)word * d;
-            if constexpr (WIDE) ld_row_wide(rsN, word, lane, yp[0]);
-            else
 #pragma unroll
-                for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
+            for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
 
             for (int a = b; a < 2 * win + 1 - b; ++a) {
                 if (a == win) continue;
@@ -405,17 +373,13 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 
                 float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
                 float *pc = A.SynPos + (int64_t)ctx * d;
-                if constexpr (WIDE) ld_row_wide(rsP, ctx, lane, xc[0]);
-                else
 #pragma unroll
-                    for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
+                for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
 #pragma unroll
                 for (int j = 0; j < SGNS_NEG; ++j) {
                     const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
-                    if constexpr (WIDE) ld_row_wide(rsN, tgt[j], lane, yn[j][0]);
-                    else
 #pragma unroll
-                        for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
+                    for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
                 }
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
@@ -457,23 +421,18 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
                     float *pn = A.SynNeg + (int64_t)tgt[j] * d;
-                    if constexpr (WIDE) st_row_wide(rsN, tgt[j], lane, yn[j][0]);
-                    else
 #pragma unroll
-                        for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+                    for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
                 }
 #pragma unroll
                 for (int c = 0; c < NV; ++c) {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
-                    if constexpr (!WIDE) st_row<VEC>(pc, d, lane, c, xc[c]);
+                    st_row<VEC>(pc, d, lane, c, xc[c]);
                 }
-                if constexpr (WIDE) st_row_wide(rsP, ctx, lane, xc[0]);
             }
-            if constexpr (WIDE) st_row_wide(rsN, word, lane, yp[0]);
-            else
 #pragma unroll
-                for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
+            for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -555,8 +514,8 @@ struct NegSet {
 // With both, the pair loop has a STATIC number of memory operations per pair (skipped targets and exhausted prefetch slots
 // go to a per-wave dummy row instead of branching), which is what lets the compiler keep two pairs' rows in flight with
 // counted s_waitcnt vmcnt(N) instead of draining to vmcnt(0) at every control-flow merge.
-template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC, bool OSCR>      // OSCR: the as-loaded copies of the delta write-back live in a per-wave global scratch
-__global__ __launch_bounds__(64, OSCR ? 3 : 1) void sgns_win_kernel(SgnsArgs A)      // area instead of LDS (half the LDS per wave -> twice the resident wavefronts)
+template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC>
+__global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     constexpr int RW = NV * VEC * WAVE;              // floats per cached row (row padded to the wave's footprint)
@@ -570,8 +529,7 @@ __global__ __launch_bounds__(64, OSCR ? 3 : 1) void sgns_win_kernel(SgnsArgs A) 
     int32_t *tok = lds;
     int32_t *negs = tok + len;                       // [2][nsamp]
     float *rowsL = reinterpret_cast<float *>(lds + ((len + 2 * nsamp + 3) & ~3));
-    float *rowsO = rowsL + (size_t)(S + 1) * RW;     // DELTA && !OSCR only; slot S of rowsL stages a context row that is not cached
-    float *oscr = OSCR ? A.oscr + (size_t)gw * (S + 1) * RW : nullptr;
+    float *rowsO = rowsL + (size_t)(S + 1) * RW;     // DELTA only; slot S of rowsL stages a context row that is not cached
 
     auto lds_ld = [&](const float *row, float (&v)[NV][VEC]) {
 #pragma unroll
@@ -597,10 +555,10 @@ __global__ __launch_bounds__(64, OSCR ? 3 : 1) void sgns_win_kernel(SgnsArgs A) 
 
     float *dummy = A.dummy + (size_t)gw * RW;        // this wave's private sink / source for predicated-off row traffic
     auto o_st = [&](int slot, const float (&v)[NV][VEC]) {            // the row as loaded (delta write-back)
-        if constexpr (OSCR) g_st(oscr + (size_t)slot * RW, v); else lds_st(rowsO + (size_t)slot * RW, v);
+        lds_st(rowsO + (size_t)slot * RW, v);
     };
     auto o_ld = [&](int slot, float (&v)[NV][VEC]) {
-        if constexpr (OSCR) g_ld(oscr + (size_t)slot * RW, v); else lds_ld(rowsO + (size_t)slot * RW, v);
+        lds_ld(rowsO + (size_t)slot * RW, v);
     };
     unsigned long long npairs = 0;
     PROF_DECL;
@@ -734,7 +692,6 @@ __global__ __launch_bounds__(64, OSCR ? 3 : 1) void sgns_win_kernel(SgnsArgs A) 
                     if (refc == 0) {
                         sX = s;
                         if constexpr (DELTA) g_ld(A.SynPos + (int64_t)vX * d, rowG);
-                        if constexpr (DELTA && OSCR) o_ld(s, rowO);          // requested a whole centre before it is needed
                     }
                 }
             }
@@ -935,7 +892,7 @@ __global__ __launch_bounds__(64, OSCR ? 3 : 1) void sgns_win_kernel(SgnsArgs A) 
                 float l[NV][VEC];
                 lds_ld(rowsL + (size_t)sX * RW, l);
                 if constexpr (DELTA) {
-                    if constexpr (!OSCR) o_ld(sX, rowO);
+                    o_ld(sX, rowO);
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
@@ -977,711 +934,20 @@ __global__ __launch_bounds__(64, OSCR ? 3 : 1) void sgns_win_kernel(SgnsArgs A) 
 #endif
 }
 
-// ---- two-wavefront TrainModel (default for window <= 12): a TRAINER and a HELPER wavefront per walk --------------------------
-// sgns_win_kernel spends half of its time between the (centre, context) pairs: per centre it draws 100 negative targets (two
-// dependent table lookups), fetches the centre's SynNeg row, the row that enters the LDS window and the row that leaves it --
-// loads whose latency a single in-order wait counter cannot hide behind the pair pipeline.  Here the two roles are split
-// over the two wavefronts of a 128-thread block:
-//   HELPER  runs up to three centres ahead and prepares one DESCRIPTOR per centre in LDS: context mask (window shrink draw),
-//           the 2*window*5 negative targets, the "special" mask (pairs that need the sequential slow path), the centre's
-//           SynNeg row, the LDS slot of every context row (it owns the window directory: enters rows, schedules the row that
-//           leaves, re-uses slots), the current value of the leaving row (delta write-back), alpha.  It may wait as it likes.
-//   TRAINER runs nothing but pair steps.  Its only loads are the five negative rows per pair, requested two pairs ahead
-//           (across centre boundaries), so every s_waitcnt is a counted vmcnt(N) with N fixed at compile time; its stores
-//           (5 rows per pair, the centre row and the leaving window row per centre) never wait.
-// Same arithmetic, order and Philox draws as sgns_kernel / the oracle; rows another wavefront of the SAME block may have
-// updated in the meantime are detected by the helper (it knows every target of the centres in flight) and re-fetched by the
-// trainer in program order, so a single block (deterministic mode) is exactly TrainModel.
-// LDS mailbox words shared by the two wavefronts of a block: explicit address space 3 so that the volatile accesses stay ds_read/ds_write
-// (a volatile access through a generic pointer becomes a FLAT instruction, which also counts against vmcnt)
-typedef __attribute__((address_space(3))) volatile int32_t n2v_lds_vi32;
-__device__ __forceinline__ int32_t flag_ld(const int32_t *p) { return *(n2v_lds_vi32 *)p; }
-__device__ __forceinline__ void flag_st(int32_t *p, int32_t v) { *(n2v_lds_vi32 *)p = v; }
-
-namespace duo {
-constexpr int KR = 5;        // descriptor ring entries
-constexpr int LEAD = 3;      // the helper produces centre h once the trainer has finished centre h - LEAD - 1
-constexpr int HDR = 16;      // header ints: mask_lo, mask_hi, word, spec, yp_stale, flush_slot, flush_node, alpha
-constexpr int NSMAX = 128;   // negative targets per centre (2 * window * 5 <= 128)
-constexpr int CTXMAX = 32;   // context positions per centre (2 * window + 1 <= 32)
-constexpr int DINTS = HDR + NSMAX + CTXMAX;
-__host__ __device__ inline int slots(int R) { return 2 * R + 1 + LEAD + 2; }
-__host__ __device__ inline size_t lds_ints(int len, int R, int rw, bool delta)
-{
-    const int lenp = (len + 3) & ~3;
-    return (size_t)2 * lenp + 8 + 64 + (size_t)KR * (DINTS + 2 * rw) + (size_t)slots(R) * rw * (delta ? 2 : 1);
-}
-}  // namespace duo
-
-template <int VEC, int NV, bool DELTA, bool FULL>
-__global__ __launch_bounds__(128) void sgns_duo_kernel(SgnsArgs A)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    constexpr int RW = NV * VEC * WAVE;
-    constexpr int NS = 2;
-    const int lane = lane_id();
-    const bool helper = (threadIdx.x >> 6) != 0;
-    const int64_t gw = blockIdx.x;
-    const int d = A.d, win = A.window, len = A.walk_len, R = win, S = duo::slots(R);
-    const int lenp = (len + 3) & ~3;
-    const int nsamp = 2 * win * SGNS_NEG;
-    const bool quirk = (A.flags & 2) != 0;
-    int32_t *tok = lds;
-    int32_t *slotpos = tok + lenp;                    // LDS slot of the SynPos row of token q
-    int32_t *flags = slotpos + lenp;                  // [0] centres produced by the helper, [1] centres finished by the trainer (flag_ld / flag_st only)
-    int32_t *livenode = flags + 8;         // [S]: node whose row still sits in slot s when the walk ends (-1: none)
-    int32_t *desc = livenode + 64;
-    float *rowsL = reinterpret_cast<float *>(desc + duo::KR * (duo::DINTS + 2 * RW));
-    float *rowsO = rowsL + (size_t)S * RW;            // DELTA only
-    auto dsc = [&](int p) { return desc + (p % duo::KR) * (duo::DINTS + 2 * RW); };
-    auto dsc_yp = [&](int p) { return reinterpret_cast<float *>(dsc(p) + duo::DINTS); };
-    auto dsc_g = [&](int p) { return reinterpret_cast<float *>(dsc(p) + duo::DINTS) + RW; };
-
-    auto lds_ld = [&](const float *row, float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) v[c][k] = row[(c * WAVE + lane) * VEC + k];
-    };
-    auto lds_st = [&](float *row, const float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) row[(c * WAVE + lane) * VEC + k] = v[c][k];
-    };
-    const int dg = FULL ? NV * VEC * WAVE : d;
-    auto g_ld = [&](const float *p, float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c) ld_row<VEC>(p, dg, lane, c, v[c]);
-    };
-    auto g_st = [&](float *p, const float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c) st_row<VEC>(p, dg, lane, c, v[c]);
-    };
-    float *dummy = A.dummy + (size_t)gw * RW;
-    unsigned long long npairs = 0;
-    PROF_DECL;
-    PROF_START();
-
-    for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
-        __syncthreads();                                 // both wavefronts are done with the previous walk
-        if (helper) {
-            const int32_t *walk = A.walks + wl * len;
-            for (int k = lane; k < len; k += WAVE) tok[k] = walk[k];
-            if (lane < 2) flag_st(flags + lane, 0);
-        }
-        __syncthreads();
-        const int64_t wid = A.walk_id_offset + wl;
-        const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
-
-        if (helper) {
-            // ================================================================ HELPER
-            int32_t slot_node = -1, slot_ref = 0, slot_fq = -1000;      // lane s < S describes window slot s
-            int32_t XA[NS]; float uA[NS];
-            auto stage_a = [&](int p) {                  // RndUnigramInt, first half: table slot (-> X through KT when the binary's quirk is mirrored)
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {           // straight-line (lanes past the last sample draw too): every load is unconditional
-                    const int s = lane + k * WAVE;
-                    const int ai = s / SGNS_NEG;
-                    const int a = ai < win ? ai : ai + 1;
-                    const int j = s - ai * SGNS_NEG + 1;
-                    const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p | ((uint32_t)a << 16),
-                                                   (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
-                    const uint32_t slot = mulhi_range(rn.x, A.n);
-                    const int32_t viaK = A.KT[slot];
-                    XA[k] = quirk ? viaK : (int32_t)slot;
-                    uA[k] = u01(rn.y);
-                }
-            };
-            // enter token q: share the slot of an equal node, else claim a slot the trainer is surely done with and request the row;
-            // returns the claimed slot (-1: nothing to write), enter_end stores the row in the window
-            float rowE[NV][VEC];
-            auto enter_begin = [&](int q) -> int {
-                const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
-                const unsigned long long hit = v >= 0 ? __builtin_amdgcn_ballot_w64(slot_node == v) : 0ull;
-                const bool miss = v >= 0 && !hit;
-                unsigned long long free_m = 1;
-                while (miss) {                            // a slot is reusable once the centre that flushed it and one more are finished
-                    const int done = flag_ld(flags + 1);
-                    free_m = __builtin_amdgcn_ballot_w64(lane < S && slot_ref == 0 && slot_fq <= done - 2);
-                    if (free_m) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                const int s = hit ? (int)__builtin_ctzll(hit) : (int)__builtin_ctzll(free_m);
-                g_ld(miss ? A.SynPos + (int64_t)v * d : dummy, rowE);        // unconditional (scratch row when there is nothing to fetch)
-                if (lane == s && hit) ++slot_ref;
-                if (lane == s && miss) { slot_node = v; slot_ref = 1; }
-                if (lane == 0) slotpos[q] = v >= 0 ? s : 0;
-                return miss ? s : -1;
-            };
-            auto enter_end = [&](int s) {
-                if (s < 0) return;
-                lds_st(rowsL + (size_t)s * RW, rowE);
-                if constexpr (DELTA) lds_st(rowsO + (size_t)s * RW, rowE);
-            };
-            auto enter = [&](int q) { enter_end(enter_begin(q)); };
-            for (int q = 0; q < R && q < len; ++q) enter(q);
-            stage_a(0);
-            int32_t prev_word = -1;                      // centre h-1
-            unsigned long long prev_mask = 0;
-
-            for (int h = 0; h < len; ++h) {
-                while (flag_ld(flags + 1) < h - duo::LEAD) __builtin_amdgcn_s_sleep(2);
-                int32_t *D = dsc(h);
-                const int32_t word = __builtin_amdgcn_readfirstlane(tok[h]);
-                // loads first: second half of RndUnigramInt for centre h, first half for centre h+1, the centre's SynNeg row
-                int32_t XB[NS], KTv[NS]; float uB[NS], UTv[NS];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) { XB[k] = XA[k]; uB[k] = uA[k]; UTv[k] = A.UT[XB[k]]; KTv[k] = A.KT[XB[k]]; }
-                stage_a(h + 1);
-                float ypr[NV][VEC];
-                g_ld(word >= 0 ? A.SynNeg + (int64_t)word * d : dummy, ypr);
-                const int sE = h + R < len ? enter_begin(h + R) : -1;      // row requested now, stored in the window at the end
-                // the token that leaves after this centre: the trainer writes its row back when it was the last holder
-                int32_t fslot = -1, fnode = -1;
-                if (h - R >= 0) {
-                    const int32_t vx = __builtin_amdgcn_readfirstlane(tok[h - R]);
-                    if (vx >= 0) {
-                        const int s = __builtin_amdgcn_readfirstlane(slotpos[h - R]);
-                        const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
-                        if (lane == s) { slot_ref = refc; if (refc == 0) slot_fq = h; }
-                        if (refc == 0) { fslot = s; fnode = vx; }
-                    }
-                }
-                float gr[NV][VEC];
-                if constexpr (DELTA) g_ld(fnode >= 0 ? A.SynPos + (int64_t)fnode * d : dummy, gr);
-                // contexts of this centre (TrainModel's window shrink), their LDS slots
-                unsigned long long mask = 0;
-                if (word >= 0) {
-                    const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)h, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
-                    const int b = (int)(rw.x % (uint32_t)win);
-                    bool valid = false;
-                    const int a = lane, cp = h - win + a;
-                    if (a >= b && a < 2 * win + 1 - b && a != win && cp >= 0 && cp < len) valid = tok[cp] >= 0;
-                    mask = __builtin_amdgcn_ballot_w64(valid);
-                }
-                if (lane <= 2 * win) { const int cp = h - win + lane; D[duo::HDR + duo::NSMAX + lane] = (cp >= 0 && cp < len) ? slotpos[cp] : 0; }
-                // negative targets
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const int s = lane + k * WAVE;
-                    if (s < nsamp) D[duo::HDR + s] = (uB[k] < UTv[k]) ? XB[k] : KTv[k];
-                }
-                // "special" slots: a target equals this or the previous centre's word, is drawn twice, or recurs in one of the two
-                // pairs trained before it (the previous two slots; for the first two slots, the last two pairs of the previous centre)
-                uint32_t spec = 0;
-                bool stale = false;
-                {
-                    const int32_t *ng = D + duo::HDR;
-                    bool sp = false;
-                    int32_t t[SGNS_NEG];
-                    if (lane < 2 * win) {
-#pragma unroll
-                        for (int j = 0; j < SGNS_NEG; ++j) { t[j] = ng[lane * SGNS_NEG + j]; sp = sp || t[j] == word || t[j] == prev_word; }
-#pragma unroll
-                        for (int j = 0; j < SGNS_NEG; ++j)
-#pragma unroll
-                            for (int jp = 0; jp < j; ++jp) sp = sp || t[j] == t[jp];
-#pragma unroll
-                        for (int k = 0; k < 2 * SGNS_NEG; ++k) {
-                            const int idx = (lane - 2) * SGNS_NEG + k;
-                            const int32_t u = ng[idx >= 0 ? idx : 0];
-#pragma unroll
-                            for (int j = 0; j < SGNS_NEG; ++j) sp = sp || (idx >= 0 && t[j] == u);
-                        }
-                    }
-                    // the last two pairs of the previous centre
-                    if (h > 0 && prev_mask) {
-                        const int32_t *pg = dsc(h - 1) + duo::HDR;
-                        unsigned long long pm = prev_mask;
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            if (!pm) break;
-                            const int a = 63 - (int)__builtin_clzll(pm);
-                            pm &= ~(1ull << a);
-                            const int ai = a < win ? a : a - 1;
-#pragma unroll
-                            for (int j = 0; j < SGNS_NEG; ++j) {
-                                const int32_t u = pg[ai * SGNS_NEG + j];
-                                if (lane < 2 * win)
-#pragma unroll
-                                    for (int jj = 0; jj < SGNS_NEG; ++jj) sp = sp || t[jj] == u;
-                            }
-                        }
-                    }
-                    spec = (uint32_t)__builtin_amdgcn_ballot_w64(sp);
-                    {   // slots in flight are ai-1, ai-2 only if the valid contexts are contiguous (always, but for padded walks)
-                        const unsigned long long lowm = (1ull << win) - 1ull;
-                        const unsigned long long mai = (mask & lowm) | ((mask >> (win + 1)) << win);
-                        const unsigned long long sh = mai ? (mai >> __builtin_ctzll(mai)) : 0ull;
-                        if (sh & (sh + 1ull)) spec = 0xFFFFFFFFu;
-                    }
-                    // is the SynNeg row fetched above possibly older than an update the trainer has not finished storing?  It is if
-                    // the word is a target or the centre word of one of the (up to LEAD + 1) centres before this one.
-                    bool st = false;
-                    for (int back = 1; back <= duo::LEAD + 1 && back <= h; ++back) {
-                        const int32_t *pg = dsc(h - back);
-                        st = st || pg[2] == word;
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) { const int s = lane + k * WAVE; st = st || (s < nsamp && pg[duo::HDR + s] == word); }
-                    }
-                    stale = __builtin_amdgcn_ballot_w64(st) != 0;
-                }
-                lds_st(dsc_yp(h), ypr);
-                if constexpr (DELTA) lds_st(dsc_g(h), gr);
-                enter_end(sE);
-                if (lane == 0) {
-                    const int64_t t = A.token_offset + wl * len + h;
-                    const int64_t tq = t - (t % 10000);
-                    float alpha = A.alpha0 * (1.0f - (float)((double)tq / (double)A.denom));
-                    alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
-                    D[0] = (int32_t)(uint32_t)mask; D[1] = (int32_t)(uint32_t)(mask >> 32); D[2] = word; D[3] = (int32_t)spec;
-                    D[4] = stale ? 1 : 0; D[5] = fslot; D[6] = fnode; D[7] = __builtin_bit_cast(int32_t, alpha);
-                }
-                prev_word = word; prev_mask = mask;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) flag_st(flags, h + 1);
-            }
-            // rows still in the window when the walk ends
-            if (lane < 64) livenode[lane] = (lane < S && slot_ref > 0) ? slot_node : -1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) flag_st(flags, len + 1);
-        } else {
-            // ================================================================ TRAINER
-            int p = 0;
-            unsigned long long m_proc = 0, m_iss = 0, m_issn = 0;
-            int32_t word = -1; uint32_t spec = 0; float alpha = 0.f; bool had_pairs = false;
-            int32_t Tc[SGNS_NEG], Tn[SGNS_NEG], ctxslotv = 0;
-            float yp[NV][VEC];
-#pragma unroll
-            for (int j = 0; j < SGNS_NEG; ++j) { Tc[j] = -1; Tn[j] = -1; }
-
-            // per-centre state of centre p out of its descriptor (and the targets of centre p+1 for the prefetch across the boundary)
-            auto load_centre = [&](bool first) __attribute__((always_inline)) {
-                const int need = p + 2 < len ? p + 2 : len;
-                PROF_LAP(0);
-                while (flag_ld(flags) < need) __builtin_amdgcn_s_sleep(1);
-                PROF_LAP(5);                                // waiting for the helper
-                asm volatile("" ::: "memory");          // LDS operations of one wavefront execute in order: a compiler barrier is all the acquire needs
-                const int32_t *D = dsc(p);
-                const unsigned long long mask = (unsigned long long)(uint32_t)D[0] | ((unsigned long long)(uint32_t)D[1] << 32);
-                word = __builtin_amdgcn_readfirstlane(D[2]);
-                spec = (uint32_t)__builtin_amdgcn_readfirstlane(D[3]);
-                const int stale = __builtin_amdgcn_readfirstlane(D[4]);
-                alpha = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(D[7]));
-                m_proc = __builtin_amdgcn_readfirstlane((uint32_t)mask) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(mask >> 32)) << 32);
-                if (first) {
-                    m_iss = m_proc;
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) Tc[j] = D[duo::HDR + (lane < 2 * win ? lane : 0) * SGNS_NEG + j];
-                } else {
-                    m_iss = m_issn;
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) Tc[j] = Tn[j];
-                }
-                ctxslotv = D[duo::HDR + duo::NSMAX + (lane < duo::CTXMAX ? lane : 0)];
-                if (stale && word >= 0) {                 // rare: re-fetch after this wavefront's own stores (program order); staged through LDS
-                    float t[NV][VEC];                     // so that the wait for it stays inside this branch
-                    g_ld(A.SynNeg + (int64_t)word * d, t);
-                    lds_st(dsc_yp(p), t);
-                }
-                lds_ld(dsc_yp(p), yp);
-                if (p + 1 < len) {
-                    const int32_t *Dn = dsc(p + 1);
-                    const unsigned long long mn = (unsigned long long)(uint32_t)Dn[0] | ((unsigned long long)(uint32_t)Dn[1] << 32);
-                    m_issn = __builtin_amdgcn_readfirstlane((uint32_t)mn) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(mn >> 32)) << 32);
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) Tn[j] = Dn[duo::HDR + (lane < 2 * win ? lane : 0) * SGNS_NEG + j];
-                } else m_issn = 0;
-                had_pairs = m_proc != 0;
-                PROF_LAP(6);                                    // per-centre state out of the descriptor
-                npairs += (unsigned long long)__builtin_popcountll(m_proc);
-            };
-            // finish centre p (stores only), then move to the next one; false when the walk is over
-            auto advance = [&]() __attribute__((always_inline)) -> bool {
-                PROF_LAP(0);
-                g_st(word >= 0 && had_pairs ? A.SynNeg + (int64_t)word * d : dummy, yp);     // a centre without contexts leaves its row alone
-                {
-                    const int32_t *D = dsc(p);
-                    const int fs = __builtin_amdgcn_readfirstlane(D[5]);
-                    const int32_t fn = __builtin_amdgcn_readfirstlane(D[6]);
-                    float l[NV][VEC];
-                    lds_ld(rowsL + (size_t)(fs >= 0 ? fs : 0) * RW, l);
-                    if constexpr (DELTA) {
-                        float o[NV][VEC], g[NV][VEC];
-                        lds_ld(rowsO + (size_t)(fs >= 0 ? fs : 0) * RW, o);
-                        lds_ld(dsc_g(p), g);
-                        if (fs >= 0) lds_st(rowsO + (size_t)fs * RW, l);            // the slot may live on (a returning node): next delta is against this value
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) l[c][k] = g[c][k] + (l[c][k] - o[c][k]);
-                    }
-                    g_st(fs >= 0 ? A.SynPos + (int64_t)fn * d : dummy, l);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) flag_st(flags + 1, p + 1);
-                PROF_LAP(7);                                    // end of a centre: its row and the leaving window row written back
-                ++p;
-                if (p >= len) return false;
-                load_centre(false);
-                return true;
-            };
-            load_centre(true);
-
-            // a prefetch set: byte offsets of its five SynNeg rows (32-bit: the launcher takes this kernel only for tables < 4 GB) and the rows
-            struct PSet { uint32_t off[SGNS_NEG]; float y[SGNS_NEG][NV][VEC]; };
-            PSet q0, q1, q2;
-            const uint32_t rowb = (uint32_t)(FULL ? NV * VEC * WAVE : d) * 4u;
-            const char *negb = reinterpret_cast<const char *>(A.SynNeg);
-            auto row_ld = [&](uint32_t off, float (&v)[NV][VEC]) { g_ld(reinterpret_cast<const float *>(negb + off), v); };
-            auto row_st = [&](uint32_t off, const float (&v)[NV][VEC]) { g_st(reinterpret_cast<float *>(const_cast<char *>(negb) + off), v); };
-            auto issue = [&](PSet &Q) __attribute__((always_inline)) {
-                const bool cur = m_iss != 0, live = cur || m_issn != 0;
-                const unsigned long long mm = cur ? m_iss : m_issn;
-                const int a = live ? (int)__builtin_ctzll(mm) : 0;
-                const unsigned long long cl = mm & (mm - 1);
-                m_iss = cur ? cl : m_iss;
-                m_issn = cur ? m_issn : cl;
-                const int ai = a < win ? a : a - 1;
-#pragma unroll
-                for (int j = 0; j < SGNS_NEG; ++j) {
-                    const int32_t tsel = cur ? Tc[j] : Tn[j];
-                    const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane(tsel, ai);
-                    Q.off[j] = (live ? tg : 0u) * rowb;        // exhausted: the same five loads, of row 0 (never trained on)
-                    row_ld(Q.off[j], Q.y[j]);
-                }
-            };
-            issue(q0);
-            issue(q1);
-
-            auto step = [&](PSet &C, PSet &P2) __attribute__((always_inline)) {
-                PROF_LAP(0);
-                const int a = (int)__builtin_ctzll(m_proc);
-                m_proc &= m_proc - 1;
-                issue(P2);
-                PROF_LAP(1);
-                const int cslot = __builtin_amdgcn_readlane(ctxslotv, a);
-                float *lrow = rowsL + (size_t)cslot * RW;
-                float xc[NV][VEC], neu[NV][VEC];
-                lds_ld(lrow, xc);
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) neu[c][k] = 0.f;
-                const int ai_c = a < win ? a : a - 1;
-                PROF_LAP(2);
-                PROF_WAIT_VM(10);
-                PROF_LAP(3);
-                if (!((spec >> ai_c) & 1u)) {
-                    // fast path: the six targets are distinct rows and none is the centre word -> six independent updates
-                    float part[6];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) part[j] = 0.f;
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) {
-                            part[0] = fmaf(xc[c][k], yp[c][k], part[0]);
-#pragma unroll
-                            for (int j = 0; j < SGNS_NEG; ++j) part[j + 1] = fmaf(xc[c][k], C.y[j][c][k], part[j + 1]);
-                        }
-                    const float f = wave_sum6(part, lane);
-                    const float gl = sgns_grad_fast(f, (lane & 7) == 0 ? 1.0f : 0.0f, alpha);     // lanes 0..5: g of target 0..5
-                    float g[6];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) g[j] = bcast_lane(gl, j);
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) {
-                            neu[c][k] = fmaf(g[0], yp[c][k], neu[c][k]);
-                            yp[c][k] = fmaf(g[0], xc[c][k], yp[c][k]);
-                        }
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) {
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) {
-                                neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
-                                C.y[j][c][k] = fmaf(g[j + 1], xc[c][k], C.y[j][c][k]);
-                            }
-                        row_st(C.off[j], C.y[j]);
-                    }
-                } else {
-                    // slow path (exact sequential semantics): the rows may have been requested before an update of the same row
-                    // (by one of the two previous pairs, or the previous centre's own row) was stored -- fetch them again; then the six
-                    // targets one at a time (t = 0: the centre word, label 1), each on the rows as the earlier ones left them
-                    const uint32_t woff = (uint32_t)word * rowb;
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) row_ld(C.off[j], C.y[j]);
-#pragma nounroll
-                    for (int t = 0; t < 6; ++t) {
-#pragma unroll
-                        for (int j = 1; j < SGNS_NEG; ++j)                       // a target drawn twice sees the first update
-#pragma unroll
-                            for (int jp = 0; jp < j; ++jp)
-                                if (C.off[jp] == C.off[j] && t == j + 1) {
-#pragma unroll
-                                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                        for (int k = 0; k < VEC; ++k) C.y[j][c][k] = C.y[jp][c][k];
-                                }
-                        float part[6];
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) part[j] = 0.f;
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) {
-                                part[0] = fmaf(xc[c][k], yp[c][k], part[0]);
-#pragma unroll
-                                for (int j = 0; j < SGNS_NEG; ++j) part[j + 1] = fmaf(xc[c][k], C.y[j][c][k], part[j + 1]);
-                            }
-                        const float f = wave_sum6(part, lane);
-                        const float gl = sgns_grad_fast(f, (lane & 7) == 0 ? 1.0f : 0.0f, alpha);
-                        float g[6];
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            g[j] = bcast_lane(gl, j);
-                            const bool skip = j > 0 && C.off[j > 0 ? j - 1 : 0] == woff;     // TrainModel: `if (Target == Word) continue`
-                            g[j] = (j == t && !skip) ? g[j] : 0.f;
-                        }
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) {
-                                neu[c][k] = fmaf(g[0], yp[c][k], neu[c][k]);
-                                yp[c][k] = fmaf(g[0], xc[c][k], yp[c][k]);
-#pragma unroll
-                                for (int j = 0; j < SGNS_NEG; ++j) {
-                                    neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
-                                    C.y[j][c][k] = fmaf(g[j + 1], xc[c][k], C.y[j][c][k]);
-                                }
-                            }
-                    }
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) {
-                        // a row equal to the centre word is not written (its registers hold a stale copy of yp's row); of a repeated target only
-                        // the last copy is current -- earlier copies go to the scratch row
-                        bool dead = C.off[j] == woff;
-#pragma unroll
-                        for (int jn = j + 1; jn < SGNS_NEG; ++jn) dead = dead || C.off[jn] == C.off[j];
-                        if (dead) g_st(dummy, C.y[j]); else row_st(C.off[j], C.y[j]);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) xc[c][k] += neu[c][k];
-                lds_st(lrow, xc);
-                PROF_LAP(4);
-            };
-            bool more = true;
-            while (true) {
-                while (more && !m_proc) more = advance();
-                if (!more) break;
-                step(q0, q2);
-                while (more && !m_proc) more = advance();
-                if (!more) break;
-                step(q1, q0);
-                while (more && !m_proc) more = advance();
-                if (!more) break;
-                step(q2, q1);
-            }
-            {   // prefetch slots filled past the last pair are dead: retire their loads for the compiler's wait-count bookkeeping
-                auto retire = [&](PSet &Q) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j)
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(Q.y[j][c][k]));
-                };
-                retire(q0); retire(q1); retire(q2);
-            }
-            // rows still in the window: written back as they are (delta mode: against their current value)
-            while (flag_ld(flags) < len + 1) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            for (int s = 0; s < S; ++s) {
-                const int32_t v = __builtin_amdgcn_readfirstlane(livenode[s]);
-                if (v < 0) continue;
-                float l[NV][VEC];
-                lds_ld(rowsL + (size_t)s * RW, l);
-                if constexpr (DELTA) {
-                    float o[NV][VEC], g[NV][VEC];
-                    lds_ld(rowsO + (size_t)s * RW, o);
-                    g_ld(A.SynPos + (int64_t)v * d, g);
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) l[c][k] = g[c][k] + (l[c][k] - o[c][k]);
-                }
-                g_st(A.SynPos + (int64_t)v * d, l);
-            }
-            // the helper of the next walk reads rows this wavefront has just stored: let the stores land first
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    if (!helper) {
-        PROF_LAP(0);
-        if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
-#ifdef GEMHIP_SGNS_PROFILE
-        if (lane == 0 && A.prof) for (int k = 0; k < 8; ++k) atomicAdd(A.prof + k, prof_acc[k]);
-#endif
-    }
-}
-
-template <int VEC, int NV, bool DELTA>
-void launch_sgns_duo(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
-{
-    if (A.d == NV * VEC * WAVE) hipLaunchKernelGGL((sgns_duo_kernel<VEC, NV, DELTA, true>), dim3(blocks), dim3(threads), lds, s, A);
-    else hipLaunchKernelGGL((sgns_duo_kernel<VEC, NV, DELTA, false>), dim3(blocks), dim3(threads), lds, s, A);
-}
-
-// OPT-IN variant (flag GEMHIP_N2V_SHARED_NEGATIVES): the five negative targets are drawn ONCE PER CENTRE WORD and shared
-// by all of its contexts, so their rows stay in registers next to the positive row (per centre: 2*(1+5) + 2*contexts
-// row transfers instead of 2 + 12*contexts).  This is NOT the reference's sampling (TrainModel draws fresh negatives
-// for every (centre, context) pair); it is the usual GPU word2vec trade and is validated on MAP only.
-template <int VEC, int NV>
-__global__ __launch_bounds__(256) void sgns_shared_kernel(SgnsArgs A)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
-    int32_t *tok = lds + wave * (A.walk_len + 2 * A.window * SGNS_NEG);
-    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (gw >= A.nwaves) return;
-    const int d = A.d, win = A.window;
-    const bool quirk = (A.flags & 2) != 0;
-    unsigned long long npairs = 0;
-    for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
-        const int32_t *walk = A.walks + wl * A.walk_len;
-        for (int k = lane; k < A.walk_len; k += WAVE) tok[k] = walk[k];
-        __builtin_amdgcn_wave_barrier();
-        const int64_t wid = A.walk_id_offset + wl;
-        const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
-        for (int pos = 0; pos < A.walk_len; ++pos) {
-            const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
-            if (word < 0) continue;
-            const int64_t t = A.token_offset + wl * A.walk_len + pos;
-            const int64_t tq = t - (t % 10000);
-            float alpha = A.alpha0 * (1.0f - (float)((double)tq / (double)A.denom));
-            alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
-            const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
-            const int b = (int)(rw.x % (uint32_t)win);
-            int32_t mine = -1;
-            if (lane >= 1 && lane <= SGNS_NEG) {
-                const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)lane << 16));
-                const uint32_t slot = mulhi_range(rn.x, A.n);
-                const int32_t X = quirk ? A.KT[slot] : (int32_t)slot;
-                mine = (u01(rn.y) < A.UT[X]) ? X : A.KT[X];
-            }
-            int32_t tgt[SGNS_NEG]; bool use[SGNS_NEG];
-#pragma unroll
-            for (int j = 0; j < SGNS_NEG; ++j) {
-                tgt[j] = __builtin_amdgcn_readlane(mine, j + 1);
-                use[j] = tgt[j] != word;
-#pragma unroll
-                for (int jp = 0; jp < j; ++jp) use[j] = use[j] && tgt[jp] != tgt[j];     // a repeated draw counts once
-            }
-            float yp[NV][VEC], yn[SGNS_NEG][NV][VEC];
-            float *pp = A.SynNeg + (int64_t)word * d;
-#pragma unroll
-            for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
-#pragma unroll
-            for (int j = 0; j < SGNS_NEG; ++j) {
-                const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
-#pragma unroll
-                for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
-            }
-            for (int a = b; a < 2 * win + 1 - b; ++a) {
-                if (a == win) continue;
-                const int cp = pos - win + a;
-                if (cp < 0 || cp >= A.walk_len) continue;
-                const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[cp]);
-                if (ctx < 0) continue;
-                ++npairs;
-                float xc[NV][VEC], neu[NV][VEC];
-                float *pc = A.SynPos + (int64_t)ctx * d;
-#pragma unroll
-                for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) neu[c][v] = 0.f;
-                {
-                    float part = 0.f;
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yp[c][v], part);
-                    const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yp[c][v], neu[c][v]); yp[c][v] = fmaf(g, xc[c][v], yp[c][v]); }
-                }
-#pragma unroll
-                for (int j = 0; j < SGNS_NEG; ++j) {
-                    if (!use[j]) continue;
-                    float part = 0.f;
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yn[j][c][v], part);
-                    const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
-                }
-#pragma unroll
-                for (int c = 0; c < NV; ++c) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
-                    st_row<VEC>(pc, d, lane, c, xc[c]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < SGNS_NEG; ++j)
-                if (use[j]) {
-                    float *pn = A.SynNeg + (int64_t)tgt[j] * d;
-#pragma unroll
-                    for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
-                }
-#pragma unroll
-            for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
-}
-
-template <int VEC, int NV>
-void launch_sgns_shared(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
-{
-    hipLaunchKernelGGL((sgns_shared_kernel<VEC, NV>), dim3(blocks), dim3(threads), lds, s, A);
-}
-
 using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
-template <int VEC, int NV, bool WIDE = false>
+template <int VEC, int NV>
 void launch_sgns(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
 {
-    hipLaunchKernelGGL((sgns_kernel<VEC, NV, WIDE>), dim3(blocks), dim3(threads), lds, s, A);
+    hipLaunchKernelGGL((sgns_kernel<VEC, NV>), dim3(blocks), dim3(threads), lds, s, A);
 }
 template <int VEC, int NV, bool DELTA>
 void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
 {
     const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window;
-    if constexpr (DELTA) {
-        if (full && allc && A.oscr) { hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, true, true, true, true>), dim3(blocks), dim3(threads), lds, s, A); return; }
-    }
-    if (full && allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true, false>), dim3(blocks), dim3(threads), lds, s, A);
-    else if (full) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, false, false>), dim3(blocks), dim3(threads), lds, s, A);
-    else if (allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, true, false>), dim3(blocks), dim3(threads), lds, s, A);
-    else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, false, false>), dim3(blocks), dim3(threads), lds, s, A);
+    if (full && allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true>), dim3(blocks), dim3(threads), lds, s, A);
+    else if (full) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, false>), dim3(blocks), dim3(threads), lds, s, A);
+    else if (allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, true>), dim3(blocks), dim3(threads), lds, s, A);
+    else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, false>), dim3(blocks), dim3(threads), lds, s, A);
 }
 template <bool DELTA>
 sgns_fn pick_sgns_win(int d)
@@ -1693,26 +959,11 @@ sgns_fn pick_sgns_win(int d)
     const int nv = (d + 63) / 64;
     return nv <= 1 ? launch_sgns_win<1, 1, DELTA> : nv <= 2 ? launch_sgns_win<1, 2, DELTA> : nv <= 4 ? launch_sgns_win<1, 4, DELTA> : nullptr;
 }
-template <bool DELTA>
-sgns_fn pick_sgns_duo(int d)
-{
-    if (d % 2 == 0) {
-        const int nv = (d + 127) / 128;
-        return nv <= 1 ? launch_sgns_duo<2, 1, DELTA> : nv <= 2 ? launch_sgns_duo<2, 2, DELTA> : nullptr;
-    }
-    const int nv = (d + 63) / 64;
-    return nv <= 1 ? launch_sgns_duo<1, 1, DELTA> : nv <= 2 ? launch_sgns_duo<1, 2, DELTA> : nullptr;
-}
 // floats one cached row occupies in LDS (the wave's footprint of a row, see sgns_win_kernel)
 int sgns_win_row_floats(int d) { return d % 2 == 0 ? ((d + 127) / 128) * 128 : ((d + 63) / 64) * 64; }
 
-sgns_fn pick_sgns(int d, int64_t n = 0, bool allow_wide = false, bool shared = false)
+sgns_fn pick_sgns(int d)
 {
-    if (shared) {
-        if (d % 2 == 0) { const int nv = (d + 127) / 128; return nv <= 1 ? launch_sgns_shared<2, 1> : nv <= 2 ? launch_sgns_shared<2, 2> : nv <= 4 ? launch_sgns_shared<2, 4> : nullptr; }
-        const int nv = (d + 63) / 64; return nv <= 1 ? launch_sgns_shared<1, 1> : nv <= 2 ? launch_sgns_shared<1, 2> : nv <= 4 ? launch_sgns_shared<1, 4> : nullptr;
-    }
-    if (allow_wide && d == 128 && n > 0 && n * 512 < ((int64_t)1 << 32)) return launch_sgns<2, 1, true>;
     if (d % 2 == 0) {
         const int nv = (d + 127) / 128;
         if (nv <= 1) return launch_sgns<2, 1>;
@@ -2104,6 +1355,10 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     }
     auto *h = new gemhip_n2v();
     h->n = n; h->nnz = nnz; h->uniform_rows = uniform; h->m_start = (int64_t)start.size();
+    // A/B knobs: read ONCE, here (the launch path reads no environment); the setters below override them per handle
+    if (const char *e = getenv("GEMHIP_SGNS_MAX_WAVES")) h->max_waves = std::max(0, atoi(e));
+    if (const char *e = getenv("GEMHIP_SGNS_CACHE_R")) h->cache_radius = std::min(31, std::max(-1, atoi(e)));
+    if (const char *e = getenv("GEMHIP_SGNS_CACHE_DELTA")) h->cache_delta = std::min(1, std::max(-1, atoi(e)));
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
     hipError_t e = hipMalloc((void **)&h->d_row_ptr, (n + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMemcpy(h->d_row_ptr, row_ptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
@@ -2127,7 +1382,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
 {
     if (!h) return GEMHIP_OK;
     hipFree(h->d_start);
-    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_bcnt); hipFree(h->d_oscr);
+    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_bcnt);
     if (h->own_counts) hipFree(h->d_counts);
     hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
@@ -2507,85 +1762,31 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.token_offset = token_offset; A.walk_id_offset = h->walk_id_offset; A.epoch = epoch;
     A.UT = h->d_UT; A.KT = h->d_KT; A.UK = h->d_UK; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
-    A.dummy = nullptr; A.oscr = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1;
+    A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1;
     const bool deterministic = (flags & 4) != 0;
-    // Hogwild concurrency.  Each in-flight wavefront has ~7 embedding rows open (read-modify-write) at any
-    // time; when (waves x 7) approaches n, concurrent writers overwrite each other's updates and the
-    // embedding degrades (measured: tests/test_n2v_gpu.py).  Cap the number of concurrent
-    // wavefronts at n/HOGWILD_ROWS_PER_WAVE; at BASELINE scale (n >= 1M) the cap is the machine.
+    // Hogwild concurrency on small graphs: every in-flight wavefront has rows open (read-modify-write); when the open rows approach n,
+    // concurrent writers overwrite each other's updates and the embedding degrades (tests/test_n2v_gpu.py).  sgns_kernel: n/128.
     const int64_t hog_cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / HOGWILD_ROWS_PER_WAVE);
 
     // window-cached kernel (default): radius R = tokens either side of the centre whose SynPos row stays in LDS
-    int R = h->cache_radius;
-    if (const char *e = getenv("GEMHIP_SGNS_CACHE_R")) R = atoi(e);
-    if (R < 0) R = 10;
+    int R = h->cache_radius < 0 ? 10 : h->cache_radius;
     R = std::min(R, std::min(window, 31));
-    bool win_ok = R > 0 && !(flags & (32 | 64 | GEMHIP_N2V_NO_WINDOW_CACHE)) && 2 * window * SGNS_NEG <= 2 * WAVE && h->walk_len >= 2;
+    bool win_ok = R > 0 && !(flags & GEMHIP_N2V_NO_WINDOW_CACHE) && 2 * window * SGNS_NEG <= 2 * WAVE && h->walk_len >= 2;
     if (win_ok) {      // the window (2R+1 rows, twice with the delta write-back) has to fit a block's LDS: wide rows / long walks fall back to sgns_kernel
         const size_t rwb = (size_t)sgns_win_row_floats(h->d) * sizeof(float);
         const size_t worst = (size_t)((h->walk_len + 4 * window * SGNS_NEG + 3) & ~3) * sizeof(int32_t) + (size_t)((2 * R + 1) * 2 + 1) * rwb;
         win_ok = worst <= 64 * 1024 && (h->d % 2 == 0 ? h->d <= 512 : h->d <= 256);
     }
     if (win_ok) {
-        int mode = h->cache_delta;                       // -1 auto: delta write-back whenever other wavefronts train concurrently
-        if (const char *e = getenv("GEMHIP_SGNS_CACHE_DELTA")) mode = atoi(e);
+        const int mode = h->cache_delta;                 // -1 auto: delta write-back whenever other wavefronts train concurrently
         const int rw = sgns_win_row_floats(h->d);
         const size_t ints = (size_t)((h->walk_len + 4 * window * SGNS_NEG + 3) & ~3);
         auto lds_bytes = [&](bool delta) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * (delta ? 2 : 1) + 1) * rw * sizeof(float); };
-        // two-wavefront kernel (trainer + helper per walk): the default whenever the whole window is cached and the block fits
-        int duo_on = h->sgns_duo;
-        if (const char *e = getenv("GEMHIP_SGNS_DUO")) duo_on = atoi(e);
-        if (duo_on != 0 && R >= window) {
-            const bool delta_d = !deterministic && mode != 0;
-            const size_t lds_d = duo::lds_ints(h->walk_len, R, rw, delta_d) * sizeof(int32_t);
-            sgns_fn fnd = delta_d ? pick_sgns_duo<true>(h->d) : pick_sgns_duo<false>(h->d);
-            if (fnd != nullptr && lds_d <= 64 * 1024 && 2 * window + 1 <= duo::CTXMAX && h->walk_len >= 2) {
-                int64_t waves_d = 1;
-                if (!deterministic) {
-                    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_d + 512)));
-                    const int64_t hog_win = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1 + duo::LEAD + 2)));
-                    waves_d = std::min<int64_t>(std::min<int64_t>(hog_win, 256 * per_cu), walk_hi - walk_lo);
-                }
-                A.nwaves = (int32_t)waves_d; A.cache_radius = R;
-                const size_t need = (size_t)waves_d * rw * sizeof(float);
-                if (need > h->dummy_bytes) {
-                    if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
-                    GEMHIP_CHECK(hipMalloc(&h->d_dummy, need));
-                    GEMHIP_CHECK(hipMemset(h->d_dummy, 0, need));
-                    h->dummy_bytes = need;
-                }
-                A.dummy = h->d_dummy;
-                A.prof = nullptr;
-#ifdef GEMHIP_SGNS_PROFILE
-                static unsigned long long *d_prof2 = nullptr;
-                if (!d_prof2) GEMHIP_CHECK(hipMalloc(&d_prof2, 64));
-                GEMHIP_CHECK(hipMemset(d_prof2, 0, 64));
-                A.prof = d_prof2;
-#endif
-                fnd(A, (int)waves_d, 128, lds_d, (hipStream_t)stream);
-                GEMHIP_CHECK(hipGetLastError());
-#ifdef GEMHIP_SGNS_PROFILE
-                {
-                    unsigned long long hp[8];
-                    GEMHIP_CHECK(hipDeviceSynchronize());
-                    GEMHIP_CHECK(hipMemcpy(hp, A.prof, 64, hipMemcpyDeviceToHost));
-                    fprintf(stderr, "[sgns duo profile] trainers=%lld lds=%zu cycles: outside=%llu issue=%llu ctx_lds=%llu wait_rows=%llu update_store=%llu wait_helper=%llu load_centre=%llu centre_end=%llu\n",
-                            (long long)waves_d, lds_d, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
-                }
-#endif
-                return GEMHIP_OK;
-            }
-        }
         int64_t waves = 1;
         bool delta = false;
-        int oscr_on = 0;                                 // A/B (GEMHIP_SGNS_OSCR=1): as-loaded copies in global scratch instead of LDS -> 12 instead of 6 wavefronts per CU; measured 1-5 % slower
-        if (const char *e = getenv("GEMHIP_SGNS_OSCR")) oscr_on = atoi(e);
-        const bool oscr = oscr_on != 0 && !deterministic && mode != 0 && R >= window && rw == h->d;
         if (!deterministic) {
             delta = mode != 0;
-            const size_t lds_w = oscr ? lds_bytes(false) : lds_bytes(delta);
-            const int64_t vgpr_cap = oscr ? 12 : 8;      // 170 / 183 VGPRs: 3 / 2 wavefronts per SIMD
-            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(vgpr_cap, (int64_t)(160 * 1024) / (int64_t)(lds_w + 512)));
+            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(delta) + 512)));   // 184 VGPRs: 2 per SIMD
             // a wavefront of this kernel holds 2R+1 more rows (the window) than sgns_kernel's ~8: same bound on the fraction of the
             // table that is open at any time (1/16), hence proportionally fewer concurrent wavefronts on small graphs
             // ... measured both ways: SBM-1024 (d=16) loses 3.5 % MAP at 8 wavefronts (n/128) and nothing at 2 (n/464); at d=128, SBM 16k / 32k /
@@ -2598,25 +1799,13 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             //   wavefronts   384      768      1024     1280     1536 (all that fit)
             //   MAP vs seq.  -0.04 %  -0.12 %  -0.41 %  -0.75 %  -0.8 .. -1.3 % (three runs)
             //   seconds      22.5     12.6     11.4     10.2     9.5
-            // north_star's bar is 1 %: the default stops at 1024 (4 per CU); GEMHIP_SGNS_MAX_WAVES / gemhip_n2v_set_max_waves trade it back
-            int64_t quality_cap = h->max_waves > 0 ? (int64_t)h->max_waves : 1024;
-            if (const char *e = getenv("GEMHIP_SGNS_MAX_WAVES")) quality_cap = std::max(1, atoi(e));
+            const int64_t quality_cap = h->max_waves > 0 ? (int64_t)h->max_waves : 1024;
             waves = std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(hog_win, quality_cap), 256 * per_cu), walk_hi - walk_lo);
             if (waves == 1 && mode < 0) delta = false;
         }
-        const bool use_oscr = oscr && delta;
-        const size_t lds = use_oscr ? lds_bytes(false) : lds_bytes(delta);
+        const size_t lds = lds_bytes(delta);
         GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for the LDS window (%zu bytes)", lds);
-        A.nwaves = (int32_t)waves; A.cache_radius = R; A.oscr = nullptr;
-        if (use_oscr) {
-            const size_t need_o = (size_t)waves * (2 * R + 2) * rw * sizeof(float);
-            if (need_o > h->oscr_bytes) {
-                if (h->d_oscr) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_oscr); h->d_oscr = nullptr; h->oscr_bytes = 0; }
-                GEMHIP_CHECK(hipMalloc(&h->d_oscr, need_o));
-                h->oscr_bytes = need_o;
-            }
-            A.oscr = h->d_oscr;
-        }
+        A.nwaves = (int32_t)waves; A.cache_radius = R;
         const size_t need = (size_t)waves * rw * sizeof(float);
         if (need > h->dummy_bytes) {
             if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
@@ -2650,7 +1839,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
 
     const size_t per_wave = (size_t)(h->walk_len + 2 * window * SGNS_NEG) * sizeof(int32_t);
     int blocks, threads;
-    A.cache_radius = 0; A.dummy = nullptr; A.prof = nullptr; A.oscr = nullptr;
+    A.cache_radius = 0; A.dummy = nullptr; A.prof = nullptr;
     if (deterministic) { blocks = 1; threads = 64; A.nwaves = 1; }
     else {
         threads = 256;
@@ -2661,7 +1850,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     }
     const size_t lds = per_wave * (threads / 64);
     GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window too large for LDS staging (%zu bytes)", lds);
-    sgns_fn fn = pick_sgns(h->d, h->n, (flags & 32) != 0, (flags & 64) != 0);
+    sgns_fn fn = pick_sgns(h->d);
     GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
     fn(A, blocks, threads, lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());

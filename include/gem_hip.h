@@ -133,11 +133,10 @@ int gemhip_gf_objective(int64_t n, int64_t m, const int32_t *src,
 #define GEMHIP_N2V_DETERMINISTIC 4
 #define GEMHIP_N2V_UNIFORM_FIRST_HOP 8
 #define GEMHIP_N2V_SNAP_COMPAT 11
-#define GEMHIP_N2V_SHARED_NEGATIVES 64 /* OPT-IN, NOT the reference's sampling: the 5 negatives are drawn once per centre word and shared
-                                         by its contexts (rows stay in registers: ~4x less table traffic); validated on MAP only */
 #define GEMHIP_N2V_NO_WINDOW_CACHE 128 /* A/B switch: train with the round-1 kernel (every context row goes to memory for every pair) instead of the
                                           LDS-window kernel (gemhip_sgns_set_window_cache); same arithmetic and draws either way */
-#define GEMHIP_N2V_WIDE_ROWS 32 /* A/B switch (d == 128): 16-byte sc1 buffer accesses from half a wave + v_permlane32_swap; measured slower than the default 8-byte path */
+/* (bits 32 and 64 selected two round-1/2 experiments -- 16-byte row accesses, negatives shared per centre word -- that were measured slower /
+ * are not the reference's sampling; round 3 removed them from the library, see DESIGN.md 3.3 and the git history of gem_amd/csrc/n2v.hip) */
 
 typedef struct gemhip_n2v *gemhip_n2v_t;
 
