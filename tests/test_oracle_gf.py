@@ -28,6 +28,16 @@ def test_f64_oracle_reproduces_reference_python_loop(tag, gname, request):
     np.testing.assert_allclose(X, g['X'], rtol=1e-9, atol=1e-13)
 
 
+def test_python_loop_restatement_equals_the_vectors_gf_py_produced(karate):
+    """oracle/gf_pyloop.py (bench.py's `cpu_baseline.python_loop`: gf.py:93-100 operation by operation) against the vectors produced by
+    running gf.py itself -- same numpy ops in the same order, so equal to the last bit or two."""
+    from oracle import gf_pyloop
+    g, n, src, dst, w, hp = _case('karate_train', karate)
+    X, visits, _ = gf_pyloop.gf_python_loop(src, dst, w, hp['eta'], hp['regu'], hp['max_iter'], g['X0'])
+    assert visits == hp['max_iter'] * len(src)
+    np.testing.assert_allclose(X, g['X'], rtol=1e-12, atol=1e-15)
+
+
 @pytest.mark.parametrize('tag,gname', [('karate_train', 'karate'), ('sbm1024_d32', 'sbm1024')])
 def test_f32_oracle_tracks_f64(tag, gname, request):
     graph = request.getfixturevalue(gname)
