@@ -386,9 +386,13 @@ class HopeWorkload(object):
     def __init__(self, args, rank, world, comm):
         if args.nodes == 1000000 and args.edges == 10000000:
             args.nodes, args.edges, args.blocks = 100000, 1000000, 32
-        self.name = 'sbm%dk_%dk_hope_d%d_beta0.01' % (args.nodes // 1000, args.edges // 1000, args.d)
+        self.directed = bool(getattr(args, 'hope_directed', False))
+        self.name = 'sbm%dk_%dk_hope_d%d_beta0.01%s' % (args.nodes // 1000, args.edges // 1000, args.d, '_directed' if self.directed else '')
         self.args = args
         g = make_graph(args)
+        if self.directed:        # hope.py:28-36 assumes no symmetry: the same SBM with every undirected edge kept in ONE random direction (A != A^T)
+            from gem_amd.graph import orient_randomly
+            g = orient_randomly(g, 1)
         self.n_edges = g.number_of_edges()
         n, src, dst, w, _ = edge_arrays(g)
         self.n = n
@@ -444,6 +448,9 @@ class HopeWorkload(object):
         a = self.args
         n_s = min(20000, self.n)
         gs = sbm_graph(n_s, n_s * (a.edges // a.nodes), max(1, n_s // (a.nodes // a.blocks)), seed=7)
+        if self.directed:
+            from gem_amd.graph import orient_randomly
+            gs = orient_randomly(gs, 1)
         A = sp.csr_matrix((np.ones(gs.number_of_edges()), (gs.src, gs.dst)), shape=(n_s, n_s))
         t = time.time()
         _, s_cpu = hope_oracle.hope_operator_series(A, 0.01, a.d, tol=1e-5)
@@ -544,6 +551,7 @@ def main():
     ap.add_argument('--inout-q', type=float, default=1.0, help='node2vec in-out parameter q (node2vec.py:41 -q:)')
     ap.add_argument('--gf-eta', type=float, default=1e-2)
     ap.add_argument('--gf-regu', type=float, default=1e-2)
+    ap.add_argument('--hope-directed', action='store_true', help='hope: orient every undirected edge in one random direction (A != A^T: the general case of hope.py)')
     ap.add_argument('--episodes', type=int, default=64, help='N>1 node2vec: episodes of the partitioned schedule')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -597,6 +605,9 @@ def main():
         del w3
         torch.cuda.empty_cache()
         extra['hope_sbm100k_1m'], w4 = time_workload('hope', copy.copy(args), rank, world, comm, None, None, with_cpu=not args.no_cpu_baseline)
+        del w4
+        a5 = copy.copy(args); a5.hope_directed = True      # the general (directed) Katz case: block-Krylov SVD on S^T S, no eigen-path
+        extra['hope_sbm100k_directed'], w5 = time_workload('hope', a5, rank, world, comm, None, None, with_cpu=not args.no_cpu_baseline)
         out['workloads'] = extra
 
     if rank == 0:

@@ -158,6 +158,20 @@ def sbm_graph(n, n_directed_edges, n_blocks, seed, intra=0.8):
     return EdgeListGraph(n, src[perm].astype(np.int32), dst[perm].astype(np.int32), None)
 
 
+def orient_randomly(g, seed):
+    """A DIRECTED graph from an undirected one stored in both directions: every undirected edge {a, b} is kept in ONE direction chosen
+    by a fair coin (half the arcs).  HOPE's general case (hope.py:28-36 makes no symmetry assumption): A != A^T, S has distinct left
+    and right singular vectors."""
+    rng = np.random.default_rng(seed)
+    src, dst = np.asarray(g.src), np.asarray(g.dst)
+    und = src < dst
+    a, b = src[und], dst[und]
+    flip = rng.random(len(a)) < 0.5
+    s2 = np.where(flip, b, a); d2 = np.where(flip, a, b)
+    perm = np.lexsort((d2, s2))
+    return EdgeListGraph(g.n, s2[perm].astype(np.int32), d2[perm].astype(np.int32), None)
+
+
 def rmat_graph(scale, n_directed_edges, seed, a=0.57, b=0.19, c=0.19):
     """R-MAT (Chakrabarti et al.) power-law graph, symmetrised, self-loops and
     duplicates dropped; 2**scale nodes (BASELINE configs[4])."""

@@ -133,6 +133,23 @@ def test_all_64_singular_values_at_baseline_config_vs_arpack():
     assert rel.max() <= 1e-4, (rel.max(), int(rel.argmax()))
 
 
+def test_all_64_singular_values_of_the_directed_graph_vs_arpack():
+    """The general case of hope.py:28-36 (no symmetry): the same SBM 100k/1M with every undirected edge kept in one random direction
+    (gem_amd.graph.orient_randomly, seed 1; bench.py's `hope_sbm100k_directed` workload).  ARPACK svds on the implicit Katz operator,
+    tol 1e-9 (scripts/make_golden_hope_sigma.py --directed) vs the HIP block-Krylov solve: all 64 singular values to 1e-4 relative, and
+    the solver reports the general path."""
+    from gem_amd.graph import orient_randomly
+    ref = json.load(open(golden_path('hope_sigma_sbm100k_directed.json')))
+    pr = ref['params']
+    g = orient_randomly(sbm_graph(pr['n'], pr['edges'], pr['blocks'], pr['seed']), pr['orient_seed'])
+    m = HOPE(d=pr['d'], beta=pr['beta'])
+    m.learn_embedding(graph=g, is_weighted=True, no_python=True)
+    assert m._stats['solver'] == 'block_krylov'
+    s_ref = np.asarray(ref['sigma_ascending'])
+    rel = np.abs(np.asarray(m._sigma) / s_ref - 1.0)
+    assert rel.max() <= 1e-4, (rel.max(), int(rel.argmax()))
+
+
 def test_symmetric_eigen_path_agrees_with_the_block_krylov_path(monkeypatch):
     """Undirected graphs take the Chebyshev-filtered eigen-path on A (hope.hip sym_filter_svd; automatic from 16384 nodes, forced here
     at 8192): same singular values and the same rank-k reconstruction U S V^T as the general block-Krylov solver on S^T S, which the
