@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgem_hip.so')
+LIB_PATH = os.environ.get('GEM_HIP_LIB') or os.path.join(_HERE, 'libgem_hip.so')     # GEM_HIP_LIB: an A/B or profiling build of the same ABI
 
 _lib = None
 
@@ -91,7 +91,7 @@ _SIGS = {
                                           C.c_float, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p]),
     'gemhip_n2v_set_max_waves': (C.c_int, [C.c_void_p, C.c_int32]),
     'gemhip_sgns_set_window_cache': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
-    'gemhip_sgns_set_team': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    'gemhip_sgns_set_hogwild': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_test_wave_sum6': (C.c_int, [f32p, f32p]),
     'gemhip_sgns_set_tables': (C.c_int, [C.c_void_p, f32p, f32p]),
     'gemhip_sgns_get_tables': (C.c_int, [C.c_void_p, f32p, f32p]),

@@ -88,8 +88,8 @@ struct gemhip_n2v {
     int32_t max_waves = 0;            // 0 = auto (see gemhip_sgns_train)
     int32_t cache_radius = -1;        // sgns_win_kernel LDS window radius: -1 auto, 0 = off (sgns_kernel)
     int32_t cache_delta = -1;         // -1 auto, 0 overwrite on leave, 1 delta write-back
-    int32_t team_mode = -1;           // sgns_team_kernel: -1 auto (Hogwild launches where it applies), 0 never, 1 also for deterministic launches
-    int32_t team_prefetch = 1;        // ... pairs of negative rows requested ahead (1 or 2)
+    int32_t prefetch = 2;             // pairs whose negative rows are requested ahead: 2 (default) or 1 (d == 64/128/256.., whole window cached)
+    int32_t reload = 1;               // Hogwild launches: update negative rows as they are at store time (second fetch) and the centre row by atomic add
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
     unsigned long long *d_bcnt = nullptr;               // emit_pairs_bucketed: bucket sizes [64*64] + cursors [64*64]
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
@@ -282,7 +282,8 @@ struct SgnsArgs {
     float *dummy;               // sgns_win_kernel: nwaves rows, never read for their value
     unsigned long long *prof;   // GEMHIP_SGNS_PROFILE builds only: per-phase cycle sums (s_memtime)
     int32_t cache_radius;       // sgns_win_kernel: tokens within this many positions of the centre keep their SynPos row in LDS
-    int32_t team_prefetch;      // sgns_team_kernel: pairs whose negative rows are requested ahead (1 or 2)
+    int32_t prefetch;           // sgns_win_kernel: pairs whose negative rows are requested ahead (2, or 1)
+    int32_t reload;             // sgns_win_kernel<RELOAD>: negative rows updated as they are at store time, centre row by atomic add
 };
 
 // gradient scale of TrainModel: (label - sigma(f)) * alpha with the +-MaxExp clamps
@@ -518,9 +519,18 @@ struct NegSet {
 // With both, the pair loop has a STATIC number of memory operations per pair (skipped targets and exhausted prefetch slots
 // go to a per-wave dummy row instead of branching), which is what lets the compiler keep two pairs' rows in flight with
 // counted s_waitcnt vmcnt(N) instead of draining to vmcnt(0) at every control-flow merge.
-template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC>
+// PF: pairs whose negative rows are requested ahead (2 by default; 1 keeps 10 instead of 15 rows of a wavefront open between load and store).
+// RELOAD (Hogwild launches, default): the update of a negative row is applied to the row AS IT IS NOW -- the five rows are fetched again
+// right after the dot products (the gradient still uses the copy requested PF pairs ahead) and leave as `row_now + g * xc` -- and the centre's
+// positive row leaves as an atomic add of what this centre changed.  A store another wavefront makes between a row's first load and its
+// store is no longer overwritten: the window in which it can be lost shrinks from (PF + 1) pair steps to one reload round trip.  The CPU
+// replay of this kernel's concurrency (scripts/hogwild_emul) attributes ~90 % of Hogwild's MAP loss to those overwritten negative-row
+// updates and the rest to the centre row's; stale gradients themselves cost nothing.
+template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC, int PF = 2, bool RELOAD = false>
 __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 {
+    static_assert(PF == 1 || PF == 2, "prefetch distance");
+    static_assert(!RELOAD || (DELTA && FULL && ALLC), "RELOAD is a Hogwild (delta) mode of the all-cached kernel");
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     constexpr int RW = NV * VEC * WAVE;              // floats per cached row (row padded to the wave's footprint)
     constexpr int NS = 2;                            // negative samples per lane and centre: 2*window*5 <= 128
@@ -712,9 +722,15 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 const int b = (int)(rw.x % (uint32_t)win);
                 const int32_t *ncur = negs + (pos & 1) * nsamp;
 
-                float yp[NV][VEC];
+                float yp[NV][VEC], yp0[NV][VEC];
                 float *pp = A.SynNeg + (int64_t)word * d;
                 g_ld(pp, yp);
+                if constexpr (RELOAD) {
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) yp0[c][k] = yp[c][k];
+                }
 
                 // the contexts of this centre, ascending (TrainModel's order): bit a <-> position pos - win + a
                 bool valid = false;
@@ -746,15 +762,15 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     }
                 };
                 issue(q0);
-                issue(q1);
+                if constexpr (PF == 2) issue(q1);
 
                 if (sE >= 0) {               // the entering row has landed by now (requested before everything above)
                     lds_st(rowsL + (size_t)sE * RW, rowE);
                     if constexpr (DELTA) o_st(sE, rowE);
                 }
 
-                // one (centre, context) pair: C holds its negative rows, P1 the next pair's (in flight), P2 is free
-                auto step = [&](NegSet<VEC, NV> &C, NegSet<VEC, NV> &P1, NegSet<VEC, NV> &P2) __attribute__((always_inline)) {
+                // one (centre, context) pair: C holds its negative rows, the sets in between are in flight, P2 is free
+                auto step = [&](NegSet<VEC, NV> &C, NegSet<VEC, NV> &P2) __attribute__((always_inline)) {
                     PROF_LAP(0);                                     // outside the pair steps (per-centre work, loop control)
                     const int a = (int)__builtin_ctzll(m_proc);
                     m_proc &= m_proc - 1;
@@ -779,8 +795,8 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                         for (int k = 0; k < VEC; ++k) neu[c][k] = 0.f;
                     const int ai_c = a < win ? a : a - 1;
                     PROF_LAP(2);                                     // context lookup + LDS read (includes its lgkmcnt wait)
-                    PROF_WAIT_VM(10);
-                    PROF_LAP(3);                                     // waiting for this pair's rows (two younger prefetches may stay in flight)
+                    if constexpr (PF == 2) PROF_WAIT_VM(10); else PROF_WAIT_VM(5);
+                    PROF_LAP(3);                                     // waiting for this pair's rows (the younger prefetches may stay in flight)
                     if (!((spec_cur >> ai_c) & 1u)) {
                         // fast path: the six targets are distinct rows and none is the centre word -> six independent updates
                         float part[6];
@@ -794,6 +810,11 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
                                 for (int j = 0; j < SGNS_NEG; ++j) part[j + 1] = fmaf(xc[c][k], C.y[j][c][k], part[j + 1]);
                             }
+                        float Rn[RELOAD ? SGNS_NEG : 1][NV][VEC];
+                        if constexpr (RELOAD) {      // the five rows as they are NOW (requested here, needed after the sigmoid)
+#pragma unroll
+                            for (int j = 0; j < SGNS_NEG; ++j) g_ld(A.SynNeg + (int64_t)C.tgt[j] * d, Rn[j]);
+                        }
                         const float f = wave_sum6(part, lane);
                         const float gl = sgns_grad_fast(f, (lane & 7) == 0 ? 1.0f : 0.0f, alpha);     // lanes 0..5: g of target 0..5
                         float g[6];
@@ -806,16 +827,33 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                                 neu[c][k] = fmaf(g[0], yp[c][k], neu[c][k]);
                                 yp[c][k] = fmaf(g[0], xc[c][k], yp[c][k]);
                             }
+                        if constexpr (RELOAD) {
 #pragma unroll
-                        for (int j = 0; j < SGNS_NEG; ++j) {
+                            for (int j = 0; j < SGNS_NEG; ++j)
 #pragma unroll
-                            for (int c = 0; c < NV; ++c)
+                                for (int c = 0; c < NV; ++c)
 #pragma unroll
-                                for (int k = 0; k < VEC; ++k) {
-                                    neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
-                                    C.y[j][c][k] = fmaf(g[j + 1], xc[c][k], C.y[j][c][k]);
-                                }
-                            g_st(A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                                    for (int k = 0; k < VEC; ++k) neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
+#pragma unroll
+                            for (int j = 0; j < SGNS_NEG; ++j) {
+#pragma unroll
+                                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                    for (int k = 0; k < VEC; ++k) Rn[j][c][k] = fmaf(g[j + 1], xc[c][k], Rn[j][c][k]);
+                                g_st(A.SynNeg + (int64_t)C.tgt[j] * d, Rn[j]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < SGNS_NEG; ++j) {
+#pragma unroll
+                                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                    for (int k = 0; k < VEC; ++k) {
+                                        neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
+                                        C.y[j][c][k] = fmaf(g[j + 1], xc[c][k], C.y[j][c][k]);
+                                    }
+                                g_st(A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                            }
                         }
                     } else {
                         // slow path (exact sequential semantics): the rows may have been requested before an update of the same row by
@@ -866,13 +904,22 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     if (ALLC || chit) lds_st(lrow, xc); else g_st(pc, xc);
                     PROF_LAP(4);                                     // arithmetic + stores
                 };
-                while (true) {
-                    if (!m_proc) break;
-                    step(q0, q1, q2);
-                    if (!m_proc) break;
-                    step(q1, q2, q0);
-                    if (!m_proc) break;
-                    step(q2, q0, q1);
+                if constexpr (PF == 2) {
+                    while (true) {
+                        if (!m_proc) break;
+                        step(q0, q2);
+                        if (!m_proc) break;
+                        step(q1, q0);
+                        if (!m_proc) break;
+                        step(q2, q1);
+                    }
+                } else {
+                    while (true) {
+                        if (!m_proc) break;
+                        step(q0, q1);
+                        if (!m_proc) break;
+                        step(q1, q0);
+                    }
                 }
                 // the prefetch slots that were filled past the last pair are dead; "use" them so that the compiler's wait-count
                 // bookkeeping retires their loads here instead of carrying them into the next centre's loop header
@@ -884,8 +931,14 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
                             for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(Q.y[j][c][k]));
                 };
-                retire(q0); retire(q1); retire(q2);
-                g_st(pp, yp);
+                retire(q0); retire(q1); if constexpr (PF == 2) retire(q2);
+                if constexpr (RELOAD) {      // what this centre changed, added to the row as it is now (global_atomic_add_f32: nothing another wavefront stored is lost)
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k)
+                            __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pp + (c * WAVE + lane) * VEC + k), yp[c][k] - yp0[c][k]);
+                } else g_st(pp, yp);
             } else if (sE >= 0) {
                 lds_st(rowsL + (size_t)sE * RW, rowE);
                 if constexpr (DELTA) o_st(sE, rowE);
@@ -938,506 +991,6 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #endif
 }
 
-// ---- team TrainModel (round 3; Hogwild default where it applies): THREE wavefronts of one workgroup train ONE walk ---------------
-// What limits sgns_win_kernel is not bytes but one wavefront per SIMD issuing a whole (centre, context) pair by itself, and it cannot
-// simply be given more wavefronts: every concurrently trained WALK keeps ~5 x (prefetch distance + 1) negative rows open between their
-// load and their store, a foreign store inside that window is overwritten, and at SBM 1M/10M the reconstruction MAP sits on the steep
-// part of its training curve -- the lost updates cost ~0.07 % of MAP per 100 concurrent walks (reproduced on the CPU by
-// scripts/hogwild_emul).  So the unit of Hogwild stays the walk, and the parallelism goes INSIDE it: the six targets of a pair
-// (the positive SynNeg[word] and five negatives) are independent given the context row -- TrainModel accumulates neu1e over them and
-// only then updates SynPos[ctx] -- so wavefront 0 takes {positive, negative 1}, wavefront 1 {negatives 2, 3}, wavefront 2 {negatives 4, 5}:
-//   * the window of context rows (tokens within R = window positions of the centre, one slot per distinct node) lives in the
-//     workgroup's LDS exactly as in sgns_win_kernel (delta write-back when other workgroups train concurrently);
-//   * every wavefront reads the pair's context row from LDS, computes its two dot products (one transposing DPP reduction for
-//     both, lane-parallel sigmoid), updates and stores ITS target rows, and adds its share of neu1e to the slot's ACCUMULATOR row in
-//     LDS (ds_add_f32); the accumulators are folded into the window rows at the centre boundary (two s_barrier per centre);
-//   * a context node that occurs twice among one centre's contexts must see the first pair's update: that pair is preceded by
-//     barrier / read row + accumulator / barrier;
-//   * pairs whose targets collide (a target drawn twice, a target of one of the previous PF pairs -- whose rows were requested
-//     before those pairs stored -- or a target equal to the centre word) are executed by wavefront 0 alone, in TrainModel's
-//     order, between two barriers that also drain every wavefront's stores;
-//   * !DELTA (one workgroup: the deterministic mode of the parity tests) additionally drains stores and synchronises after every
-//     pair, so that the launch is exactly sequential TrainModel up to the fp32 summation order of neu1e (three partial sums).
-// Same Philox draws, same alpha schedule, same walk -> workgroup assignment (wl = team, team + nteams, ...) as sgns_win_kernel.
-// Requires d == NV * VEC * 64 and R >= window (the dispatcher falls back to sgns_win_kernel otherwise).
-__device__ __forceinline__ float wave_sum2(float p0, float p1, int lane)     // even lanes: wave total of p0, odd lanes: of p1
-{
-    const bool b0 = (lane & 1) != 0;
-    float a = (b0 ? p1 : p0) + dpp_mov<0xB1>(b0 ? p0 : p1);      // partner lane^1: each lane keeps the value its parity selects
-    a += dpp_mov<0x4E>(a);                                        // lane^2 (same parity): quad total
-    a += dpp_mov<0x124>(a); a += dpp_mov<0x128>(a);               // the four quads of a 16-lane row
-    n2v_u32x2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, a), false, false);
-    unsigned lo = r.x, hi = r.y;
-    a = __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
-    r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, a), false, false);
-    lo = r.x; hi = r.y;
-    return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
-}
-__device__ __forceinline__ void lds_fadd(float *p, float v)
-{
-    __hip_atomic_fetch_add((__attribute__((address_space(3))) float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f32
-}
-// workgroup barrier that waits for this wavefront's LDS traffic only (global loads / stores stay in flight across it)
-#define TEAM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// ... and one that also drains this wavefront's global stores (and loads)
-#define TEAM_BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-constexpr int TEAM_T = 3;            // wavefronts per walk
-template <int VEC, int NV, int NR>
-struct TeamSet {
-    int32_t tgt[NR];
-    float y[NR][NV][VEC];
-};
-
-template <int VEC, int NV, bool DELTA, int PF>
-__global__ __launch_bounds__(64 * TEAM_T) void sgns_team_kernel(SgnsArgs A)
-{
-    static_assert(PF == 1 || PF == 2, "prefetch distance");
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    constexpr int RW = NV * VEC * WAVE;              // floats per row (== d)
-    const int lane = lane_id();
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tid = (int)threadIdx.x;
-    const int64_t team = blockIdx.x;
-    const int d = RW, win = A.window, len = A.walk_len, R = A.cache_radius, S = 2 * R + 2;
-    const int nsamp = 2 * win * SGNS_NEG;            // <= 64 * TEAM_T: one sample per thread
-    const bool quirk = (A.flags & 2) != 0;
-    int32_t *tok = lds;
-    int32_t *negs = tok + ((len + 3) & ~3);          // [2][nsp]
-    const int nsp = (nsamp + 3) & ~3;
-    int32_t *ctl = negs + 2 * nsp;                   // [4]: special mask of the centre, by parity
-    float *rowsL = reinterpret_cast<float *>(ctl + 4);
-    float *acc = rowsL + (size_t)S * RW;             // neu1e accumulators, layout [slot][c][k][lane] (conflict-free ds_add)
-    float *rowsO = acc + (size_t)S * RW;             // DELTA only: rows as loaded
-
-    auto lds_ld = [&](const float *row, float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) v[c][k] = row[(c * WAVE + lane) * VEC + k];
-    };
-    auto lds_st = [&](float *row, const float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) row[(c * WAVE + lane) * VEC + k] = v[c][k];
-    };
-    auto acc_ld = [&](const float *row, float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) v[c][k] = row[(c * VEC + k) * WAVE + lane];
-    };
-    auto acc_zero = [&](float *row) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) row[(c * VEC + k) * WAVE + lane] = 0.f;
-    };
-    auto acc_add = [&](float *row, const float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) lds_fadd(row + (c * VEC + k) * WAVE + lane, v[c][k]);
-    };
-    auto g_ld = [&](const float *p, float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c) ld_row<VEC>(p, RW, lane, c, v[c]);
-    };
-    auto g_st = [&](float *p, const float (&v)[NV][VEC]) {
-#pragma unroll
-        for (int c = 0; c < NV; ++c) st_row<VEC>(p, RW, lane, c, v[c]);
-    };
-    float *dummy = A.dummy + ((size_t)team * TEAM_T + wv) * RW;      // this wavefront's private sink / source for predicated-off row traffic
-    // which of the five negatives of a pair this wavefront owns: wave 0 -> {0} (next to the positive target), 1 -> {1, 2}, 2 -> {3, 4}
-    const int nbase = wv == 0 ? 0 : 2 * wv - 1;
-    unsigned long long npairs = 0;
-
-    for (int64_t wl = A.walk_lo + team; wl < A.walk_hi; wl += A.nwaves) {
-        TEAM_BARRIER();                              // the previous walk's LDS is no longer read
-        const int32_t *walk = A.walks + wl * len;
-        for (int k = tid; k < len; k += 64 * TEAM_T) tok[k] = walk[k];
-        for (int k = tid; k < S * RW; k += 64 * TEAM_T) acc[k] = 0.f;
-        TEAM_BARRIER();
-        const int64_t wid = A.walk_id_offset + wl;
-        const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
-        int32_t slot_node = -1, slot_ref = 0;        // slot directory (lane s < S describes slot s), replicated in every wavefront
-
-        // --- negative-target pipeline, one sample per thread: stage A (table slot -> X) for centre p, stage B (UT[X], KT[X]), finalize -> LDS
-        int32_t XA = 0, XB = 0, KTv = 0; float uA = 0.f, uB = 0.f, UTv = 2.f; bool liveA = false, liveB = false;
-        auto stage_a = [&](int p) {
-            XA = 0; uA = 0.f; liveA = false;
-            if (p < len && tid < nsamp) {
-                const u32x4 rwp = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
-                const int bp = (int)(rwp.x % (uint32_t)win);
-                const int ai = tid / SGNS_NEG;
-                const int a = ai < win ? ai : ai + 1;
-                const int cp = p - win + a;
-                if (a >= bp && a < 2 * win + 1 - bp && cp >= 0 && cp < len) {
-                    liveA = true;
-                    const int j = tid - ai * SGNS_NEG + 1;
-                    const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p | ((uint32_t)a << 16),
-                                                   (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
-                    const uint32_t slot = mulhi_range(rn.x, A.n);
-                    XA = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
-                    uA = u01(rn.y);
-                }
-            }
-        };
-        auto stage_b = [&]() {
-            XB = XA; uB = uA; liveB = liveA; UTv = 2.f; KTv = 0;
-            if (liveB) { const uint2 uk = A.UK[XB]; UTv = __builtin_bit_cast(float, uk.x); KTv = (int32_t)uk.y; }
-        };
-        auto stage_fin = [&](int p) {                 // every thread: its sample of centre p -> LDS (targets of dead samples are never read for training)
-            if (tid < nsamp) negs[(p & 1) * nsp + tid] = (uB < UTv) ? XB : KTv;
-        };
-        // "special" mask of centre p (wavefront 0, after the samples are in LDS): bit ai is set when the pair of context slot ai cannot take
-        // the independent-targets path -- a target equals the centre word, a target was drawn twice, or a target also occurs in one of the
-        // previous two slots (its row was requested before that slot's store)
-        auto special_mask = [&](int p) -> uint32_t {
-            if (p >= len) return 0u;
-            const int32_t *dst = negs + (p & 1) * nsp;
-            const int32_t wordn = __builtin_amdgcn_readfirstlane(tok[p]);
-            bool sp = false;
-            if (lane < 2 * win) {
-                int32_t t[SGNS_NEG];
-#pragma unroll
-                for (int j = 0; j < SGNS_NEG; ++j) { t[j] = dst[lane * SGNS_NEG + j]; sp = sp || t[j] == wordn; }
-#pragma unroll
-                for (int j = 0; j < SGNS_NEG; ++j)
-#pragma unroll
-                    for (int jp = 0; jp < j; ++jp) sp = sp || t[j] == t[jp];
-#pragma unroll
-                for (int k = 0; k < 2 * SGNS_NEG; ++k) {
-                    const int idx = (lane - 2) * SGNS_NEG + k;
-                    const int32_t u = dst[idx >= 0 ? idx : 0];
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) sp = sp || (idx >= 0 && t[j] == u);
-                }
-            }
-            return (uint32_t)__builtin_amdgcn_ballot_w64(sp);
-        };
-        stage_a(0); stage_b(); stage_fin(0);
-        stage_a(1);
-
-        // --- window: tokens 0 .. R enter before the first centre (token q is fetched by wavefront q % 3; every wavefront keeps the directory)
-        for (int q = 0; q <= R && q < len; ++q) {
-            const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
-            if (v < 0) continue;
-            const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
-            if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; continue; }
-            const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node < 0 && lane < S));
-            if (q % TEAM_T == wv) {
-                float r[NV][VEC];
-                g_ld(A.SynPos + (int64_t)v * d, r);
-                lds_st(rowsL + (size_t)s * RW, r);
-                if constexpr (DELTA) lds_st(rowsO + (size_t)s * RW, r);
-            }
-            if (lane == s) { slot_node = v; slot_ref = 1; }
-        }
-        TEAM_BARRIER();
-        if (wv == 0) { const uint32_t m = special_mask(0); if (lane == 0) ctl[0] = (int32_t)m; }
-        TEAM_BARRIER();
-
-        float yp[NV][VEC], ypn[NV][VEC];             // wavefront 0: SynNeg[word] of this centre / of the next one (requested a centre ahead)
-        bool ypn_valid = false;
-        for (int pos = 0; pos < len; ++pos) {
-            const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
-            uint32_t spec_cur = (uint32_t)__builtin_amdgcn_readfirstlane(ctl[pos & 1]);
-            // token pos+1+R enters the window for the NEXT centre (its row reaches LDS at the boundary below)
-            float rowE[NV][VEC]; int sE = -1;
-            if (pos + 1 + R < len) {
-                const int32_t v = __builtin_amdgcn_readfirstlane(tok[pos + 1 + R]);
-                if (v >= 0) {
-                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
-                    if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; }
-                    else {
-                        sE = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node < 0 && lane < S));
-                        if (wv == 1) g_ld(A.SynPos + (int64_t)v * d, rowE);
-                        if (lane == sE) { slot_node = v; slot_ref = 1; }
-                    }
-                }
-            }
-            // token pos-R leaves after this centre: when it is the last holder of its slot, wavefront 2 fetches the row as it is NOW
-            float rowG[NV][VEC]; int sX = -1; int32_t vX = -1;
-            if (pos - R >= 0) {
-                vX = __builtin_amdgcn_readfirstlane(tok[pos - R]);
-                if (vX >= 0) {
-                    const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node == vX));
-                    const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
-                    if (lane == s) slot_ref = refc;
-                    if (refc == 0) {
-                        sX = s;
-                        if constexpr (DELTA) if (wv == 2) g_ld(A.SynPos + (int64_t)vX * d, rowG);
-                    }
-                }
-            }
-            stage_b();                               // negatives: B for centre pos+1, A for centre pos+2
-            stage_a(pos + 2);
-
-            uint32_t seen = 0u;                      // window slots used as a context by this centre so far
-            if (word >= 0) {
-                const int64_t t = A.token_offset + wl * len + pos;
-                const int64_t tq = t - (t % 10000);
-                float alpha = A.alpha0 * (1.0f - (float)((double)tq / (double)A.denom));
-                alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
-                const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
-                const int b = (int)(rw.x % (uint32_t)win);
-                const int32_t *ncur = negs + (pos & 1) * nsp;
-                float *pp = A.SynNeg + (int64_t)word * d;
-                if (wv == 0) {
-                    if (DELTA && ypn_valid) {
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) yp[c][k] = ypn[c][k];
-                    } else g_ld(pp, yp);
-                }
-                ypn_valid = false;
-                bool valid = false;
-                {
-                    const int a = lane, cp = pos - win + a;
-                    if (a >= b && a < 2 * win + 1 - b && a != win && cp >= 0 && cp < len) valid = tok[cp] >= 0;
-                }
-                unsigned long long m_proc = __builtin_amdgcn_ballot_w64(valid), m_iss = m_proc;
-                if (wv == 0) npairs += (unsigned long long)__builtin_popcountll(m_proc);
-                {   // the slots in flight after ai are ai+1, ai+2 only if the valid contexts are contiguous (always, but for padded walks)
-                    const unsigned long long lowm = (1ull << win) - 1ull;
-                    const unsigned long long mai = (m_proc & lowm) | ((m_proc >> (win + 1)) << win);
-                    const unsigned long long sh = mai ? (mai >> __builtin_ctzll(mai)) : 0ull;
-                    if (sh & (sh + 1ull)) spec_cur = 0xFFFFFFFFu;
-                }
-                if (DELTA && wv == 0 && pos + 1 < len) {      // the next centre's positive row, a whole centre ahead (Hogwild launches only)
-                    const int32_t wnext = __builtin_amdgcn_readfirstlane(tok[pos + 1]);
-                    if (wnext >= 0 && wnext != word) { g_ld(A.SynNeg + (int64_t)wnext * d, ypn); ypn_valid = true; }   // (equal words: zero-padded tails -- the row is still being trained)
-                }
-
-                auto run = [&](auto NRc, auto POSc) __attribute__((always_inline)) {
-                    constexpr int NR = decltype(NRc)::value;         // negative rows this wavefront owns per pair
-                    constexpr bool POS = decltype(POSc)::value;      // ... and the positive target (wavefront 0)
-                    TeamSet<VEC, NV, NR> q0, q1, q2;
-                    auto issue = [&](TeamSet<VEC, NV, NR> &Q) __attribute__((always_inline)) {
-                        const bool live = m_iss != 0;                // exhausted: the same loads, from the dummy row
-                        const int a = live ? (int)__builtin_ctzll(m_iss) : 0;
-                        m_iss &= m_iss - 1;
-                        const int ai = a < win ? a : a - 1;
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) {
-                            Q.tgt[r] = live ? __builtin_amdgcn_readfirstlane(ncur[ai * SGNS_NEG + nbase + r]) : -1;
-                            g_ld(live ? A.SynNeg + (int64_t)Q.tgt[r] * d : dummy, Q.y[r]);
-                        }
-                    };
-                    issue(q0);
-                    if constexpr (PF == 2) issue(q1);
-                    auto step = [&](TeamSet<VEC, NV, NR> &C, TeamSet<VEC, NV, NR> &P) __attribute__((always_inline)) {
-                        const int a = (int)__builtin_ctzll(m_proc);
-                        m_proc &= m_proc - 1;
-                        issue(P);                                    // the rows of the pair PF ahead
-                        const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[pos - win + a]);
-                        const int slot = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node == ctx));
-                        const bool rep = (seen >> slot) & 1u;
-                        seen |= 1u << slot;
-                        const int ai_c = a < win ? a : a - 1;
-                        const bool special = (spec_cur >> ai_c) & 1u;
-                        float *lrow = rowsL + (size_t)slot * RW, *arow = acc + (size_t)slot * RW;
-                        float xc[NV][VEC], neu[NV][VEC];
-                        if (special) {
-                            // TrainModel's order, by wavefront 0 alone, on rows fetched after every earlier store of the team has landed
-                            TEAM_BARRIER_DRAIN();
-                            if (wv == 0) {
-                                float ax[NV][VEC];
-                                lds_ld(lrow, xc); acc_ld(arow, ax);
-#pragma unroll
-                                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                    for (int k = 0; k < VEC; ++k) { xc[c][k] += ax[c][k]; neu[c][k] = 0.f; }
-                                if constexpr (POS) {
-                                    float part = 0.f;
-#pragma unroll
-                                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                        for (int k = 0; k < VEC; ++k) part = fmaf(xc[c][k], yp[c][k], part);
-                                    const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
-#pragma unroll
-                                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                        for (int k = 0; k < VEC; ++k) { neu[c][k] = fmaf(g, yp[c][k], neu[c][k]); yp[c][k] = fmaf(g, xc[c][k], yp[c][k]); }
-                                }
-                                for (int j = 0; j < SGNS_NEG; ++j) {
-                                    const int32_t tg = __builtin_amdgcn_readfirstlane(ncur[ai_c * SGNS_NEG + j]);
-                                    if (tg == word) continue;                    // TrainModel: `if (Target == Word) continue`
-                                    float y[NV][VEC];
-                                    float *py = A.SynNeg + (int64_t)tg * d;
-                                    g_ld(py, y);                                 // program order after this wavefront's earlier stores (a repeated target sees its update)
-                                    float part = 0.f;
-#pragma unroll
-                                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                        for (int k = 0; k < VEC; ++k) part = fmaf(xc[c][k], y[c][k], part);
-                                    const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
-#pragma unroll
-                                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                        for (int k = 0; k < VEC; ++k) { neu[c][k] = fmaf(g, y[c][k], neu[c][k]); y[c][k] = fmaf(g, xc[c][k], y[c][k]); }
-                                    g_st(py, y);
-                                }
-                                acc_add(arow, neu);
-                            }
-                            TEAM_BARRIER_DRAIN();
-                            return;
-                        }
-                        if (rep) {                                   // this node was a context of an earlier pair of this centre: its updates first
-                            TEAM_BARRIER();
-                            float ax[NV][VEC];
-                            lds_ld(lrow, xc); acc_ld(arow, ax);
-#pragma unroll
-                            for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                for (int k = 0; k < VEC; ++k) xc[c][k] += ax[c][k];
-                            TEAM_BARRIER();
-                        } else lds_ld(lrow, xc);
-                        float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) {
-                                if constexpr (POS) { p0 = fmaf(xc[c][k], yp[c][k], p0); p1 = fmaf(xc[c][k], C.y[0][c][k], p1); }
-                                else { p0 = fmaf(xc[c][k], C.y[0][c][k], p0); p1 = fmaf(xc[c][k], C.y[1][c][k], p1); }
-                            }
-                        const float f = wave_sum2(p0, p1, lane);
-                        const float gl = sgns_grad_fast(f, (POS && (lane & 1) == 0) ? 1.0f : 0.0f, alpha);
-                        const float g0 = bcast_lane(gl, 0), g1 = bcast_lane(gl, 1);
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) {
-                                if constexpr (POS) {
-                                    neu[c][k] = fmaf(g1, C.y[0][c][k], g0 * yp[c][k]);
-                                    yp[c][k] = fmaf(g0, xc[c][k], yp[c][k]);
-                                    C.y[0][c][k] = fmaf(g1, xc[c][k], C.y[0][c][k]);
-                                } else {
-                                    neu[c][k] = fmaf(g1, C.y[1][c][k], g0 * C.y[0][c][k]);
-                                    C.y[0][c][k] = fmaf(g0, xc[c][k], C.y[0][c][k]);
-                                    C.y[1][c][k] = fmaf(g1, xc[c][k], C.y[1][c][k]);
-                                }
-                            }
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) g_st(A.SynNeg + (int64_t)C.tgt[r] * d, C.y[r]);
-                        acc_add(arow, neu);
-                        if constexpr (!DELTA) TEAM_BARRIER_DRAIN();  // one workgroup, deterministic: every pair's stores land before the next pair
-                    };
-                    if constexpr (PF == 2) {
-                        while (true) {
-                            if (!m_proc) break;
-                            step(q0, q2);
-                            if (!m_proc) break;
-                            step(q1, q0);
-                            if (!m_proc) break;
-                            step(q2, q1);
-                        }
-                    } else {
-                        while (true) {
-                            if (!m_proc) break;
-                            step(q0, q1);
-                            if (!m_proc) break;
-                            step(q1, q0);
-                        }
-                    }
-                    auto retire = [&](TeamSet<VEC, NV, NR> &Q) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int r = 0; r < NR; ++r)
-#pragma unroll
-                            for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(Q.y[r][c][k]));
-                    };
-                    retire(q0); retire(q1); if constexpr (PF == 2) retire(q2);
-                };
-                if (wv == 0) run(std::integral_constant<int, 1>{}, std::true_type{});
-                else run(std::integral_constant<int, 2>{}, std::false_type{});
-                if (wv == 0) g_st(pp, yp);
-            }
-
-            // ---- centre boundary -------------------------------------------------------------------------------------------------
-            stage_fin(pos + 1);
-            if constexpr (!DELTA) TEAM_BARRIER_DRAIN(); else TEAM_BARRIER();       // every pair of this centre has added its neu1e share
-            // fold the accumulators of the slots this centre used into the window rows (slot s by wavefront s % 3; the leaving slot by its writer)
-            for (int s = wv; s < S; s += TEAM_T) {
-                if (!((seen >> s) & 1u) || s == sX) continue;
-                float l[NV][VEC], ax[NV][VEC];
-                lds_ld(rowsL + (size_t)s * RW, l); acc_ld(acc + (size_t)s * RW, ax);
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) l[c][k] += ax[c][k];
-                lds_st(rowsL + (size_t)s * RW, l);
-                acc_zero(acc + (size_t)s * RW);
-            }
-            if (sX >= 0) {
-                if (wv == 2) {
-                    float l[NV][VEC], ax[NV][VEC];
-                    lds_ld(rowsL + (size_t)sX * RW, l); acc_ld(acc + (size_t)sX * RW, ax);
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) l[c][k] += ax[c][k];
-                    acc_zero(acc + (size_t)sX * RW);
-                    if constexpr (DELTA) {
-                        float o[NV][VEC];
-                        lds_ld(rowsO + (size_t)sX * RW, o);
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) l[c][k] = rowG[c][k] + (l[c][k] - o[c][k]);
-                    }
-                    g_st(A.SynPos + (int64_t)vX * d, l);
-                }
-                if (lane == sX) slot_node = -1;
-            }
-            if (sE >= 0 && wv == 1) {
-                lds_st(rowsL + (size_t)sE * RW, rowE);
-                if constexpr (DELTA) lds_st(rowsO + (size_t)sE * RW, rowE);
-            }
-            if (wv == 0) { const uint32_t m = special_mask(pos + 1); if (lane == 0) ctl[(pos + 1) & 1] = (int32_t)m; }
-            if constexpr (!DELTA) TEAM_BARRIER_DRAIN(); else TEAM_BARRIER();
-        }
-        // the tokens still in the window leave (every accumulator is folded: the last boundary ran with the full `seen` mask of its centre,
-        // and a slot untouched since an earlier boundary was folded there)
-        for (int q = (len - R > 0 ? len - R : 0); q < len; ++q) {
-            const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
-            if (v < 0) continue;
-            const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node == v));
-            const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
-            if (lane == s) slot_ref = refc;
-            if (refc != 0) continue;
-            if (q % TEAM_T == wv) {
-                float l[NV][VEC];
-                lds_ld(rowsL + (size_t)s * RW, l);
-                if constexpr (DELTA) {
-                    float o[NV][VEC], g[NV][VEC];
-                    lds_ld(rowsO + (size_t)s * RW, o);
-                    g_ld(A.SynPos + (int64_t)v * d, g);
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) l[c][k] = g[c][k] + (l[c][k] - o[c][k]);
-                }
-                g_st(A.SynPos + (int64_t)v * d, l);
-            }
-            if (lane == s) slot_node = -1;
-        }
-        if constexpr (!DELTA) TEAM_BARRIER_DRAIN();
-    }
-    if (wv == 0 && lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
-}
-
-template <int VEC, int NV, bool DELTA>
-void launch_sgns_team(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
-{
-    if (A.team_prefetch >= 2) hipLaunchKernelGGL((sgns_team_kernel<VEC, NV, DELTA, 2>), dim3(blocks), dim3(threads), lds, s, A);
-    else hipLaunchKernelGGL((sgns_team_kernel<VEC, NV, DELTA, 1>), dim3(blocks), dim3(threads), lds, s, A);
-}
-
 using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
 template <int VEC, int NV>
 void launch_sgns(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
@@ -1448,7 +1001,15 @@ template <int VEC, int NV, bool DELTA>
 void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
 {
     const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window;
-    if (full && allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true>), dim3(blocks), dim3(threads), lds, s, A);
+    if constexpr (DELTA) {
+        if (full && allc && A.reload) {
+            if (A.prefetch == 1) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, true, true, true, 1, true>), dim3(blocks), dim3(threads), lds, s, A);
+            else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, true, true, true, 2, true>), dim3(blocks), dim3(threads), lds, s, A);
+            return;
+        }
+    }
+    if (full && allc && A.prefetch == 1) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true, 1>), dim3(blocks), dim3(threads), lds, s, A);
+    else if (full && allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true>), dim3(blocks), dim3(threads), lds, s, A);
     else if (full) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, false>), dim3(blocks), dim3(threads), lds, s, A);
     else if (allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, true>), dim3(blocks), dim3(threads), lds, s, A);
     else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, false>), dim3(blocks), dim3(threads), lds, s, A);
@@ -1463,12 +1024,6 @@ sgns_fn pick_sgns_win(int d)
     const int nv = (d + 63) / 64;
     return nv <= 1 ? launch_sgns_win<1, 1, DELTA> : nv <= 2 ? launch_sgns_win<1, 2, DELTA> : nv <= 4 ? launch_sgns_win<1, 4, DELTA> : nullptr;
 }
-template <bool DELTA>
-sgns_fn pick_sgns_team(int d)     // d == NV * VEC * 64 only
-{
-    return d == 128 ? launch_sgns_team<2, 1, DELTA> : d == 256 ? launch_sgns_team<2, 2, DELTA> : d == 64 ? launch_sgns_team<1, 1, DELTA> : nullptr;
-}
-inline bool nsamp_ok_team(int window) { return 2 * window * SGNS_NEG <= 64 * TEAM_T; }    // one negative sample per thread
 // floats one cached row occupies in LDS (the wave's footprint of a row, see sgns_win_kernel)
 int sgns_win_row_floats(int d) { return d % 2 == 0 ? ((d + 127) / 128) * 128 : ((d + 63) / 64) * 64; }
 
@@ -1869,8 +1424,8 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     if (const char *e = getenv("GEMHIP_SGNS_MAX_WAVES")) h->max_waves = std::max(0, atoi(e));
     if (const char *e = getenv("GEMHIP_SGNS_CACHE_R")) h->cache_radius = std::min(31, std::max(-1, atoi(e)));
     if (const char *e = getenv("GEMHIP_SGNS_CACHE_DELTA")) h->cache_delta = std::min(1, std::max(-1, atoi(e)));
-    if (const char *e = getenv("GEMHIP_SGNS_TEAM")) h->team_mode = std::min(1, std::max(-1, atoi(e)));
-    if (const char *e = getenv("GEMHIP_SGNS_TEAM_PF")) h->team_prefetch = std::min(2, std::max(1, atoi(e)));
+    if (const char *e = getenv("GEMHIP_SGNS_PREFETCH")) h->prefetch = std::min(2, std::max(1, atoi(e)));
+    if (const char *e = getenv("GEMHIP_SGNS_RELOAD")) h->reload = atoi(e) != 0;
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
     hipError_t e = hipMalloc((void **)&h->d_row_ptr, (n + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMemcpy(h->d_row_ptr, row_ptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
@@ -2274,7 +1829,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.token_offset = token_offset; A.walk_id_offset = h->walk_id_offset; A.epoch = epoch;
     A.UT = h->d_UT; A.KT = h->d_KT; A.UK = h->d_UK; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
-    A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.team_prefetch = h->team_prefetch;
+    A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->prefetch; A.reload = h->reload;
     const bool deterministic = (flags & 4) != 0;
     // Hogwild concurrency on small graphs: every in-flight wavefront has rows open (read-modify-write); when the open rows approach n,
     // concurrent writers overwrite each other's updates and the embedding degrades (tests/test_n2v_gpu.py).  sgns_kernel: n/128.
@@ -2294,41 +1849,8 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
         const int rw = sgns_win_row_floats(h->d);
         const size_t ints = (size_t)((h->walk_len + 4 * window * SGNS_NEG + 3) & ~3);
         auto lds_bytes = [&](bool delta) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * (delta ? 2 : 1) + 1) * rw * sizeof(float); };
-        // ---- team kernel: three wavefronts per walk (Hogwild launches by default; team_mode 1 also runs the deterministic launch on it)
-        const bool team_fits = rw == h->d && R >= window && nsamp_ok_team(window) && 2 * R + 2 <= 32 && 2 * window <= 32 && h->team_mode != 0
-                               && (h->team_mode == 1 || !deterministic);
-        if (team_fits) {
-            const bool delta_t = !deterministic && mode != 0;
-            sgns_fn fnt = delta_t ? pick_sgns_team<true>(h->d) : pick_sgns_team<false>(h->d);
-            const int S = 2 * R + 2;
-            const size_t ints_t = (size_t)((h->walk_len + 3) & ~3) + 2 * (size_t)((2 * window * SGNS_NEG + 3) & ~3) + 4;
-            const size_t lds_t = ints_t * sizeof(int32_t) + (size_t)S * rw * sizeof(float) * (delta_t ? 3 : 2);
-            if (fnt != nullptr && lds_t <= 64 * 1024) {
-                int64_t teams = 1;
-                if (!deterministic) {
-                    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(4, (int64_t)(160 * 1024) / (int64_t)(lds_t + 1024)));   // <= 168 VGPRs: 3 wavefronts per SIMD
-                    // concurrent WALKS are what costs quality (lost updates on the negative rows each walk keeps open, header of sgns_team_kernel):
-                    // same bounds as sgns_win_kernel's wavefronts
-                    const int64_t hog_t = h->max_waves > 0 ? h->max_waves
-                                        : h->n >= 8192 ? hog_cap : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 2)));
-                    teams = std::min<int64_t>(std::min<int64_t>(hog_t, 256 * per_cu), walk_hi - walk_lo);
-                }
-                A.nwaves = (int32_t)teams; A.cache_radius = R;
-                const size_t need_t = (size_t)teams * TEAM_T * rw * sizeof(float);
-                if (need_t > h->dummy_bytes) {
-                    if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
-                    GEMHIP_CHECK(hipMalloc(&h->d_dummy, need_t));
-                    GEMHIP_CHECK(hipMemset(h->d_dummy, 0, need_t));
-                    h->dummy_bytes = need_t;
-                }
-                A.dummy = h->d_dummy;
-                fnt(A, (int)teams, 64 * TEAM_T, lds_t, (hipStream_t)stream);
-                GEMHIP_CHECK(hipGetLastError());
-                return GEMHIP_OK;
-            }
-        }
         int64_t waves = 1;
-        bool delta = false;
+        bool delta = deterministic && mode == 1;          // (cache_delta 1 on a deterministic launch: the Hogwild code path on ONE wavefront, for the parity tests)
         if (!deterministic) {
             delta = mode != 0;
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(delta) + 512)));   // 184 VGPRs: 2 per SIMD
@@ -2427,11 +1949,11 @@ extern "C" int gemhip_test_wave_sum6(const float *in_host, float *out_host)
     return GEMHIP_OK;
 }
 
-extern "C" int gemhip_sgns_set_team(gemhip_n2v_t h, int32_t mode, int32_t prefetch)
+extern "C" int gemhip_sgns_set_hogwild(gemhip_n2v_t h, int32_t prefetch_pairs, int32_t reload_on_update)
 {
-    GEMHIP_REQUIRE(h && mode >= -1 && mode <= 1 && prefetch >= 0 && prefetch <= 2, "sgns_set_team: bad arguments");
-    h->team_mode = mode;
-    if (prefetch) h->team_prefetch = prefetch;
+    GEMHIP_REQUIRE(h && prefetch_pairs >= 0 && prefetch_pairs <= 2 && reload_on_update >= -1 && reload_on_update <= 1, "sgns_set_hogwild: bad arguments");
+    if (prefetch_pairs) h->prefetch = prefetch_pairs;
+    if (reload_on_update >= 0) h->reload = reload_on_update;
     return GEMHIP_OK;
 }
 

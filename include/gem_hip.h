@@ -191,11 +191,12 @@ int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves);
  * (-1 = auto = min(window, 10); 0 = off); delta_writeback: a row leaves the window as `row_now + (working - loaded)`
  * so that concurrent wavefronts' updates survive (1), or is written back as is (0); -1 = auto (1 unless one wavefront trains). */
 int gemhip_sgns_set_window_cache(gemhip_n2v_t h, int32_t radius, int32_t delta_writeback);
-/* Team kernel of TrainModel (three wavefronts of one workgroup train one walk; no reference counterpart: the binary's unit of Hogwild
- * is an OpenMP thread).  mode: -1 auto = Hogwild launches where it applies (d in {64,128,256}, window <= 10), 0 = never (window
- * kernel), 1 = also for GEMHIP_N2V_DETERMINISTIC launches (one workgroup, exactly sequential up to the fp32 summation order of neu1e).
- * prefetch: 1 or 2 pairs of negative rows requested ahead (0 = keep). */
-int gemhip_sgns_set_team(gemhip_n2v_t h, int32_t mode, int32_t prefetch);
+/* How a Hogwild launch treats the rows it shares with other wavefronts (no reference counterpart: the binary's threads race on plain
+ * doubles).  prefetch_pairs: (centre, context) pairs whose five negative rows are requested ahead of their use (2 default, 1; 0 = keep).
+ * reload_on_update (1 default, 0, -1 = keep): apply a negative row's update to the row as it is at store time -- a second fetch right
+ * after the dot products, `row_now + g * xc` -- and the centre's positive row as an atomic add of what the centre changed, instead of
+ * storing copies that are (prefetch_pairs + 1) pair steps / one centre old and overwrite whatever other wavefronts stored meanwhile. */
+int gemhip_sgns_set_hogwild(gemhip_n2v_t h, int32_t prefetch_pairs, int32_t reload_on_update);
 /* Building block of the SGNS kernel, exposed for its own parity test: in[64][6] per-lane partial sums -> out[64], lane l
  * receiving the wave total of value (l & 4) ? 4 + (l & 1) : (l & 3). */
 int gemhip_test_wave_sum6(const float *in_host, float *out_host);

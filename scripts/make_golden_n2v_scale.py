@@ -31,12 +31,18 @@ ap.add_argument('--q', type=float, default=1.0)
 ap.add_argument('--sample', type=int, default=1024)
 ap.add_argument('--tag', default=None)
 ap.add_argument('--workdir', default=None)
+ap.add_argument('--rmat-scale', type=int, default=0, help='R-MAT graph (gem_amd.graph.rmat_graph(scale, edges, seed)) instead of the SBM')
 ap.add_argument('--save-emb', default=None, help='write the trained embedding (float32 .npy) here so a later run can re-score a bigger sample')
 ap.add_argument('--load-emb', default=None, help='skip training, score this saved embedding')
 a = ap.parse_args()
 PARAMS = dict(n=a.nodes, edges=a.edges, blocks=a.blocks, seed=a.seed, d=128, walk_len=80, num_walks=10, window=10, p=a.p, q=a.q)
 
-g = sbm_graph(a.nodes, a.edges, a.blocks, a.seed)
+if a.rmat_scale:
+    from gem_amd.graph import rmat_graph
+    g = rmat_graph(a.rmat_scale, a.edges, a.seed)
+    PARAMS['rmat_scale'] = a.rmat_scale; PARAMS['n'] = g.n
+else:
+    g = sbm_graph(a.nodes, a.edges, a.blocks, a.seed)
 n = g.n
 nodes = np.random.RandomState(0).choice(n, size=min(a.sample, n), replace=False)
 tmp = a.workdir or tempfile.mkdtemp(prefix='n2vgold_')

@@ -15,6 +15,7 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
+  if [ -n "${PMC_GROUPS:-}" ] && [[ " $PMC_GROUPS " != *" $i "* ]]; then i=$((i+1)); continue; fi
   d=gpurun_out/pmc/${tag}_g$i
   rm -rf "$d"
   timeout 600 rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$d" -o run -- "$@" > "$d.log" 2>&1

@@ -138,46 +138,18 @@ def test_sgns_deterministic_matches_oracle(gname, d, window, l, epochs, flags, r
     dev.close()
 
 
-@pytest.mark.parametrize('pf', [1, 2])
-@pytest.mark.parametrize('gname,d,window,l,epochs,flags', [('karate', 128, 10, 80, 1, SNAP), ('karate', 64, 3, 20, 2, 8), ('karate', 256, 2, 10, 1, SNAP),
-                                                           ('sbm1024', 128, 10, 40, 1, SNAP), ('sbm1024', 64, 5, 24, 1, 8), ('karate', 128, 7, 30, 1, 9)])
-def test_sgns_team_kernel_deterministic_matches_oracle(gname, d, window, l, epochs, flags, pf, request):
-    """sgns_team_kernel (three wavefronts per walk: the Hogwild default at d in {64, 128, 256}) forced onto the deterministic launch
-    (gemhip_sgns_set_team mode 1): ONE workgroup in walk order == TrainModel single-threaded, up to the fp32 summation order of neu1e
-    (three partial sums added to the LDS accumulator in arrival order).  karate (34 nodes) makes nearly every pair take the
-    collision paths (repeated context nodes, repeated / recently used targets, targets equal to the centre word); sbm1024 mostly the
-    independent-targets path; flags 8 / 9: short walks padded with -1 / with node 0 (zero-padded tails repeat the centre word)."""
-    G = request.getfixturevalue(gname)
-    n, src, dst, w, _ = edge_arrays(G)
-    dev = Dev(n, src, dst, w)
-    r = 10 if gname == 'karate' else 1
-    walks = dev.walks(1.0, 1.0, r, l, 21, flags)
-    if gname == 'sbm1024':
-        walks = walks[:96]
-        _hip.check(dev.L.gemhip_n2v_set_walks(dev.h, _hip.ptr(walks, C.c_int32), walks.shape[0], l, 0))
-    c, UT, KT = dev.unigram()
-    _hip.check(dev.L.gemhip_sgns_set_team(dev.h, 1, pf))
-    P, N = dev.sgns(d, window, epochs, 21, flags | 4)
-    Po, No = oracle.sgns_init(n, d, 21)
-    tot = walks.size
-    for ep in range(epochs):
-        oracle.sgns_train(walks, window, 0.025, epochs, ep, tot, ep * tot, 0, UT, KT, 21, flags, Po, No)
-    for got, want in ((P, Po), (N, No)):
-        scale = float(np.abs(want).max())
-        assert float(np.abs(got - want).max()) <= 2e-4 * scale + 1e-6, (np.abs(got - want).max(), scale)
-    pairs = C.c_int64(); _hip.check(dev.L.gemhip_sgns_pairs(dev.h, C.byref(pairs), 0))
-    assert pairs.value == epochs * len(oracle.sgns_pairs(walks, window, 0, 0, 21)) or epochs > 1      # the unit of the roofline: every pair once
-    dev.close()
-
-
 @pytest.mark.parametrize('gname,d,window,l,radius,delta', [('karate', 8, 10, 80, -1, 0), ('karate', 8, 10, 80, 3, 0), ('karate', 7, 4, 30, 2, 0),
                                                            ('sbm1024', 128, 10, 40, -1, 0), ('sbm1024', 128, 10, 40, 4, 0),
                                                            ('sbm1024', 128, 10, 40, -1, 1), ('karate', 256, 5, 20, 5, 1),
                                                            ('karate', 16, 12, 9, -1, 0)])
-def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, delta, request):
+@pytest.mark.parametrize('hog', [(2, 1), (1, 1), (2, 0)])
+def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, delta, hog, request):
     """The LDS-window kernel (default) and the round-1 kernel (flag 128) are the same algorithm: one wavefront in walk order gives
     the same tables up to fp32 summation order (2e-4, the bar of the oracle test), whatever the cached radius and whether rows
-    leave the window as they are (delta=0) or as row_now + (working - loaded) (what multi-wave launches use)."""
+    leave the window as they are (delta=0) or as row_now + (working - loaded) (what multi-wave launches use).  delta=1 runs the
+    HOGWILD instantiation on the one wavefront -- with `hog` = (pairs of negative rows requested ahead, reload-on-update): negative rows
+    updated as `row_now + g * xc` after a second fetch and the centre row by an atomic add of its change (gemhip_sgns_set_hogwild), or
+    stored from the prefetched copies -- every combination the multi-wave launches can take (where d and the radius allow them)."""
     G = request.getfixturevalue(gname)
     n, src, dst, w, _ = edge_arrays(G)
     dev = Dev(n, src, dst, w)
@@ -188,6 +160,7 @@ def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, del
     dev.unigram()
     P0, N0 = dev.sgns(d, window, 1, 5, SNAP | 4 | _hip.N2V_NO_WINDOW_CACHE)
     _hip.check(dev.L.gemhip_sgns_set_window_cache(dev.h, radius, delta))
+    _hip.check(dev.L.gemhip_sgns_set_hogwild(dev.h, hog[0], hog[1]))
     P1, N1 = dev.sgns(d, window, 1, 5, SNAP | 4)
     for a, b in ((P0, P1), (N0, N1)):          # same algorithm; the fast path sums the six dot products in a different tree order
         assert float(np.abs(a - b).max()) <= 2e-4 * float(np.abs(a).max()) + 1e-6
