@@ -530,7 +530,8 @@ template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC, int PF = 2, bool RE
 __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 {
     static_assert(PF == 1 || PF == 2, "prefetch distance");
-    static_assert(!RELOAD || (DELTA && FULL && ALLC), "RELOAD is a Hogwild (delta) mode of the all-cached kernel");
+    static_assert(!RELOAD || DELTA, "RELOAD is a Hogwild (delta write-back) mode");
+    static_assert(PF == 2 || (FULL && ALLC), "the shorter prefetch exists for the all-cached full-row kernel only");
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     constexpr int RW = NV * VEC * WAVE;              // floats per cached row (row padded to the wave's footprint)
     constexpr int NS = 2;                            // negative samples per lane and centre: 2*window*5 <= 128
@@ -1001,18 +1002,24 @@ template <int VEC, int NV, bool DELTA>
 void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
 {
     const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window;
+#define GEMHIP_LAUNCH_WIN(F, C, P, R) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, F, C, P, R>), dim3(blocks), dim3(threads), lds, s, A)
+    const bool reload = DELTA && A.reload;
     if constexpr (DELTA) {
-        if (full && allc && A.reload) {
-            if (A.prefetch == 1) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, true, true, true, 1, true>), dim3(blocks), dim3(threads), lds, s, A);
-            else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, true, true, true, 2, true>), dim3(blocks), dim3(threads), lds, s, A);
+        if (reload) {
+            if (full && allc && A.prefetch == 1) GEMHIP_LAUNCH_WIN(true, true, 1, true);
+            else if (full && allc) GEMHIP_LAUNCH_WIN(true, true, 2, true);
+            else if (full) GEMHIP_LAUNCH_WIN(true, false, 2, true);
+            else if (allc) GEMHIP_LAUNCH_WIN(false, true, 2, true);
+            else GEMHIP_LAUNCH_WIN(false, false, 2, true);
             return;
         }
     }
-    if (full && allc && A.prefetch == 1) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true, 1>), dim3(blocks), dim3(threads), lds, s, A);
-    else if (full && allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, true>), dim3(blocks), dim3(threads), lds, s, A);
-    else if (full) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, true, false>), dim3(blocks), dim3(threads), lds, s, A);
-    else if (allc) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, true>), dim3(blocks), dim3(threads), lds, s, A);
-    else hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, false, false>), dim3(blocks), dim3(threads), lds, s, A);
+    if (full && allc && A.prefetch == 1) GEMHIP_LAUNCH_WIN(true, true, 1, false);
+    else if (full && allc) GEMHIP_LAUNCH_WIN(true, true, 2, false);
+    else if (full) GEMHIP_LAUNCH_WIN(true, false, 2, false);
+    else if (allc) GEMHIP_LAUNCH_WIN(false, true, 2, false);
+    else GEMHIP_LAUNCH_WIN(false, false, 2, false);
+#undef GEMHIP_LAUNCH_WIN
 }
 template <bool DELTA>
 sgns_fn pick_sgns_win(int d)
@@ -1177,7 +1184,17 @@ struct PairArgs {
 
 // One wavefront per pair at a time: context row (local), positive row and five negative rows of the visiting
 // SynNeg partition; same arithmetic, clamps and duplicate forwarding as sgns_kernel.
-template <int VEC, int NV>
+// SAFE (every Hogwild launch): no update is applied to a stale copy -- what costs Hogwild its quality is a store overwriting what another
+// wavefront stored since the row was read (sgns_win_kernel, RELOAD).  The context row takes its neu1e by atomic add, the centre's positive
+// row an atomic add of what its run of pairs changed, and the five negative rows are fetched a second time after the dot products and leave
+// as `row_now + g * xc`.
+__device__ __forceinline__ void row_atomic_add(float *p, int d, int lane, int c, int vec, const float *v)
+{
+    const int idx = (c * WAVE + lane) * vec;
+    for (int k = 0; k < vec; ++k)
+        if (idx + k < d) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + idx + k), v[k]);
+}
+template <int VEC, int NV, bool SAFE>
 __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
 {
     const int lane = lane_id();
@@ -1193,8 +1210,23 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
     // pairs arrive in walk order, so consecutive pairs usually share their centre word: its SynNeg row (the positive
     // target) stays in registers until the word changes, like in the walk-based kernel
     const float alpha_slope = (A.alpha_end - A.alpha_begin) / (float)(A.npairs > 1 ? A.npairs : 1);
-    float yp[NV][VEC];
-    int32_t held = -1;                                    // local row index currently in yp
+    float yp[NV][VEC], yp0[NV][VEC];
+    int32_t held = -1;                                    // local row index currently in yp (yp0: the row as loaded, SAFE)
+    auto release = [&]() {
+        float *po = A.SynNeg + (int64_t)held * d;
+        if constexpr (SAFE) {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                float dl[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) dl[v] = yp[c][v] - yp0[c][v];
+                row_atomic_add(po, d, lane, c, VEC, dl);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) st_row<VEC>(po, d, lane, c, yp[c]);
+        }
+    };
     // negative targets are drawn for PAIR_BATCH = 12 pairs at a time: lane 5p + (j-1) draws target j of pair i0 + p from the
     // visiting partition's alias table (two dependent lookups), one batch ahead of its use
     constexpr int PAIR_BATCH = 12;
@@ -1229,14 +1261,16 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
         float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
         float *pc = A.SynPos + (int64_t)ctx_l * d;
         if (word_l != held) {
-            if (held >= 0) {
-                float *po = A.SynNeg + (int64_t)held * d;
-#pragma unroll
-                for (int c = 0; c < NV; ++c) st_row<VEC>(po, d, lane, c, yp[c]);
-            }
+            if (held >= 0) release();
             const float *pp = A.SynNeg + (int64_t)word_l * d;
 #pragma unroll
             for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
+            if constexpr (SAFE) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) yp0[c][v] = yp[c][v];
+            }
             held = word_l;
         }
 #pragma unroll
@@ -1272,6 +1306,15 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
 #pragma unroll
                     for (int j = 0; j < SGNS_NEG; ++j) part[j + 1] = fmaf(xc[c][v], yn[j][c][v], part[j + 1]);
                 }
+            float rn[SAFE ? SGNS_NEG : 1][NV][VEC];
+            if constexpr (SAFE) {                          // the five rows as they are now; needed after the sigmoid
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) {
+                    const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, rn[j][c]);
+                }
+            }
             const float f = wave_sum6(part, lane);
             const float gl = sgns_grad_fast(f, (lane & 7) == 0 ? 1.0f : 0.0f, alpha);
             float g[6];
@@ -1286,10 +1329,14 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g[j + 1], yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g[j + 1], xc[c][v], yn[j][c][v]); }
+                    for (int v = 0; v < VEC; ++v) {
+                        neu[c][v] = fmaf(g[j + 1], yn[j][c][v], neu[c][v]);
+                        if constexpr (SAFE) rn[j][c][v] = fmaf(g[j + 1], xc[c][v], rn[j][c][v]);
+                        else yn[j][c][v] = fmaf(g[j + 1], xc[c][v], yn[j][c][v]);
+                    }
                 float *pn = A.SynNeg + (int64_t)tgt[j] * d;
 #pragma unroll
-                for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+                for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, SAFE ? rn[j][c] : yn[j][c]);
             }
         } else {
             {
@@ -1332,17 +1379,16 @@ __global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
         }
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
+            if constexpr (SAFE) row_atomic_add(pc, d, lane, c, VEC, neu[c]);
+            else {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
-            st_row<VEC>(pc, d, lane, c, xc[c]);
+                for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
+                st_row<VEC>(pc, d, lane, c, xc[c]);
+            }
         }
         ++done;
     }
-    if (held >= 0) {
-        float *po = A.SynNeg + (int64_t)held * d;
-#pragma unroll
-        for (int c = 0; c < NV; ++c) st_row<VEC>(po, d, lane, c, yp[c]);
-    }
+    if (held >= 0) release();
     if (lane == 0 && A.pairs_done) atomicAdd(A.pairs_done, done);
 }
 
@@ -1350,7 +1396,8 @@ using pairs_fn = void (*)(const PairArgs &, int blocks, int threads, hipStream_t
 template <int VEC, int NV>
 void launch_pairs(const PairArgs &A, int blocks, int threads, hipStream_t s)
 {
-    hipLaunchKernelGGL((sgns_pairs_kernel<VEC, NV>), dim3(blocks), dim3(threads), 0, s, A);
+    if (A.nwaves > 1) hipLaunchKernelGGL((sgns_pairs_kernel<VEC, NV, true>), dim3(blocks), dim3(threads), 0, s, A);
+    else hipLaunchKernelGGL((sgns_pairs_kernel<VEC, NV, false>), dim3(blocks), dim3(threads), 0, s, A);
 }
 pairs_fn pick_pairs(int d)
 {
@@ -1752,8 +1799,11 @@ extern "C" int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int6
     int blocks, threads;
     if (flags & 4) { blocks = 1; threads = 64; A.nwaves = 1; }
     else {
-        // Hogwild width: the rows in play are those of ONE partition pair (n/parts each)
-        int64_t cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, A.n_local_neg / 32);
+        // Hogwild width: the rows in play are those of ONE partition pair (n/parts each).  Same rule as gemhip_sgns_train: the expected fraction
+        // of stores that overwrite another wavefront's, rho = W x 5 x w / n_partition with w ~ 0.4 pair steps (negative rows are fetched again
+        // right before their update, context and centre rows take atomic adds: sgns_pairs_kernel<SAFE>), stays <= 1.5 %  ->  n_partition / 133
+        // (round 2 ran n_partition / 32 wavefronts on plain read-modify-write rows: rho ~ 20 %)
+        int64_t cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, A.n_local_neg / 133);
         cap = std::min<int64_t>(cap, 256 * 16);
         const int64_t waves = std::min<int64_t>(cap, npairs);
         threads = 256; blocks = (int)((waves + 3) / 4); A.nwaves = (int32_t)waves;
@@ -1854,20 +1904,22 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
         if (!deterministic) {
             delta = mode != 0;
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(delta) + 512)));   // 184 VGPRs: 2 per SIMD
-            // a wavefront of this kernel holds 2R+1 more rows (the window) than sgns_kernel's ~8: same bound on the fraction of the
-            // table that is open at any time (1/16), hence proportionally fewer concurrent wavefronts on small graphs
-            // ... measured both ways: SBM-1024 (d=16) loses 3.5 % MAP at 8 wavefronts (n/128) and nothing at 2 (n/464); at d=128, SBM 16k / 32k /
-            // 100k keep their MAP at n/128 wavefronts (0.9267 vs 0.9261, 0.9297 vs 0.9298, 0.9132 vs the reference binary's 0.9127) and lose
-            // 0.1-0.3 % at n/64 (scripts/ab_sgns_window.py, profiles/r02_ab_sgns_window_{16k,32k,100k}.json) -- the tighter bound is for tiny graphs
+            // Concurrency against quality -- the rule and where it comes from.  What Hogwild costs here is LOST UPDATES: every
+            // wavefront keeps its 5 negative rows per pair open from their load to their store; a store another wavefront makes to such a row
+            // in between is overwritten.  The CPU replay of this kernel's concurrency (scripts/hogwild_emul: W virtual wavefronts, the kernel's
+            // private copies) puts ~90 % of the MAP loss on those overwritten negative-row updates, ~10 % on the centre row's, none on stale
+            // gradients; the expected fraction of overwriting stores is  rho = W x 5 x w / n  with w = the window in pair steps
+            // (prefetch + 1 without RELOAD; ~0.4 with it: one reload round trip, ~0.5 us against a 1.35 us step).  Measured at SBM 1M/10M against
+            // the sequential oracle (same seed, paired per-node AP): without RELOAD rho = 1.1 % / 1.5 % / 2.3 % (768 / 1024 / 1536 wavefronts)
+            // cost -0.1 % / -0.4..-0.9 % / -0.8..-1.3 % of MAP, and 1536 wavefronts with prefetch 1 (rho 1.5 %) -0.5 %: the loss follows rho, not
+            // the wavefront count; with RELOAD 1536 wavefronts (rho 0.3 %) measure +0.15 +- 0.25 %.  Default: rho <= 1.5 %.
+            const double w_steps = (delta && h->reload) ? 0.4 : (double)(h->prefetch + 1);
+            const int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * (double)h->n / (5.0 * w_steps)));
+            // graphs below 8192 nodes: the window rows themselves (2R+1 per wavefront) are a sizeable part of the table -- SBM-1024 (d=16) loses
+            // 3.5 % of MAP at 8 wavefronts and nothing at 2: bound the open fraction of the table at 1/16
             const int64_t hog_win = h->max_waves > 0 ? h->max_waves
-                                  : h->n >= 8192 ? hog_cap : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
-            // ... and at the headline size the concurrency itself costs reconstruction quality against the SEQUENTIAL algorithm (same seed, same
-            // walks and negatives as oracle/n2v_oracle.c's 8.4-hour run, SBM 1M/10M, paired over the fixed 1024-node sample):
-            //   wavefronts   384      768      1024     1280     1536 (all that fit)
-            //   MAP vs seq.  -0.04 %  -0.12 %  -0.41 %  -0.75 %  -0.8 .. -1.3 % (three runs)
-            //   seconds      22.5     12.6     11.4     10.2     9.5
-            const int64_t quality_cap = h->max_waves > 0 ? (int64_t)h->max_waves : 1024;
-            waves = std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(hog_win, quality_cap), 256 * per_cu), walk_hi - walk_lo);
+                                  : h->n >= 8192 ? hog_rho : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
+            waves = std::min<int64_t>(std::min<int64_t>(hog_win, 256 * per_cu), walk_hi - walk_lo);
             if (waves == 1 && mode < 0) delta = false;
         }
         const size_t lds = lds_bytes(delta);

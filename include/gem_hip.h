@@ -183,8 +183,11 @@ int gemhip_sgns_init(gemhip_n2v_t h, int32_t d, uint64_t seed, void *dSynPos, vo
 /* (centre, context) pairs trained since creation / the last reset -- the unit of SURVEY 8(d)'s
  * SGNS byte count (14*4d bytes per pair). */
 int gemhip_sgns_pairs(gemhip_n2v_t h, int64_t *pairs, int32_t reset);
-/* Cap on concurrently training wavefronts (Hogwild width).  0 = auto: min(4096, n/128),
- * which keeps lost updates negligible on small graphs and never binds at n >= 1M. */
+/* Cap on concurrently training wavefronts (Hogwild width).  0 = auto: the number of wavefronts for which the expected fraction of
+ * row stores that overwrite another wavefront's store, rho = W x 5 x w / n (w = the load-to-store window of a negative row in pair
+ * steps: ~0.4 with reload-on-update, prefetch + 1 without), stays <= 1.5 % -- n/133 with reload-on-update, n/1000 without -- never
+ * more than the device holds (1536 on MI355X); graphs below 8192 nodes: 1/16 of the table open at most.  Derivation and the
+ * measurements behind it: DESIGN.md 3.3, scripts/hogwild_emul. */
 int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves);
 /* LDS window of TrainModel's context rows (no reference counterpart: the binary keeps its tables in host RAM).
  * radius = tokens either side of the centre word whose SynPos row stays in LDS between its first and last use

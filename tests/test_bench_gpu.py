@@ -65,32 +65,45 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
 
 
 def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference():
-    """The same comparison at BASELINE's own size (SBM 1M/10M).  Reference runs take 8-10 h of CPU each (scripts/make_golden_n2v_scale.py
-    --nodes 1000000 --edges 10000000 --blocks 100 [--engine oracle]): committed is the sequential restatement's run
-    (tests/golden/n2v_ref_oracle_1000k.json, 30161 s; it lands on the binary's MAP to 0.3 % at 100k); the binary's own run is used too
-    once it is there.  Same seed as the oracle run -> same walks and negative draws, so the per-node AP difference is paired: its standard
-    error over the 1024 sampled nodes is ~0.4 % of the MAP, and that is the resolution of this check.  Measured: the gap
-    grows with the number of concurrent wavefronts (-0.04 % at 384 ... -1.1 % at 1536); at the default (1024) three runs gave -0.41 %,
-    -0.93 %, -0.89 %.  Asserted: the gap does not exceed north_star's 1 % by more than two standard errors of its own estimate
-    (and never 2 %)."""
-    refs = [(e, golden_path('n2v_ref_%s_1000k.json' % e)) for e in ('snap', 'oracle')]
-    refs = [(e, json.load(open(f))) for e, f in refs if os.path.exists(f)]
+    """north_star's parity clause at BASELINE's own size (SBM 1M/10M): MAP within 1 % of the reference -- a flat 1 %, no allowance.
+    Reference runs take 8-12 h of CPU each (scripts/make_golden_n2v_scale.py --nodes 1000000 --edges 10000000 --blocks 100): the
+    sequential restatement (tests/golden/n2v_ref_oracle_1000k*.json; it lands on the binary's MAP to 0.3 % at 100k) and, when its run has
+    finished, the race-free SNAP binary itself (n2v_ref_snap_1000k.json).
+      * oracle: the HIP path is run with the ORACLE'S SEED (same walks, same negative draws), so per-node AP differences are paired and what
+        remains is Hogwild: three runs, their MEAN relative gap must be inside +-1 %.  Measured with the round-3 default (all 1536 resident
+        wavefronts, reload-on-update): +0.36, -0.07, +0.51, -0.26 % (profiles/r03_ab_sgns_1m.jsonl), i.e. mean +0.1 %, run-to-run s.d.
+        0.35 %, plus 0.4 % (1024-node sample) / 0.2 % (4096) sampling error of the gap that the three runs share: the bar is > 2 s.d. away on
+        either side, P(flake) < 2 %.  (Round 2's default sat at -0.74 % and needed "+2 s.e.".)
+      * SNAP binary: its seed is time(), so the comparison is UNPAIRED in the walks: seed-to-seed the MAP of either implementation moves by
+        ~0.5 % (s.d.; HIP 0.498-0.508 over four seeds), so three HIP seeds are averaged against the binary's single run; the expected s.d. of
+        that gap is ~0.7 % even for identical algorithms, hence this leg asserts 2 % (a 1 % bar would flake in ~15 % of the runs) and bench.py
+        prints the measured gap (`quality.map_minus_reference_map`) for the record."""
+    refs = {e: golden_path(f) for e, f in (('snap', 'n2v_ref_snap_1000k.json'), ('oracle', 'n2v_ref_oracle_1000k_s4096.json'), ('oracle1k', 'n2v_ref_oracle_1000k.json'))}
+    refs = {e: json.load(open(f)) for e, f in refs.items() if os.path.exists(f)}
+    if 'oracle' in refs:
+        refs.pop('oracle1k', None)
+    elif 'oracle1k' in refs:
+        refs['oracle'] = refs.pop('oracle1k')
     if not refs:
         pytest.skip('no 1M/10M reference run committed yet')
-    pr = refs[0][1]['params']
+    pr = next(iter(refs.values()))['params']
     g = sbm_graph(pr['n'], pr['edges'], pr['blocks'], pr['seed'])
-    nodes = np.random.RandomState(0).choice(g.n, size=len(refs[0][1]['ap']), replace=False)
-    m = node2vec(d=pr['d'], max_iter=1, walk_len=pr['walk_len'], num_walks=pr['num_walks'], con_size=pr['window'], ret_p=1, inout_p=1,
-                 seed=20260923)
-    X = m.learn_embedding(graph=g, is_weighted=True, no_python=True)
-    ap = gr.sampled_ap_gpu(g, None, X, nodes)
-    for engine, ref in refs:
-        d = ap - np.asarray(ref['ap'])
-        se = d.std(ddof=1) / np.sqrt(len(d))
-        assert d.mean() >= -(0.01 * ref['MAP'] + 2.0 * se), (engine, ap.mean(), ref['MAP'], d.mean(), se)
-        assert d.mean() <= 0.01 * ref['MAP'] + 2.0 * se, (engine, ap.mean(), ref['MAP'], d.mean(), se)
-        if engine == 'oracle':                      # paired run (same seed): also a hard 2 % ceiling; the binary's draws are its own (unpaired: se ~1.6 %)
-            assert abs(ap.mean() - ref['MAP']) <= 0.02 * ref['MAP']
+    nmax = max(len(r['ap']) for r in refs.values())
+    nodes = np.random.RandomState(0).choice(g.n, size=nmax, replace=False)            # (a smaller golden sample is a prefix of it)
+
+    def run(seed):
+        m = node2vec(d=pr['d'], max_iter=1, walk_len=pr['walk_len'], num_walks=pr['num_walks'], con_size=pr['window'], ret_p=1, inout_p=1, seed=seed)
+        return gr.sampled_ap_gpu(g, None, m.learn_embedding(graph=g, is_weighted=True, no_python=True), nodes)
+    if 'oracle' in refs:
+        ref = refs['oracle']
+        k = len(ref['ap'])
+        gaps = [float((run(20260923)[:k] - np.asarray(ref['ap'])).mean() / ref['MAP']) for _ in range(3)]
+        assert abs(np.mean(gaps)) <= 0.01, (gaps, ref['MAP'])
+    if 'snap' in refs:
+        ref = refs['snap']
+        k = len(ref['ap'])
+        gaps = [float((run(seed)[:k] - np.asarray(ref['ap'])).mean() / ref['MAP']) for seed in (1, 2, 3)]
+        assert abs(np.mean(gaps)) <= 0.02, (gaps, ref['MAP'])
 
 
 def test_node2vec_map_at_100k_within_one_percent_of_the_reference_binary():
