@@ -98,7 +98,10 @@ class GFWorkload(object):
         Xb = Xa.clone()
         r0, r1 = rank * (n_pad // world), min((rank + 1) * (n_pad // world), n)
         self.b = multi_gpu.HipBackendGF(n, src, dst, None, self.d, r0, r1, Xa, Xb)
-        self.job = multi_gpu.GFSharded(self.b, comm, rank, world, n, src, dst)       # N>1: halo exchange per sweep, one gather at the end
+        # N>1: halo exchange after every `--gf-exchange-every`-th sweep (default 8: a 0.6 ms sweep cannot pay a ~1 ms exchange each time;
+        # other ranks' rows are then up to 7 sweeps stale -- block-Jacobi with delay; 1 = bit-identical to one GPU), one gather at the end
+        self.exchange_every = args.gf_exchange_every if world > 1 else 1
+        self.job = multi_gpu.GFSharded(self.b, comm, rank, world, n, src, dst, exchange_every=self.exchange_every)
         self.kernel_ms, self.launches = 0.0, 0
         log('[rank %d] GF plan: rows %d updates %d levels %d' % (rank, self.b.rows, self.b.updates, self.b.levels))
 
@@ -200,7 +203,8 @@ class GFWorkload(object):
     def phase_split(self, steps):
         comm = self.job.comm_seconds(reset=False)
         return {'exchange_seconds_per_sweep': comm / steps, 'exchange': 'halo all-to-all' if self.job.halo else 'all-gather',
-                'halo_rows_per_rank': self.job.halo_rows}
+                'exchange_every_sweeps': self.exchange_every, 'halo_rows_per_rank': self.job.halo_rows,
+                'note': 'exchange_every_sweeps > 1: rows of other ranks are up to that many sweeps - 1 stale (not the single-GPU result; 1 is bit-identical)'}
 
     def check(self):
         assert bool(torch.isfinite(self.last).all()), 'non-finite embedding'
@@ -551,6 +555,7 @@ def main():
     ap.add_argument('--inout-q', type=float, default=1.0, help='node2vec in-out parameter q (node2vec.py:41 -q:)')
     ap.add_argument('--gf-eta', type=float, default=1e-2)
     ap.add_argument('--gf-regu', type=float, default=1e-2)
+    ap.add_argument('--gf-exchange-every', type=int, default=8, help='N>1 GF: sweeps between halo exchanges (1 = exchange after every sweep: bit-identical to one GPU)')
     ap.add_argument('--hope-directed', action='store_true', help='hope: orient every undirected edge in one random direction (A != A^T: the general case of hope.py)')
     ap.add_argument('--episodes', type=int, default=64, help='N>1 node2vec: episodes of the partitioned schedule')
     ap.add_argument('--no-cpu-baseline', action='store_true')

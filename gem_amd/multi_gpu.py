@@ -130,9 +130,15 @@ class GFSharded(object):
     is a fraction of the full-table all-gather; without locality (R-MAT) the plan falls back to the all-gather.  `gather()`
     assembles the full table once at the end."""
 
-    def __init__(self, backend, comm, rank, world, n, src=None, dst=None):
+    def __init__(self, backend, comm, rank, world, n, src=None, dst=None, exchange_every=1):
         self.b, self.comm, self.rank, self.world = backend, comm, rank, world
         self.n = n
+        # exchange_every = s > 1: the halo crosses the fabric only after every s-th sweep; in between a rank keeps training against the
+        # last copy it received of the other ranks' rows (SURVEY 8e "or every s sweeps").  The result is then NOT the single-GPU one any
+        # more: rows of other ranks are up to s-1 sweeps stale (block-Jacobi with delay across ranks, Gauss-Seidel inside one) -- the
+        # difference is O(s * eta) per sweep relative to an update (tests/test_multi_gpu_cpu.py states it for the test graph).
+        self.exchange_every = max(1, int(exchange_every))
+        self._since = 0
         self.n_pad = (n + world - 1) // world * world
         self.block = self.n_pad // world
         self.r0 = rank * self.block
@@ -183,11 +189,20 @@ class GFSharded(object):
                 import torch
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if self.halo:
+            self._since += 1
+            if self.halo and self._since < self.exchange_every:
+                # no exchange after this sweep: the halo rows of the table just written are whatever they were two sweeps ago -- carry the
+                # last received copy over from the previous table (a device-local copy of the halo rows, no fabric traffic)
+                need_idx = self.halo[2]
+                old = self.b.X[self.b.cur ^ 1]
+                new.index_copy_(0, need_idx, old.index_select(0, need_idx))
+            elif self.halo:
+                self._since = 0
                 send_idx, send_counts, need_idx, need_counts = self.halo
                 recv = self.comm.all_to_all_rows(new.index_select(0, send_idx), send_counts, need_counts, cached=True)
                 new.index_copy_(0, need_idx, recv)
             else:
+                self._since = 0
                 self.gather(new)
             if timed:
                 e1.record()

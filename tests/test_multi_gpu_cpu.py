@@ -95,6 +95,17 @@ def _worker(rank, world, port, out):
     halo_used = bool(job.halo)
     halo_small = 0 < job.halo_rows[0] < 0.75 * job.block and job.halo_rows[world - 1] == 0   # dst > src: the last rank reads nobody
     ok_gf = ok_gf and halo_used and halo_small and bool(np.array_equal(job.gather(last).numpy()[:n], ref))
+    # exchange only after every 4th sweep (SURVEY 8e "or every s sweeps"): no longer the single-GPU result -- other ranks' rows are up to
+    # 3 sweeps stale -- but close: the statement of the parity cost on this graph (eta 0.05, 8 sweeps)
+    job = multi_gpu.GFSharded(None, comm, rank, world, n, src, dst, exchange_every=4)
+    job.b = OracleGF(n, src, dst, 8, job.r0, job.r1, X0p)
+    for _ in range(8):
+        last = job.sweep(0.05, 0.01)
+    ref8 = oracle.gf_train_f32(n, src, dst, None, 8, 0.05, 0.01, 8, X0)
+    got8 = job.gather(last).numpy()[:n]
+    moved = float(np.abs(ref8 - X0).max())
+    stale_rel = float(np.abs(got8 - ref8).max()) / moved
+    ok_gf = ok_gf and 0.0 < stale_rel < 0.15                 # measured 0.083 of the largest change 8 sweeps make at this (large) eta; > 0: it IS a different schedule
     # a graph without locality falls back to the all-gather
     rs = np.random.RandomState(1); s2 = np.sort(rs.randint(0, n, 20000)).astype(np.int32); d2 = rs.randint(0, n, 20000).astype(np.int32)   # rows visited in ascending order
     job = multi_gpu.GFSharded(None, comm, rank, world, n, s2, d2)
@@ -116,6 +127,7 @@ def _worker(rank, world, port, out):
         np.save(out, P.numpy())
         with open(out + '.flags', 'w') as fh:
             fh.write('%d %d %d %d %d' % (ok_gf, ok_counts, ok_same, job.lo, job.hi))
+        print('GF exchange_every=4: max deviation from the sequential sweeps = %.4f of the largest change' % stale_rel, flush=True)
     dist.destroy_process_group()
 
 
