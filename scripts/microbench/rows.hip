@@ -314,6 +314,18 @@ int main(int argc, char **argv)
     const uint32_t nrows = 2000000;       // 1 GB: SynPos + SynNeg of the headline config
     float *T, *sink;
     CK(hipMalloc(&T, (size_t)nrows * 512)); CK(hipMemset(T, 0, (size_t)nrows * 512)); CK(hipMalloc(&sink, 64));
+    if (argc > 1 && argv[1][0] == 'c') {
+        // PMC calibration (VERDICT r2 "missing" #6): three launches of KNOWN byte counts in exactly the SGNS / GF access pattern (random 512-byte rows
+        // of a 1 GB table, 8 bytes per lane, sc1), to be run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes):
+        // every launch moves rows x 512 B per direction; the table is 4x the Infinity Cache, so nearly every row load is an HBM read.
+        // Each variant is launched twice (iters/10 warm-up, then iters): expected bytes per dispatch are printed below.
+        const int waves = 256 * 6, U = 6, iters = 20000 / U;
+        printf("{\"calibration\": true, \"rows_small_launch\": %.0f, \"rows_big_launch\": %.0f, \"bytes_per_row\": 512}\n", (double)waves * (iters / 10) * U, (double)waves * iters * U);
+        run<0, M_LOAD, 6>("sc1_8B_load", T, nrows, sink, 6);
+        run<0, M_STORE, 6>("sc1_8B_store", T, nrows, sink, 6);
+        run<0, M_LOAD | M_STORE, 6>("sc1_8B_rmw", T, nrows, sink, 6);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'w') {
         int *G; CK(hipMalloc(&G, (size_t)(1u << 21) * 4)); CK(hipMemset(G, 0, (size_t)(1u << 21) * 4));
         for (int w : {6, 12}) {

@@ -1,0 +1,69 @@
+"""examples/run_sbm.py:66-72's exact hyper-parameters on the reference's own SBM-1024 graph (tests/data/sbm.gpickle, here
+tests/golden/sbm1024_*.npy), each model against its oracle: GraphFactorization(d=128, max_iter=1000, eta=1e-4, regu=1.0),
+HOPE(d=256, beta=0.01), node2vec(d=182, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1).  d = 182 is the one
+embedding width no other test uses (not a multiple of the 128-float row a wavefront moves: guarded tails in every row access, the
+LDS window padded to 256 floats)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import hope_oracle
+from gem_amd import _hip
+from gem_amd.embedding.gf import GraphFactorization
+from gem_amd.embedding.hope import HOPE
+from gem_amd.embedding.node2vec import node2vec
+from gem_amd.evaluation import reconstruction as gr
+from gem_amd.graph import edge_arrays
+from test_n2v_gpu import Dev, SNAP
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gf_run_sbm_setting_matches_the_fp32_oracle(sbm1024):
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    np.random.seed(11)
+    m = GraphFactorization(d=128, max_iter=1000, eta=1 * 10 ** -4, regu=1.0, data_set='sbm')
+    Y = m.learn_embedding(graph=sbm1024, edge_f=None, is_weighted=True, no_python=True)
+    GraphFactorization.hyper_params.pop('data_set', None)            # (GEM's ctor merges kwargs into the class-level dict)
+    np.random.seed(11)
+    X0 = (0.01 * np.random.randn(n, 128)).astype(np.float32)                 # gf.py:92 under the same numpy seed
+    Xo = oracle.gf_train_f32(n, src, dst, w, 128, 1e-4, 1.0, 1000, X0)
+    assert Y.dtype == np.float64 and Y.shape == (n, 128)
+    assert float(np.abs(Y - Xo).max()) <= 2e-5 * float(np.abs(Xo).max()) + 1e-7
+
+
+def test_hope_run_sbm_setting_matches_the_dense_oracle(sbm1024):
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    m = HOPE(d=256, beta=0.01)
+    Y = m.learn_embedding(graph=sbm1024, edge_f=None, is_weighted=True, no_python=True)
+    Xo, so = hope_oracle.hope_dense(hope_oracle.adjacency(n, src, dst, w), 0.01, 256)
+    k = 128
+    assert np.allclose(np.sort(m._sigma), np.sort(so), rtol=5e-5), np.abs(np.sort(m._sigma) / np.sort(so) - 1).max()
+    R = Y[:, :k] @ Y[:, k:].T; Ro = Xo[:, :k] @ Xo[:, k:].T
+    assert np.linalg.norm(R - Ro) <= 3e-3 * np.linalg.norm(Ro)
+
+
+def test_node2vec_run_sbm_setting_d182(sbm1024):
+    """(1) TrainModel at d = 182 on one wavefront in walk order against the sequential oracle (2e-4, a slice of the corpus); (2) the full
+    learn_embedding() call of run_sbm.py (Hogwild): reconstruction MAP against the sequential oracle's on the same seed -- the oracle's MAP at this
+    size moves by ~3 % between seeds and Hogwild adds ~2 %, the bar is 8 % like the other SBM-1024 Hogwild tests (P(flake) < 1e-3)."""
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    dev = Dev(n, src, dst, w)
+    walks = dev.walks(1.0, 1.0, 1, 40, 21, SNAP)[:64]
+    _hip.check(dev.L.gemhip_n2v_set_walks(dev.h, _hip.ptr(walks, C.c_int32), walks.shape[0], 40, 0))
+    c, UT, KT = dev.unigram()
+    P, N = dev.sgns(182, 10, 1, 21, SNAP | 4)
+    Po, No = oracle.sgns_init(n, 182, 21)
+    oracle.sgns_train(walks, 10, 0.025, 1, 0, walks.size, 0, 0, UT, KT, 21, SNAP, Po, No)
+    for got, want in ((P, Po), (N, No)):
+        assert float(np.abs(got - want).max()) <= 2e-4 * float(np.abs(want).max()) + 1e-6
+    dev.close()
+    m = node2vec(d=182, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1, data_set='sbm', seed=5)
+    Y = m.learn_embedding(graph=sbm1024, edge_f=None, is_weighted=True, no_python=True)
+    node2vec.hyper_params.pop('data_set', None)
+    MAP = gr.evaluateStaticGraphReconstruction(sbm1024, m, Y, None)[0]
+    Xs, _ = oracle.n2v_train(n, src, dst, w, 182, 80, 10, 10, 1, 1.0, 1.0, 5, SNAP)
+    MAPs = gr.evaluateStaticGraphReconstruction(sbm1024, m, Xs.astype(np.float64), None)[0]
+    assert abs(MAP - MAPs) <= 0.08 * MAPs, (MAP, MAPs)
