@@ -54,7 +54,8 @@ def pmc_traffic(kernel, key):
         if f.endswith('_pmc_traffic.json'):
             try:
                 best = json.load(open(os.path.join(pdir, f)))[kernel][key]
-                src = 'profiles/%s (separate rocprofv3 --pmc passes of the same kernel, replayed per unit; not measured in this run)' % f
+                src = ('profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel, calibrated on launches of known byte counts in the '
+                       'same access pattern, replayed per unit; not measured in this run)' % f)
             except (KeyError, ValueError):
                 pass
     return best, src
@@ -96,7 +97,7 @@ class GFWorkload(object):
 
     def __init__(self, args, rank, world, comm):
         self.name = '%s%dk_%dk_gf_d%d_eta%g_regu%g' % (args.graph, args.nodes // 1000, args.edges // 1000, args.d, args.gf_eta, args.gf_regu)
-        self.world, self.d = world, args.d
+        self.world, self.d, self.args = world, args.d, args
         # default: the "trainable" setting; --gf-eta 1e-4 --gf-regu 1.0 is examples/run_sbm.py:66's (same arithmetic per edge)
         self.eta, self.regu = args.gf_eta, args.gf_regu
         g = make_graph(args)
@@ -148,8 +149,9 @@ class GFWorkload(object):
         compulsory = (self.b.rows * 2 * 4 * self.d + self.b.updates * (4 * self.d + 8)) / self.b.levels
         ach = algo / avg_s / 1e9
         per_upd, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_update')
+        traffic = None if per_upd is None else per_upd * self.b.updates / self.b.levels
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': None if per_upd is None else per_upd * self.b.updates / self.b.levels, 'traffic_source': tsrc,
+                'traffic': traffic, 'traffic_source': tsrc, 'achieved_traffic_GBs': None if traffic is None else traffic / avg_s / 1e9,
                 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
                 'note': 'algorithmic = 1548 B/update (X_i r+w, X_j r per update); the kernel keeps X_i in registers for a whole row, '
                         'so its compulsory HBM bytes are %.3g per launch = %.0f GB/s' % (compulsory, compulsory / avg_s / 1e9)}
@@ -282,8 +284,10 @@ class N2VWorkload(object):
         ach = algo / avg_s / 1e9
         tokens = (self.job.hi - self.job.lo) * self.args.walk_len
         per_pair, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_pair')
+        traffic = None if per_pair is None else per_pair * pairs / launches
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': None if per_pair is None else per_pair * pairs / launches, 'traffic_source': tsrc, 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
+                'traffic': traffic, 'traffic_source': tsrc, 'achieved_traffic_GBs': None if traffic is None else traffic / avg_s / 1e9,
+                'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
                 'pairs_per_launch': pairs / launches, 'tokens_per_launch': tokens,
                 'sgns_fraction_of_step': ms / dev_ms_total,
                 'note': 'algorithmic = 7168+24 B per (centre,context) pair at d=128 (SynPos r+w, 6 x SynNeg r+w); the kernel keeps the '
@@ -444,8 +448,9 @@ class HopeWorkload(object):
         ach = algo / avg_s / 1e9
         gather = (4.0 * bavg + 8.0) * self.n_edges + 8.0 * self.n * bavg
         per_col, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_column')
+        traffic = None if per_col is None else per_col * bavg
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': None if per_col is None else per_col * bavg, 'traffic_source': tsrc,
+                'traffic': traffic, 'traffic_source': tsrc, 'achieved_traffic_GBs': None if traffic is None else traffic / avg_s / 1e9,
                 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6, 'spmm_launches_per_step': launches / self.calls,
                 'avg_block_columns': bavg, 'device_seconds_per_step': self.dev_s / self.calls, 'spmm_seconds_per_step': self.spmm_s / self.calls,
                 'host_eig_seconds_per_step': self.eig_s / self.calls, 'restarts': self.stats[5], 'katz_terms': self.stats[3],
