@@ -52,3 +52,26 @@ def test_round2_default_line_carries_all_three_workloads():
     assert c['all_cores']['MAP'] < c['single_thread_race_free']['MAP'] and abs(c['hip_map_same_sample'] - c['single_thread_race_free']['MAP']) < 0.02
     assert 'traffic_source' in j['roofline']
     assert j['quality']['nodes_sampled'] == 1024
+
+
+def test_round3_default_line_is_one_run_with_every_baseline_config():
+    """profiles/r03_bench_all.json = stdout of ONE un-profiled `python bench.py` on the GPU box (scripts/profile_round3.sh bench; nothing stitched):
+    node2vec headline (BASELINE configs[3]) + GF configs[1] and 1M/10M + HOPE configs[2] and its directed (general Katz) variant + configs[4]
+    (R-MAT scale 22: node2vec and GF).  Rooflines carry the calibrated real traffic next to the algorithmic rate; GF's cpu_baseline is the real
+    gf.cpp binary (kind "reference") with the C port and GEM's Python loop beside it; node2vec's quotes the committed full-size reference runs."""
+    j = json.load(open(os.path.join(ROOT, 'profiles', 'r03_bench_all.json')))
+    _check_line(j)
+    assert 'assembled_from' not in j
+    assert j['config']['workload'].startswith('sbm1000k_10000k_node2vec')
+    assert set(j['workloads']) == {'gf_sbm10k_100k_run_sbm_setting', 'gf_sbm1m_10m', 'hope_sbm100k_1m', 'hope_sbm100k_directed', 'node2vec_rmat22', 'gf_rmat22'}
+    for name, w in j['workloads'].items():
+        _check_line(w, with_cpu='rmat22' not in name)
+        assert w['roofline']['achieved_traffic_GBs'] is None or 0 < w['roofline']['achieved_traffic_GBs'] < 8000.0
+    assert j['workloads']['hope_sbm100k_directed']['roofline']['solver'] == 'block_krylov'
+    assert j['workloads']['hope_sbm100k_1m']['roofline']['solver'] == 'symmetric_chebyshev_filter'
+    g = j['workloads']['gf_sbm1m_10m']['cpu_baseline']
+    assert g['kind'] == 'reference' and g['reference_binary']['loop_only_edges_per_s'] > 0 and g['python_loop']['edges_per_s'] > 0 and g['c_port']['edges_per_s'] > 0
+    assert any(r['nodes'] == 1000000 for r in j['cpu_baseline']['committed_full_size_runs'])
+    q = j['quality']
+    assert q['oracle_map'] and abs(q['map_minus_oracle_map']) <= 0.01 * q['oracle_map']          # north_star: MAP within 1 % (paired with the sequential algorithm)
+    assert 0.5 < j['roofline']['frac'] < 1.0 and j['roofline']['achieved_traffic_GBs'] < 8000.0
