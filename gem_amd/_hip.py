@@ -92,6 +92,7 @@ _SIGS = {
     'gemhip_n2v_set_max_waves': (C.c_int, [C.c_void_p, C.c_int32]),
     'gemhip_sgns_set_window_cache': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_sgns_set_hogwild': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    'gemhip_sgns_set_hot_rows': (C.c_int, [C.c_void_p, C.c_int32]),
     'gemhip_test_wave_sum6': (C.c_int, [f32p, f32p]),
     'gemhip_sgns_set_tables': (C.c_int, [C.c_void_p, f32p, f32p]),
     'gemhip_sgns_get_tables': (C.c_int, [C.c_void_p, f32p, f32p]),

@@ -90,6 +90,10 @@ struct gemhip_n2v {
     int32_t cache_delta = -1;         // -1 auto, 0 overwrite on leave, 1 delta write-back
     int32_t prefetch = 2;             // pairs whose negative rows are requested ahead: 2 (default) or 1 (d == 64/128/256.., whole window cached)
     int32_t reload = 1;               // Hogwild launches: update negative rows as they are at store time (second fetch) and the centre row by atomic add
+    int32_t hot_count = -1;           // nodes with at least this many tokens never enter the LDS window: -1 auto (tokens / ((W-1) x (2R+1))), 0 off
+    // vocabulary statistics (gemhip_n2v_build_unigram*): how concentrated the row traffic is
+    double vocab_total = 0.0, vocab_max = 0.0;
+    double n_eff_neg = 0.0;           // 1 / sum_v q_v^2, q = unigram^0.75 distribution: the table size a uniform graph with the same collision rate would have
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
     unsigned long long *d_bcnt = nullptr;               // emit_pairs_bucketed: bucket sizes [64*64] + cursors [64*64]
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
@@ -284,6 +288,7 @@ struct SgnsArgs {
     int32_t cache_radius;       // sgns_win_kernel: tokens within this many positions of the centre keep their SynPos row in LDS
     int32_t prefetch;           // sgns_win_kernel: pairs whose negative rows are requested ahead (2, or 1)
     int32_t reload;             // sgns_win_kernel<RELOAD>: negative rows updated as they are at store time, centre row by atomic add
+    const int32_t *counts; int32_t hot_thr;   // sgns_win_kernel<!ALLC>: nodes with counts[v] >= hot_thr > 0 never enter the LDS window (HOT ROWS below)
 };
 
 // gradient scale of TrainModel: (label - sigma(f)) * alpha with the +-MaxExp clamps
@@ -526,6 +531,12 @@ struct NegSet {
 // store is no longer overwritten: the window in which it can be lost shrinks from (PF + 1) pair steps to one reload round trip.  The CPU
 // replay of this kernel's concurrency (scripts/hogwild_emul) attributes ~90 % of Hogwild's MAP loss to those overwritten negative-row
 // updates and the rest to the centre row's; stale gradients themselves cost nothing.
+// HOT ROWS (power-law graphs; !ALLC instantiations with A.hot_thr > 0).  A node that makes up the fraction p of all tokens sits in
+// W x (2R+1) x p LDS windows at once; every one of those copies trains for ~2R+1 centres on a stale base and leaves as a delta -- for a
+// hub that is hundreds of concurrent copies whose deltas ADD UP (measured on R-MAT scale 17, 985 wavefronts: MAP -15 % against the sequential
+// algorithm, with or without RELOAD; the SBM graphs have no such node).  Nodes whose expected number of concurrent copies reaches 1
+// (counts[v] >= tokens / (W x (2R+1))) therefore never enter the window: as a context their row is fetched for the pair and takes its
+// neu1e by atomic add (RELOAD) or a plain store, like the contexts beyond the cached radius.
 template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC, int PF = 2, bool RELOAD = false>
 __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 {
@@ -569,6 +580,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     };
 
     float *dummy = A.dummy + (size_t)gw * RW;        // this wave's private sink / source for predicated-off row traffic
+    auto is_hot = [&](int32_t v) -> bool {           // (wave-uniform v: a scalar load)
+        if constexpr (ALLC) return false;
+        else return A.hot_thr > 0 && A.counts[v] >= A.hot_thr;
+    };
     auto o_st = [&](int slot, const float (&v)[NV][VEC]) {            // the row as loaded (delta write-back)
         lds_st(rowsO + (size_t)slot * RW, v);
     };
@@ -668,7 +683,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         // rows of tokens 0 .. R-1 enter before the first centre
         for (int q = 0; q < R && q < len; ++q) {
             const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
-            if (v < 0) continue;
+            if (v < 0 || is_hot(v)) continue;
             const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
             if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; continue; }
             const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node < 0 && lane < S));
@@ -686,7 +701,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             float rowE[NV][VEC]; int sE = -1;
             if (pos + R < len) {
                 const int32_t v = __builtin_amdgcn_readfirstlane(tok[pos + R]);
-                if (v >= 0) {
+                if (v >= 0 && !is_hot(v)) {
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
                     if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; }
                     else {
@@ -700,8 +715,9 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             float rowG[NV][VEC], rowO[NV][VEC]; int sX = -1; int32_t vX = -1;
             if (pos - R >= 0) {
                 vX = __builtin_amdgcn_readfirstlane(tok[pos - R]);
-                if (vX >= 0) {
-                    const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node == vX));
+                const unsigned long long hx = vX >= 0 ? __builtin_amdgcn_ballot_w64(slot_node == vX) : 0ull;     // (no slot: a hot row, never cached)
+                if (hx) {
+                    const int s = (int)__builtin_ctzll(hx);
                     const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
                     if (lane == s) slot_ref = refc;
                     if (refc == 0) {
@@ -711,8 +727,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 }
             }
             // negatives: B for centre pos+1, A for centre pos+2
+            PROF_LAP(0);
             stage_b();
             stage_a(pos + 2);
+            PROF_LAP(5);                                             // negative-target pipeline: stage B gathers, stage A Philox + table gather
 
             if (word >= 0) {
                 const int64_t t = A.token_offset + wl * len + pos;
@@ -769,6 +787,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     lds_st(rowsL + (size_t)sE * RW, rowE);
                     if constexpr (DELTA) o_st(sE, rowE);
                 }
+                PROF_LAP(6);                                         // centre set-up: alpha, window draw, masks, centre row request, first prefetches, entering row -> LDS
 
                 // one (centre, context) pair: C holds its negative rows, the sets in between are in flight, P2 is free
                 auto step = [&](NegSet<VEC, NV> &C, NegSet<VEC, NV> &P2) __attribute__((always_inline)) {
@@ -902,7 +921,15 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
                         for (int k = 0; k < VEC; ++k) xc[c][k] += neu[c][k];
-                    if (ALLC || chit) lds_st(lrow, xc); else g_st(pc, xc);
+                    if (ALLC || chit) lds_st(lrow, xc);
+                    else if constexpr (RELOAD) {                     // uncached context row (beyond the radius, or a hot row): its neu1e by atomic add
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k)
+                                if ((c * WAVE + lane) * VEC + k < dg)
+                                    __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pc + (c * WAVE + lane) * VEC + k), neu[c][k]);
+                    } else g_st(pc, xc);
                     PROF_LAP(4);                                     // arithmetic + stores
                 };
                 if constexpr (PF == 2) {
@@ -932,7 +959,9 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
                             for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(Q.y[j][c][k]));
                 };
+                PROF_LAP(0);
                 retire(q0); retire(q1); if constexpr (PF == 2) retire(q2);
+                PROF_LAP(7);                                         // draining the prefetches issued past the last pair
                 if constexpr (RELOAD) {      // what this centre changed, added to the row as it is now (global_atomic_add_f32: nothing another wavefront stored is lost)
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
@@ -965,7 +994,9 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         for (int q = (len - R > 0 ? len - R : 0); q < len; ++q) {
             const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
             if (v < 0) continue;
-            const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node == v));
+            const unsigned long long hq = __builtin_amdgcn_ballot_w64(slot_node == v);
+            if (!hq) continue;                                   // a hot row: never cached
+            const int s = (int)__builtin_ctzll(hq);
             const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
             if (lane == s) slot_ref = refc;
             if (refc != 0) continue;
@@ -1001,7 +1032,7 @@ void launch_sgns(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStre
 template <int VEC, int NV, bool DELTA>
 void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
 {
-    const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window;
+    const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window && A.hot_thr == 0;
 #define GEMHIP_LAUNCH_WIN(F, C, P, R) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, F, C, P, R>), dim3(blocks), dim3(threads), lds, s, A)
     const bool reload = DELTA && A.reload;
     if constexpr (DELTA) {
@@ -1473,6 +1504,7 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     if (const char *e = getenv("GEMHIP_SGNS_CACHE_DELTA")) h->cache_delta = std::min(1, std::max(-1, atoi(e)));
     if (const char *e = getenv("GEMHIP_SGNS_PREFETCH")) h->prefetch = std::min(2, std::max(1, atoi(e)));
     if (const char *e = getenv("GEMHIP_SGNS_RELOAD")) h->reload = atoi(e) != 0;
+    if (const char *e = getenv("GEMHIP_SGNS_HOT_COUNT")) h->hot_count = std::max(-1, atoi(e));
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
     hipError_t e = hipMalloc((void **)&h->d_row_ptr, (n + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMemcpy(h->d_row_ptr, row_ptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
@@ -1678,6 +1710,19 @@ static bool vose_unigram(const int32_t *cnt, int64_t n, int64_t stride, std::vec
     return true;
 }
 
+static void vocab_stats(gemhip_n2v_t h, const std::vector<int32_t> &cnt)
+{
+    double tot = 0.0, mx = 0.0, z = 0.0, z2 = 0.0;
+    for (int32_t c : cnt) {
+        if (c <= 0) continue;
+        tot += c; mx = std::max(mx, (double)c);
+        const double u = std::pow((double)c, 0.75);
+        z += u; z2 += u * u;
+    }
+    h->vocab_total = tot; h->vocab_max = mx;
+    h->n_eff_neg = z2 > 0.0 ? z * z / z2 : (double)h->n;
+}
+
 extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, float *UT_out, int32_t *KT_out)
 {
     GEMHIP_REQUIRE(h, "n2v_build_unigram: NULL handle");
@@ -1687,6 +1732,7 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
     std::vector<float> Uf;
     GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     GEMHIP_REQUIRE(vose_unigram(cnt.data(), n, 1, Uf, K), "n2v_build_unigram: empty vocabulary (no walks?)");
+    vocab_stats(h, cnt);
     if (!h->d_UT) GEMHIP_CHECK(hipMalloc((void **)&h->d_UT, n * sizeof(float)));
     if (!h->d_KT) GEMHIP_CHECK(hipMalloc((void **)&h->d_KT, n * sizeof(int32_t)));
     GEMHIP_CHECK(hipMemcpy(h->d_UT, Uf.data(), n * sizeof(float), hipMemcpyHostToDevice));
@@ -1712,6 +1758,7 @@ extern "C" int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, flo
     const int64_t n = h->n;
     std::vector<int32_t> cnt(n);
     GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    vocab_stats(h, cnt);
     std::vector<float> Uall(n);
     std::vector<int32_t> Kall(n);
     h->part_off.assign(parts + 1, 0);
@@ -1879,7 +1926,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.token_offset = token_offset; A.walk_id_offset = h->walk_id_offset; A.epoch = epoch;
     A.UT = h->d_UT; A.KT = h->d_KT; A.UK = h->d_UK; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
-    A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->prefetch; A.reload = h->reload;
+    A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->prefetch; A.reload = h->reload; A.counts = nullptr; A.hot_thr = 0;
     const bool deterministic = (flags & 4) != 0;
     // Hogwild concurrency on small graphs: every in-flight wavefront has rows open (read-modify-write); when the open rows approach n,
     // concurrent writers overwrite each other's updates and the embedding degrades (tests/test_n2v_gpu.py).  sgns_kernel: n/128.
@@ -1914,17 +1961,28 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             // cost -0.1 % / -0.4..-0.9 % / -0.8..-1.3 % of MAP, and 1536 wavefronts with prefetch 1 (rho 1.5 %) -0.5 %: the loss follows rho, not
             // the wavefront count; with RELOAD 1536 wavefronts (rho 0.3 %) measure +0.15 +- 0.25 %.  Default: rho <= 1.5 %.
             const double w_steps = (delta && h->reload) ? 0.4 : (double)(h->prefetch + 1);
-            const int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * (double)h->n / (5.0 * w_steps)));
+            // n -> the EFFECTIVE table size 1 / sum_v q_v^2 of the negative-sampling distribution (unigram^0.75): equal to n on a graph whose
+            // nodes are equally frequent (SBM: n / 1.06), far smaller on a power-law graph (R-MAT scale 17: 11 316 of 131 072 nodes)
+            const double n_eff = h->n_eff_neg > 0.0 ? h->n_eff_neg : (double)h->n;
+            const int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
             // graphs below 8192 nodes: the window rows themselves (2R+1 per wavefront) are a sizeable part of the table -- SBM-1024 (d=16) loses
             // 3.5 % of MAP at 8 wavefronts and nothing at 2: bound the open fraction of the table at 1/16
-            const int64_t hog_win = h->max_waves > 0 ? h->max_waves
-                                  : h->n >= 8192 ? hog_rho : std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
+            const int64_t hog_tiny = std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
+            const int64_t hog_win = h->max_waves > 0 ? h->max_waves : h->n >= 8192 ? hog_rho : std::min(hog_rho, hog_tiny);
             waves = std::min<int64_t>(std::min<int64_t>(hog_win, 256 * per_cu), walk_hi - walk_lo);
             if (waves == 1 && mode < 0) delta = false;
         }
         const size_t lds = lds_bytes(delta);
         GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for the LDS window (%zu bytes)", lds);
         A.nwaves = (int32_t)waves; A.cache_radius = R;
+        // hot rows (sgns_win_kernel): a node expected to sit in another wavefront's window at any time -- (W - 1) x (2R + 1) x count / tokens >= 1 -- is
+        // never cached; the launch then takes the instantiation that handles uncached contexts (R is reported to the launcher as "not all cached")
+        A.counts = h->d_counts; A.hot_thr = 0;
+        if (h->hot_count > 0) A.hot_thr = h->hot_count;
+        else if (h->hot_count < 0 && waves > 1 && h->vocab_total > 0.0) {
+            const double thr = h->vocab_total / ((double)(waves - 1) * (2 * R + 1));
+            if (h->vocab_max >= thr) A.hot_thr = (int32_t)std::max(2.0, std::ceil(thr));
+        }
         const size_t need = (size_t)waves * rw * sizeof(float);
         if (need > h->dummy_bytes) {
             if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
@@ -1949,8 +2007,8 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             unsigned long long hp[8];
             GEMHIP_CHECK(hipDeviceSynchronize());
             GEMHIP_CHECK(hipMemcpy(hp, A.prof, 64, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[sgns profile] waves=%lld cycles: outside=%llu issue=%llu ctx_lds=%llu wait_rows=%llu compute_store=%llu\n", (long long)waves, hp[0], hp[1],
-                    hp[2], hp[3], hp[4]);
+            fprintf(stderr, "[sgns profile] waves=%lld cycles: other=%llu issue=%llu ctx_lds=%llu wait_rows=%llu compute_store=%llu neg_pipeline=%llu centre_setup=%llu drain=%llu\n",
+                    (long long)waves, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
         }
 #endif
         return GEMHIP_OK;
@@ -2006,6 +2064,13 @@ extern "C" int gemhip_sgns_set_hogwild(gemhip_n2v_t h, int32_t prefetch_pairs, i
     GEMHIP_REQUIRE(h && prefetch_pairs >= 0 && prefetch_pairs <= 2 && reload_on_update >= -1 && reload_on_update <= 1, "sgns_set_hogwild: bad arguments");
     if (prefetch_pairs) h->prefetch = prefetch_pairs;
     if (reload_on_update >= 0) h->reload = reload_on_update;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_set_hot_rows(gemhip_n2v_t h, int32_t min_count)
+{
+    GEMHIP_REQUIRE(h && min_count >= -1, "sgns_set_hot_rows: bad arguments");
+    h->hot_count = min_count;
     return GEMHIP_OK;
 }
 

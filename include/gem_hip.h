@@ -184,9 +184,10 @@ int gemhip_sgns_init(gemhip_n2v_t h, int32_t d, uint64_t seed, void *dSynPos, vo
  * SGNS byte count (14*4d bytes per pair). */
 int gemhip_sgns_pairs(gemhip_n2v_t h, int64_t *pairs, int32_t reset);
 /* Cap on concurrently training wavefronts (Hogwild width).  0 = auto: the number of wavefronts for which the expected fraction of
- * row stores that overwrite another wavefront's store, rho = W x 5 x w / n (w = the load-to-store window of a negative row in pair
- * steps: ~0.4 with reload-on-update, prefetch + 1 without), stays <= 1.5 % -- n/133 with reload-on-update, n/1000 without -- never
- * more than the device holds (1536 on MI355X); graphs below 8192 nodes: 1/16 of the table open at most.  Derivation and the
+ * row stores that overwrite another wavefront's store, rho = W x 5 x w / n_eff (w = the load-to-store window of a negative row in pair
+ * steps: ~0.4 with reload-on-update, prefetch + 1 without; n_eff = 1 / sum q_v^2 over the negative-sampling distribution: n on a
+ * uniform graph, far less with hubs), stays <= 1.5 % -- n_eff/133 with reload-on-update, n_eff/1000 without -- never more than the
+ * device holds (1536 on MI355X); graphs below 8192 nodes: 1/16 of the table open at most.  Derivation and the
  * measurements behind it: DESIGN.md 3.3, scripts/hogwild_emul. */
 int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves);
 /* LDS window of TrainModel's context rows (no reference counterpart: the binary keeps its tables in host RAM).
@@ -200,6 +201,11 @@ int gemhip_sgns_set_window_cache(gemhip_n2v_t h, int32_t radius, int32_t delta_w
  * after the dot products, `row_now + g * xc` -- and the centre's positive row as an atomic add of what the centre changed, instead of
  * storing copies that are (prefetch_pairs + 1) pair steps / one centre old and overwrite whatever other wavefronts stored meanwhile. */
 int gemhip_sgns_set_hogwild(gemhip_n2v_t h, int32_t prefetch_pairs, int32_t reload_on_update);
+/* Hot rows: a node with at least min_count tokens in the corpus never enters a wavefront's LDS window of context rows (its row is fetched
+ * per pair and updated by atomic add) -- on a power-law graph a hub would otherwise sit in hundreds of windows at once and the deltas its
+ * copies leave with add up.  -1 = auto: the nodes expected to be in another wavefront's window at any time, tokens / ((W-1) x (2R+1));
+ * 0 = off.  No reference counterpart. */
+int gemhip_sgns_set_hot_rows(gemhip_n2v_t h, int32_t min_count);
 /* Building block of the SGNS kernel, exposed for its own parity test: in[64][6] per-lane partial sums -> out[64], lane l
  * receiving the wave total of value (l & 4) ? 4 + (l & 1) : (l & 3). */
 int gemhip_test_wave_sum6(const float *in_host, float *out_host);

@@ -141,7 +141,7 @@ def test_sgns_deterministic_matches_oracle(gname, d, window, l, epochs, flags, r
 @pytest.mark.parametrize('gname,d,window,l,radius,delta', [('karate', 8, 10, 80, -1, 0), ('karate', 8, 10, 80, 3, 0), ('karate', 7, 4, 30, 2, 0),
                                                            ('sbm1024', 128, 10, 40, -1, 0), ('sbm1024', 128, 10, 40, 4, 0),
                                                            ('sbm1024', 128, 10, 40, -1, 1), ('karate', 256, 5, 20, 5, 1),
-                                                           ('karate', 16, 12, 9, -1, 0)])
+                                                           ('karate', 16, 12, 9, -1, 0), ('karate', 128, 10, 30, 4, 1), ('karate', 128, 10, 30, -1, 9)])
 @pytest.mark.parametrize('hog', [(2, 1), (1, 1), (2, 0)])
 def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, delta, hog, request):
     """The LDS-window kernel (default) and the round-1 kernel (flag 128) are the same algorithm: one wavefront in walk order gives
@@ -159,6 +159,12 @@ def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, del
         _hip.check(dev.L.gemhip_n2v_set_walks(dev.h, _hip.ptr(walks, C.c_int32), walks.shape[0], l, 0))
     dev.unigram()
     P0, N0 = dev.sgns(d, window, 1, 5, SNAP | 4 | _hip.N2V_NO_WINDOW_CACHE)
+    # delta 9 = delta write-back + HOT ROWS forced on: every node with >= 40 tokens (the hubs of karate: most of the corpus) stays out of the LDS
+    # window and is trained through the uncached path -- per-pair fetch, neu1e by atomic add -- which must still be TrainModel's arithmetic; the
+    # ('karate', 128, 10, 30, 4, 1) case exercises the same path for contexts beyond a radius-4 window
+    if delta == 9:
+        _hip.check(dev.L.gemhip_sgns_set_hot_rows(dev.h, 40))
+        delta = 1
     _hip.check(dev.L.gemhip_sgns_set_window_cache(dev.h, radius, delta))
     _hip.check(dev.L.gemhip_sgns_set_hogwild(dev.h, hog[0], hog[1]))
     P1, N1 = dev.sgns(d, window, 1, 5, SNAP | 4)
