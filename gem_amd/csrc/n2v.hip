@@ -278,6 +278,16 @@ __device__ __forceinline__ void st_row(float *p, int d, int lane, int c, const f
     }
 }
 
+// this lane's VEC floats of a row, to an address the caller already holds (same relaxed agent-scope store as st_row)
+template <int VEC>
+__device__ __forceinline__ void st_lane(float *q, const float (&v)[VEC])
+{
+    if constexpr (VEC == 2) {
+        const unsigned long long t = (unsigned long long)__builtin_bit_cast(unsigned int, v[0]) | ((unsigned long long)__builtin_bit_cast(unsigned int, v[1]) << 32);
+        __hip_atomic_store((gu64 *)q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else __hip_atomic_store((gu32 *)q, __builtin_bit_cast(unsigned int, v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct SgnsArgs {
     const int32_t *walks; int64_t walk_lo, walk_hi; int32_t walk_len; int32_t window;
     float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
@@ -694,9 +704,29 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             if (lane == s) { slot_node = v; slot_ref = 1; }
         }
 
+        // data and address registers of the stores a centre ends with.  They are kept alive (empty asm "uses" inside the next centre's pair steps) so
+        // that the register allocator cannot hand them out again right away: overwriting the source registers of a store that is still in flight is
+        // a write-after-read hazard the compiler guards with s_waitcnt vmcnt(0) -- a full drain that waits for the store's acknowledgement (seen in the
+        // ISA: three such drains per centre, ~a quarter of the kernel's time)
+        float tail_d0[NV][VEC], tail_d1[NV][VEC]; float *tail_p0[NV], *tail_p1[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            tail_p0[c] = tail_p1[c] = nullptr;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) tail_d0[c][k] = tail_d1[c][k] = 0.f;
+        }
+        auto tail_keep = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                asm volatile("" ::"v"(tail_p0[c]), "v"(tail_p1[c]));
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(tail_d0[c][k]), "v"(tail_d1[c][k]));
+            }
+        };
         for (int pos = 0; pos < len; ++pos) {
             const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
             uint32_t spec_cur = spec_next;
+            bool fin_done = false;
             // token pos+R enters
             float rowE[NV][VEC]; int sE = -1;
             if (pos + R < len) {
@@ -722,7 +752,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     if (lane == s) slot_ref = refc;
                     if (refc == 0) {
                         sX = s;
-                        if constexpr (DELTA) g_ld(A.SynPos + (int64_t)vX * d, rowG);
+                        if constexpr (DELTA && !RELOAD) g_ld(A.SynPos + (int64_t)vX * d, rowG);      // (RELOAD: the row leaves as an atomic add of its change)
                     }
                 }
             }
@@ -732,6 +762,8 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             stage_a(pos + 2);
             PROF_LAP(5);                                             // negative-target pipeline: stage B gathers, stage A Philox + table gather
 
+            float yp[NV][VEC], yp0[NV][VEC];                         // the centre's positive row SynNeg[word] (and, RELOAD, as it was loaded)
+            float *pp = A.SynNeg + (int64_t)(word >= 0 ? word : 0) * d;
             if (word >= 0) {
                 const int64_t t = A.token_offset + wl * len + pos;
                 const int64_t tq = t - (t % 10000);
@@ -741,8 +773,6 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 const int b = (int)(rw.x % (uint32_t)win);
                 const int32_t *ncur = negs + (pos & 1) * nsamp;
 
-                float yp[NV][VEC], yp0[NV][VEC];
-                float *pp = A.SynNeg + (int64_t)word * d;
                 g_ld(pp, yp);
                 if constexpr (RELOAD) {
 #pragma unroll
@@ -787,6 +817,12 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     lds_st(rowsL + (size_t)sE * RW, rowE);
                     if constexpr (DELTA) o_st(sE, rowE);
                 }
+                // the centre row is needed by the first pair anyway; "using" it here pins its wait BEFORE the pair loop (a counted wait: the prefetches just
+                // issued stay in flight), so that the compiler does not have to drain everything when it meets yp again after a loop it cannot count through
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(yp[c][k]));
                 PROF_LAP(6);                                         // centre set-up: alpha, window draw, masks, centre row request, first prefetches, entering row -> LDS
 
                 // one (centre, context) pair: C holds its negative rows, the sets in between are in flight, P2 is free
@@ -817,6 +853,13 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     PROF_LAP(2);                                     // context lookup + LDS read (includes its lgkmcnt wait)
                     if constexpr (PF == 2) PROF_WAIT_VM(10); else PROF_WAIT_VM(5);
                     PROF_LAP(3);                                     // waiting for this pair's rows (the younger prefetches may stay in flight)
+                    tail_keep();                                     // (no instruction: the previous centre's store registers stay reserved up to here)
+                    if (!fin_done) {
+                        // the negative targets of the NEXT centre: their table gather (stage_b, issued before this centre's first prefetch) is older than
+                        // the rows just waited for, so consuming it HERE costs no wait; after the pair loop it would be a full drain
+                        spec_next = stage_fin(pos + 1);
+                        fin_done = true;
+                    }
                     if (!((spec_cur >> ai_c) & 1u)) {
                         // fast path: the six targets are distinct rows and none is the centre word -> six independent updates
                         float part[6];
@@ -959,22 +1002,20 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
                             for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(Q.y[j][c][k]));
                 };
+                // (the prefetch slots filled past the last pair are dead: nothing consumes them, nothing waits for them -- round 2 "retired" them here,
+                // which was a full drain including the last pair's stores)
                 PROF_LAP(0);
-                retire(q0); retire(q1); if constexpr (PF == 2) retire(q2);
-                PROF_LAP(7);                                         // draining the prefetches issued past the last pair
-                if constexpr (RELOAD) {      // what this centre changed, added to the row as it is now (global_atomic_add_f32: nothing another wavefront stored is lost)
-#pragma unroll
-                    for (int c = 0; c < NV; ++c)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k)
-                            __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pp + (c * WAVE + lane) * VEC + k), yp[c][k] - yp0[c][k]);
-                } else g_st(pp, yp);
             } else if (sE >= 0) {
                 lds_st(rowsL + (size_t)sE * RW, rowE);
                 if constexpr (DELTA) o_st(sE, rowE);
             }
 
-            spec_next = stage_fin(pos + 1);
+            // End of the centre.  vmcnt counts loads and stores in order and the compiler cannot count across the pair loop, so every use of an
+            // older load here is a full drain (s_waitcnt vmcnt(0)) that also waits for the acknowledgement of whatever was stored last.  Hence:
+            // first everything that CONSUMES loads (the negative targets of the next centre, the leaving row as it is now) -- one drain, of
+            // the last pair's stores -- and only then the centre's own stores, after which nothing waits until the next centre's first pair
+            // (round 2 stored the centre row, then consumed, then stored the leaving row: three exposed round trips per centre).
+            if (!fin_done) spec_next = stage_fin(pos + 1);          // (a centre without pairs; otherwise done inside its first pair step)
             if (sX >= 0) {
                 float l[NV][VEC];
                 lds_ld(rowsL + (size_t)sX * RW, l);
@@ -983,9 +1024,44 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) l[c][k] = rowG[c][k] + (l[c][k] - rowO[c][k]);
+                        for (int k = 0; k < VEC; ++k) l[c][k] = RELOAD ? l[c][k] - rowO[c][k] : rowG[c][k] + (l[c][k] - rowO[c][k]);
                 }
-                g_st(A.SynPos + (int64_t)vX * d, l);
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    tail_p1[c] = A.SynPos + (int64_t)vX * d + (c * WAVE + lane) * VEC;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) tail_d1[c][k] = l[c][k];
+                }
+            }
+            if (word >= 0) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    tail_p0[c] = pp + (c * WAVE + lane) * VEC;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) tail_d0[c][k] = RELOAD ? yp[c][k] - yp0[c][k] : yp[c][k];
+                }
+            }
+            // ---- stores only from here on
+            if (word >= 0) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    if ((c * WAVE + lane) * VEC < dg) {
+                        if constexpr (RELOAD) {      // what this centre changed, added to the row as it is now (global_atomic_add_f32: nothing another wavefront stored is lost)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(tail_p0[c] + k), tail_d0[c][k]);
+                        } else st_lane<VEC>(tail_p0[c], tail_d0[c]);
+                    }
+                }
+            }
+            if (sX >= 0) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+                    if ((c * WAVE + lane) * VEC < dg) {
+                        if constexpr (RELOAD) {      // the leaving window row: what this wavefront changed, added to the row as it is now
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(tail_p1[c] + k), tail_d1[c][k]);
+                        } else st_lane<VEC>(tail_p1[c], tail_d1[c]);
+                    }
                 if (lane == sX) slot_node = -1;
             }
             __builtin_amdgcn_wave_barrier();
