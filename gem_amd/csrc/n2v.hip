@@ -1064,6 +1064,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     }
                 if (lane == sX) slot_node = -1;
             }
+            PROF_LAP(7);                                             // end of the centre: consume, then the centre's stores
             __builtin_amdgcn_wave_barrier();
         }
         // the last R tokens are still in the window
@@ -2083,7 +2084,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             unsigned long long hp[8];
             GEMHIP_CHECK(hipDeviceSynchronize());
             GEMHIP_CHECK(hipMemcpy(hp, A.prof, 64, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[sgns profile] waves=%lld cycles: other=%llu issue=%llu ctx_lds=%llu wait_rows=%llu compute_store=%llu neg_pipeline=%llu centre_setup=%llu drain=%llu\n",
+            fprintf(stderr, "[sgns profile] waves=%lld cycles: other=%llu issue=%llu ctx_lds=%llu wait_rows=%llu compute_store=%llu neg_pipeline=%llu centre_setup=%llu centre_end=%llu\n",
                     (long long)waves, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
         }
 #endif

@@ -174,8 +174,10 @@ def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, del
 
 
 def test_sgns_window_cache_hogwild_quality(sbm1024):
-    """Multi-wave launches (delta write-back): MAP of the window kernel == MAP of the round-1 kernel within noise, for the full
-    radius and a partial one, and the pair count (the unit of the roofline) is identical."""
+    """Multi-wave launches: MAP of the window kernel (full radius and a partial one: uncached contexts take atomic adds) against the SEQUENTIAL oracle on
+    the same seed (same walks, same negatives), and the pair count (the unit of the roofline) identical to the round-1 kernel's.  Measured (round 3):
+    oracle 0.1854; window kernel 0.187-0.192 (two wavefronts, reload-on-update: nothing is lost); round-1 kernel 0.177-0.178 (eight wavefronts on plain
+    read-modify-write rows: lost updates, -4 %).  Bars: 5 % for the window kernel (run-to-run s.d. ~1.5 %), 8 % for the round-1 kernel."""
     n, src, dst, w, _ = edge_arrays(sbm1024)
     m = node2vec(d=128, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
     res = {}
@@ -189,8 +191,11 @@ def test_sgns_window_cache_hogwild_quality(sbm1024):
         res[name] = (gr.evaluateStaticGraphReconstruction(sbm1024, m, P.astype(np.float64), None)[0], pairs.value)
         dev.close()
     assert res['r1'][1] == res['win'][1] == res['win4'][1]
+    Xs, _ = oracle.n2v_train(n, src, dst, w, 128, 80, 10, 10, 1, 1.0, 1.0, 7, SNAP)
+    ref = gr.evaluateStaticGraphReconstruction(sbm1024, m, Xs.astype(np.float64), None)[0]
     for k in ('win', 'win4'):
-        assert abs(res[k][0] - res['r1'][0]) <= 0.05 * res['r1'][0], res
+        assert abs(res[k][0] - ref) <= 0.05 * ref, (res, ref)
+    assert abs(res['r1'][0] - ref) <= 0.08 * ref, (res, ref)
 
 
 def test_wave_sum6_building_block():
