@@ -1,3 +1,4 @@
+# ARCHIVED (round 3): drives the two-wavefront / global-scratch variants (GEMHIP_SGNS_DUO, GEMHIP_SGNS_OSCR), which was removed from the library; kept because committed profiles were produced with it
 """A/B of the LDS-window SGNS kernel against the round-1 kernel on the bench graph (SBM 1M/10M, d=128, r walks per node):
 time per launch, algorithmic TB/s, and the reconstruction MAP over a fixed 256-node sample for every variant.
     python scripts/ab_sgns_window.py [r] [nodes] [edges] [blocks]

@@ -1,3 +1,4 @@
+# ARCHIVED (round 3): drives the three-wavefront kernel (gemhip_sgns_set_team), which was removed from the library; kept because committed profiles were produced with it
 #!/usr/bin/env python3
 """A/B at the headline size (SBM 1M/10M, d=128): sgns_team_kernel (three wavefronts per walk) against sgns_win_kernel, for several numbers
 of concurrently trained walks and prefetch distances.  Seconds of the SGNS launch and the reconstruction MAP over the sample of

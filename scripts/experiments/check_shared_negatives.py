@@ -1,3 +1,4 @@
+# ARCHIVED (round 3): drives the shared-negatives kernel (flag 64), which was removed from the library; kept because committed profiles were produced with it
 """Opt-in shared-negatives SGNS: MAP at the 16k-node reference point and time at SBM 1M/10M."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

@@ -1,3 +1,4 @@
+# ARCHIVED (round 3): drives the three-wavefront kernel (gemhip_sgns_set_team), which was removed from the library; kept because committed profiles were produced with it
 #!/usr/bin/env python3
 """Timing diagnosis of sgns_team_kernel at SBM 1M/10M with r walks per node (default 2): the kernel with parts switched off
 (GEMHIP_TEAM_DIAG build, flags >> 16: 1 no LDS adds, 2 no repeat barriers, 4 no boundary barriers / fold, 8 no row stores -- results are
