@@ -75,7 +75,7 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
         0.35 %, plus 0.4 % (1024-node sample) / 0.2 % (4096) sampling error of the gap that the three runs share: the bar is > 2 s.d. away on
         either side, P(flake) < 2 %.  (Round 2's default sat at -0.74 % and needed "+2 s.e.".)
       * SNAP binary: its seed is time(), so the comparison is UNPAIRED in the walks: seed-to-seed the MAP of either implementation moves by
-        ~0.5 % (s.d.; HIP 0.498-0.508 over four seeds), so three HIP seeds are averaged against the binary's single run; the expected s.d. of
+        ~0.5 % (s.d.; HIP 0.498-0.508 over four seeds), so two HIP seeds are averaged against the binary's single run; the expected s.d. of
         that gap is ~0.7 % even for identical algorithms, hence this leg asserts 2 % (a 1 % bar would flake in ~15 % of the runs) and bench.py
         prints the measured gap (`quality.map_minus_reference_map`) for the record."""
     refs = {e: golden_path(f) for e, f in (('snap', 'n2v_ref_snap_1000k.json'), ('oracle', 'n2v_ref_oracle_1000k_s4096.json'), ('oracle1k', 'n2v_ref_oracle_1000k.json'))}
@@ -91,18 +91,20 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
     nmax = max(len(r['ap']) for r in refs.values())
     nodes = np.random.RandomState(0).choice(g.n, size=nmax, replace=False)            # (a smaller golden sample is a prefix of it)
 
-    def run(seed):
+    def run(seed, k):
         m = node2vec(d=pr['d'], max_iter=1, walk_len=pr['walk_len'], num_walks=pr['num_walks'], con_size=pr['window'], ret_p=1, inout_p=1, seed=seed)
-        return gr.sampled_ap_gpu(g, None, m.learn_embedding(graph=g, is_weighted=True, no_python=True), nodes)
+        return gr.sampled_ap_gpu(g, None, m.learn_embedding(graph=g, is_weighted=True, no_python=True), nodes[:k])
     if 'oracle' in refs:
         ref = refs['oracle']
-        k = len(ref['ap'])
-        gaps = [float((run(20260923)[:k] - np.asarray(ref['ap'])).mean() / ref['MAP']) for _ in range(3)]
+        k = min(len(ref['ap']), 2048)                  # (a prefix of the sample: 2048 nodes keep the tier's run time in bounds)
+        apo = np.asarray(ref['ap'])[:k]
+        gaps = [float((run(20260923, k) - apo).mean() / apo.mean()) for _ in range(3)]
         assert abs(np.mean(gaps)) <= 0.01, (gaps, ref['MAP'])
     if 'snap' in refs:
         ref = refs['snap']
-        k = len(ref['ap'])
-        gaps = [float((run(seed)[:k] - np.asarray(ref['ap'])).mean() / ref['MAP']) for seed in (1, 2, 3)]
+        k = min(len(ref['ap']), 2048)
+        aps = np.asarray(ref['ap'])[:k]
+        gaps = [float((run(seed, k) - aps).mean() / aps.mean()) for seed in (1, 2)]
         assert abs(np.mean(gaps)) <= 0.02, (gaps, ref['MAP'])
 
 
