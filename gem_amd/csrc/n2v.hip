@@ -94,6 +94,9 @@ struct gemhip_n2v {
     // vocabulary statistics (gemhip_n2v_build_unigram*): how concentrated the row traffic is
     double vocab_total = 0.0, vocab_max = 0.0;
     double n_eff_neg = 0.0;           // 1 / sum_v q_v^2, q = unigram^0.75 distribution: the table size a uniform graph with the same collision rate would have
+    std::vector<int32_t> cnt_desc;    // token counts, descending, and ...
+    std::vector<double> u2_prefix;    // ... u2_prefix[i] = sum of (count^0.75)^2 over the i largest counts; vocab_z = sum of count^0.75
+    double vocab_z = 0.0;
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
     unsigned long long *d_bcnt = nullptr;               // emit_pairs_bucketed: bucket sizes [64*64] + cursors [64*64]
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
@@ -526,6 +529,7 @@ __device__ __forceinline__ float wave_sum6(const float (&p)[6], int lane)
 template <int VEC, int NV>
 struct NegSet {
     int32_t tv;                 // lanes 0..4: the five targets (lane form, for the any-match test)
+    int32_t cnt;                // lanes 0..4: their token counts (instantiations that handle hot rows: fetched with the rows)
     int32_t tgt[SGNS_NEG];
     float y[SGNS_NEG][NV][VEC]; // their SynNeg rows (in flight, then updated in place)
 };
@@ -804,6 +808,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     const int ai = a < win ? a : a - 1;
                     Q.tv = ncur[ai * SGNS_NEG + (lane < SGNS_NEG ? lane : 0)];
                     if (lane >= SGNS_NEG || !live) Q.tv = -1;
+                    if constexpr (!ALLC && RELOAD) Q.cnt = A.counts[Q.tv >= 0 ? Q.tv : 0];      // one 4-byte gather per pair, in flight with the rows
 #pragma unroll
                     for (int j = 0; j < SGNS_NEG; ++j) {
                         Q.tgt[j] = __builtin_amdgcn_readlane(Q.tv, j);
@@ -897,13 +902,27 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                                 for (int c = 0; c < NV; ++c)
 #pragma unroll
                                     for (int k = 0; k < VEC; ++k) neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
+                            // hot negative rows (hubs drawn as negatives by many wavefronts at once): their update is an atomic add of g * xc -- no
+                            // window at all -- and the row-sized store goes to the scratch row instead (the number of loads / stores per pair stays static)
+                            unsigned hotm = 0u;
+                            if constexpr (!ALLC) hotm = A.hot_thr > 0 ? (unsigned)__builtin_amdgcn_ballot_w64(lane < SGNS_NEG && C.cnt >= A.hot_thr) : 0u;
 #pragma unroll
                             for (int j = 0; j < SGNS_NEG; ++j) {
+                                const bool hotj = (hotm >> j) & 1u;
+                                float *pj = A.SynNeg + (int64_t)C.tgt[j] * d;
+                                if (hotj) {
+#pragma unroll
+                                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                        for (int k = 0; k < VEC; ++k)
+                                            if ((c * WAVE + lane) * VEC + k < dg)
+                                                __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pj + (c * WAVE + lane) * VEC + k), g[j + 1] * xc[c][k]);
+                                }
 #pragma unroll
                                 for (int c = 0; c < NV; ++c)
 #pragma unroll
                                     for (int k = 0; k < VEC; ++k) Rn[j][c][k] = fmaf(g[j + 1], xc[c][k], Rn[j][c][k]);
-                                g_st(A.SynNeg + (int64_t)C.tgt[j] * d, Rn[j]);
+                                g_st(hotj ? dummy : pj, Rn[j]);
                             }
                         } else {
 #pragma unroll
@@ -1796,8 +1815,23 @@ static void vocab_stats(gemhip_n2v_t h, const std::vector<int32_t> &cnt)
         const double u = std::pow((double)c, 0.75);
         z += u; z2 += u * u;
     }
-    h->vocab_total = tot; h->vocab_max = mx;
+    h->vocab_total = tot; h->vocab_max = mx; h->vocab_z = z;
     h->n_eff_neg = z2 > 0.0 ? z * z / z2 : (double)h->n;
+    h->cnt_desc.assign(cnt.begin(), cnt.end());
+    std::sort(h->cnt_desc.begin(), h->cnt_desc.end(), std::greater<int32_t>());
+    h->u2_prefix.assign(cnt.size() + 1, 0.0);
+    for (size_t i = 0; i < h->cnt_desc.size(); ++i) {
+        const double u = h->cnt_desc[i] > 0 ? std::pow((double)h->cnt_desc[i], 0.75) : 0.0;
+        h->u2_prefix[i + 1] = h->u2_prefix[i] + u * u;
+    }
+}
+// effective table size of the negative-sampling distribution over the rows that are NOT hot (count < thr): hot rows take atomic adds and lose nothing
+static double n_eff_cold(const gemhip_n2v *h, double thr)
+{
+    if (h->cnt_desc.empty() || h->vocab_z <= 0.0) return (double)h->n;
+    const size_t nhot = (size_t)(std::lower_bound(h->cnt_desc.begin(), h->cnt_desc.end(), thr, [](int32_t c, double t) { return (double)c >= t; }) - h->cnt_desc.begin());
+    const double s2 = (h->u2_prefix.back() - h->u2_prefix[nhot]) / (h->vocab_z * h->vocab_z);
+    return s2 > 0.0 ? 1.0 / s2 : 1e300;
 }
 
 extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, float *UT_out, int32_t *KT_out)
@@ -2041,12 +2075,21 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             // n -> the EFFECTIVE table size 1 / sum_v q_v^2 of the negative-sampling distribution (unigram^0.75): equal to n on a graph whose
             // nodes are equally frequent (SBM: n / 1.06), far smaller on a power-law graph (R-MAT scale 17: 11 316 of 131 072 nodes)
             const double n_eff = h->n_eff_neg > 0.0 ? h->n_eff_neg : (double)h->n;
-            const int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
+            int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
             // graphs below 8192 nodes: the window rows themselves (2R+1 per wavefront) are a sizeable part of the table -- SBM-1024 (d=16) loses
             // 3.5 % of MAP at 8 wavefronts and nothing at 2: bound the open fraction of the table at 1/16
             const int64_t hog_tiny = std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
+            const int64_t w_dev = std::min<int64_t>(256 * per_cu, walk_hi - walk_lo);
+            // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
+            // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
+            if (delta && h->reload && h->hot_count < 0 && h->n >= 8192 && hog_rho < w_dev && h->vocab_total > 0.0) {
+                for (int64_t wtry = w_dev; wtry > hog_rho; wtry = wtry * 7 / 8) {
+                    const double thr = std::max(2.0, std::ceil(h->vocab_total / ((double)(wtry - 1) * (2 * R + 1))));
+                    if (0.015 * n_eff_cold(h, thr) / (5.0 * w_steps) >= (double)wtry) { hog_rho = wtry; break; }
+                }
+            }
             const int64_t hog_win = h->max_waves > 0 ? h->max_waves : h->n >= 8192 ? hog_rho : std::min(hog_rho, hog_tiny);
-            waves = std::min<int64_t>(std::min<int64_t>(hog_win, 256 * per_cu), walk_hi - walk_lo);
+            waves = std::min<int64_t>(hog_win, w_dev);
             if (waves == 1 && mode < 0) delta = false;
         }
         const size_t lds = lds_bytes(delta);
