@@ -92,7 +92,7 @@ struct gemhip_n2v {
     int32_t reload = 1;               // Hogwild launches: update negative rows as they are at store time (second fetch) and the centre row by atomic add
     int32_t hot_count = -1;           // nodes with at least this many tokens never enter the LDS window: -1 auto (tokens / ((W-1) x (2R+1))), 0 off
     // vocabulary statistics (gemhip_n2v_build_unigram*): how concentrated the row traffic is
-    double vocab_total = 0.0, vocab_max = 0.0;
+    double vocab_total = 0.0, vocab_max = 0.0, vocab_active = 0.0;     // tokens, largest count, nodes that occur at all
     double n_eff_neg = 0.0;           // 1 / sum_v q_v^2, q = unigram^0.75 distribution: the table size a uniform graph with the same collision rate would have
     std::vector<int32_t> cnt_desc;    // token counts, descending, and ...
     std::vector<double> u2_prefix;    // ... u2_prefix[i] = sum of (count^0.75)^2 over the i largest counts; vocab_z = sum of count^0.75
@@ -1011,16 +1011,6 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                         step(q1, q0);
                     }
                 }
-                // the prefetch slots that were filled past the last pair are dead; "use" them so that the compiler's wait-count
-                // bookkeeping retires their loads here instead of carrying them into the next centre's loop header
-                auto retire = [&](NegSet<VEC, NV> &Q) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j)
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(Q.y[j][c][k]));
-                };
                 // (the prefetch slots filled past the last pair are dead: nothing consumes them, nothing waits for them -- round 2 "retired" them here,
                 // which was a full drain including the last pair's stores)
                 PROF_LAP(0);
@@ -1809,9 +1799,10 @@ static bool vose_unigram(const int32_t *cnt, int64_t n, int64_t stride, std::vec
 static void vocab_stats(gemhip_n2v_t h, const std::vector<int32_t> &cnt)
 {
     double tot = 0.0, mx = 0.0, z = 0.0, z2 = 0.0;
+    h->vocab_active = 0.0;
     for (int32_t c : cnt) {
         if (c <= 0) continue;
-        tot += c; mx = std::max(mx, (double)c);
+        tot += c; mx = std::max(mx, (double)c); h->vocab_active += 1.0;
         const double u = std::pow((double)c, 0.75);
         z += u; z2 += u * u;
     }
@@ -2082,8 +2073,12 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             const int64_t w_dev = std::min<int64_t>(256 * per_cu, walk_hi - walk_lo);
             // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
             // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
-            if (delta && h->reload && h->hot_count < 0 && h->n >= 8192 && hog_rho < w_dev && h->vocab_total > 0.0) {
-                for (int64_t wtry = w_dev; wtry > hog_rho; wtry = wtry * 7 / 8) {
+            // ... but never more wavefronts than 2 % of the rows that occur at all: that is as far as the measurements behind this rule reach (stale
+            // gradients cost nothing up to there -- CPU replay at 0.4 %, SBM 100k at 0.8 %, R-MAT scale 17 at 2.0 % of the active rows; R-MAT scale 13 with
+            // 26 % of its 5 936 active rows open ended 21 % ABOVE the sequential algorithm's MAP: its hubs under-trained)
+            const int64_t w_act = std::max<int64_t>(1, (int64_t)((h->vocab_active > 0.0 ? h->vocab_active : (double)h->n) / 50.0));
+            if (delta && h->reload && h->hot_count < 0 && h->n >= 8192 && hog_rho < std::min(w_dev, w_act) && h->vocab_total > 0.0) {
+                for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
                     const double thr = std::max(2.0, std::ceil(h->vocab_total / ((double)(wtry - 1) * (2 * R + 1))));
                     if (0.015 * n_eff_cold(h, thr) / (5.0 * w_steps) >= (double)wtry) { hog_rho = wtry; break; }
                 }
