@@ -653,6 +653,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                       # rank 0 scores the embedding after the timed region: nobody tears the group down under it
         dist.destroy_process_group()
 
 
