@@ -1120,22 +1120,30 @@ void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hip
 {
     const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window && A.hot_thr == 0;
 #define GEMHIP_LAUNCH_WIN(F, C, P, R) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, F, C, P, R>), dim3(blocks), dim3(threads), lds, s, A)
-    const bool reload = DELTA && A.reload;
+    // instantiations: the A/B knobs (prefetch distance 1, Hogwild WITHOUT reload-on-update) exist for the benchmark shape only (d = 128: VEC 2, NV 1, whole
+    // window cached); every other Hogwild launch is reload-on-update with prefetch distance 2
+    constexpr bool AB = VEC == 2 && NV == 1;
+    const bool reload = DELTA && (A.reload || !(AB && full && allc));
     if constexpr (DELTA) {
         if (reload) {
-            if (full && allc && A.prefetch == 1) GEMHIP_LAUNCH_WIN(true, true, 1, true);
-            else if (full && allc) GEMHIP_LAUNCH_WIN(true, true, 2, true);
+            if constexpr (AB) { if (full && allc && A.prefetch == 1) { GEMHIP_LAUNCH_WIN(true, true, 1, true); return; } }
+            if (full && allc) GEMHIP_LAUNCH_WIN(true, true, 2, true);
             else if (full) GEMHIP_LAUNCH_WIN(true, false, 2, true);
             else if (allc) GEMHIP_LAUNCH_WIN(false, true, 2, true);
             else GEMHIP_LAUNCH_WIN(false, false, 2, true);
             return;
         }
+        if constexpr (AB) {      // (only reached with full && allc)
+            if (A.prefetch == 1) GEMHIP_LAUNCH_WIN(true, true, 1, false); else GEMHIP_LAUNCH_WIN(true, true, 2, false);
+        }
+        return;
+    } else {
+        if constexpr (AB) { if (full && allc && A.prefetch == 1) { GEMHIP_LAUNCH_WIN(true, true, 1, false); return; } }
+        if (full && allc) GEMHIP_LAUNCH_WIN(true, true, 2, false);
+        else if (full) GEMHIP_LAUNCH_WIN(true, false, 2, false);
+        else if (allc) GEMHIP_LAUNCH_WIN(false, true, 2, false);
+        else GEMHIP_LAUNCH_WIN(false, false, 2, false);
     }
-    if (full && allc && A.prefetch == 1) GEMHIP_LAUNCH_WIN(true, true, 1, false);
-    else if (full && allc) GEMHIP_LAUNCH_WIN(true, true, 2, false);
-    else if (full) GEMHIP_LAUNCH_WIN(true, false, 2, false);
-    else if (allc) GEMHIP_LAUNCH_WIN(false, true, 2, false);
-    else GEMHIP_LAUNCH_WIN(false, false, 2, false);
 #undef GEMHIP_LAUNCH_WIN
 }
 template <bool DELTA>
