@@ -230,34 +230,38 @@ __global__ __launch_bounds__(256) void hope_tsgemm_rows_kernel(int64_t n, const 
             const int k = s * 8 + 4 * h + t;
             a[s][t] = (vr && k < m) ? px[k] : 0.f;
         }
+    // column tiles two at a time: two independent accumulation chains per wavefront (a 32x32x2 fp32 MFMA has a 64-cycle latency and each
+    // chain is serially dependent; with one chain per wavefront the matrix unit idles between issues)
     const int nct = (b2 + 31) / 32;
-    for (int ct = 0; ct < nct; ++ct) {
-        const int jcol = ct * 32 + (lane & 31);
-        const bool vc = jcol < b2;
-        f32x16 acc;
+    for (int ct = 0; ct < nct; ct += 2) {
+        const int j0 = ct * 32 + (lane & 31), j1 = j0 + 32;
+        const bool v0 = j0 < b2, v1 = j1 < b2;
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s * 8 < m) {
-                float bb[4];
+                float b0[4], b1[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int k = s * 8 + 4 * h + t;
-                    bb[t] = (vc && k < m) ? Cm[(int64_t)k * ldc + jcol] : 0.f;
+                    b0[t] = (v0 && k < m) ? Cm[(int64_t)k * ldc + j0] : 0.f;
+                    b1[t] = (v1 && k < m) ? Cm[(int64_t)k * ldc + j1] : 0.f;
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][t], bb[t], acc, 0, 0, 0);
+                for (int t = 0; t < 4; ++t) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][t], b0[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][t], b1[t], acc1, 0, 0, 0);
+                }
             }
         }
-        if (vc) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t row = rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (row < n) {
-                    const float sv = Src ? Src[row * lds_ + jcol] : 0.f;
-                    Out[row * ldo + jcol] = sv + alpha * acc[q];
-                }
+        for (int q = 0; q < 16; ++q) {
+            const int64_t row = rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (row < n) {
+                if (v0) { const float sv = Src ? Src[row * lds_ + j0] : 0.f; Out[row * ldo + j0] = sv + alpha * acc0[q]; }
+                if (v1) { const float sv = Src ? Src[row * lds_ + j1] : 0.f; Out[row * ldo + j1] = sv + alpha * acc1[q]; }
             }
         }
     }
