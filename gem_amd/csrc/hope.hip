@@ -222,16 +222,22 @@ __global__ __launch_bounds__(256, 3) void hope_tsgemm_lds_kernel(int64_t n, cons
     const int64_t rt = (int64_t)blockIdx.x * 4 + wv;
     if (rt * 32 >= n) return;
     float *T = tile[wv];
-    // whole rows, coalesced: lane l carries columns 2l, 2l+1 of the row (m <= 96 < 128)
-    for (int r = 0; r < 32; ++r) {
-        const int64_t row = rt * 32 + r;
-        float v0 = 0.f, v1 = 0.f;
-        if (row < n) {
-            const float *px = X + row * ldx;
-            if (2 * lane < m) v0 = px[2 * lane];
-            if (2 * lane + 1 < m) v1 = px[2 * lane + 1];
+    // whole rows, coalesced: lane l carries columns 2l, 2l+1 of the row (m <= 96 < 128).  All 32 row loads are issued before the first LDS store
+    // (16 at a time in registers): a load -> wait -> store loop would expose one memory latency per row
+    const bool c0 = 2 * lane < m, c1 = 2 * lane + 1 < m, cw = 2 * lane < TSG_MAXM;
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += 16) {
+        float v0[16], v1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = rt * 32 + r0 + r;
+            const float *px = X + (row < n ? row : 0) * ldx;
+            v0[r] = (row < n && c0) ? px[2 * lane] : 0.f;
+            v1[r] = (row < n && c1) ? px[2 * lane + 1] : 0.f;
         }
-        if (2 * lane < TSG_MAXM) { T[r * TSG_LDA + 2 * lane] = v0; T[r * TSG_LDA + 2 * lane + 1] = v1; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (cw) { T[(r0 + r) * TSG_LDA + 2 * lane] = v0[r]; T[(r0 + r) * TSG_LDA + 2 * lane + 1] = v1[r]; }
     }
     __builtin_amdgcn_wave_barrier();
     const int h = lane >> 5, rr = lane & 31;
