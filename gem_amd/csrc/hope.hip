@@ -206,75 +206,6 @@ __global__ void hope_reduce2_kernel(const double *__restrict__ part, int C, int 
 // ------------------------------------------- tall-skinny GEMM  O = Src + alpha X C  (MFMA fp32)
 // One wavefront per 32-row x 32-column output tile.  The MFMA's k pairs are re-labelled so that lane
 // half h covers k0+4h..k0+4h+3 over four issues: every lane reads 16 contiguous bytes of its X row.
-// Round 3: the same product for m <= 96 (every call of the eigen-path), one wavefront per 32-ROW tile.  hope_tsgemm_kernel gives every 32 x 32
-// output tile its own wavefront whose lanes each read THEIR OWN row of X 16 bytes at a time (a row-major [n][ld] block: 32 cache lines per load
-// instruction) and refetches the rows once per column tile.  Here the tile's rows arrive as whole coalesced rows (one load instruction per row), are
-// staged in LDS (row stride m8 + 4 floats: the 16-byte fragment reads of 8 consecutive lanes cover all 32 banks), the A fragments are read from LDS
-// and the column tiles are swept two at a time (two independent MFMA accumulation chains), the A fragments coming from LDS.  X is read once and Out may BE X (the
-// orthonormalisation and the Ritz rotation run in place, no scratch copy back).
-constexpr int TSG_MAXM = 96;
-constexpr int TSG_LDA = TSG_MAXM + 4;
-__global__ __launch_bounds__(256, 3) void hope_tsgemm_lds_kernel(int64_t n, const float *X, int ldx, int m, const float *__restrict__ Cm, int ldc, int b2,
-                                                              float alpha, const float *Src, int lds_, float *Out, int ldo)
-{
-    __shared__ __attribute__((aligned(16))) float tile[4][32 * TSG_LDA];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const int64_t rt = (int64_t)blockIdx.x * 4 + wv;
-    if (rt * 32 >= n) return;
-    float *T = tile[wv];
-    // whole rows, coalesced: lane l carries columns 2l, 2l+1 of the row (m <= 96 < 128).  All 32 row loads are issued before the first LDS store
-    // (16 at a time in registers): a load -> wait -> store loop would expose one memory latency per row
-    const bool c0 = 2 * lane < m, c1 = 2 * lane + 1 < m, cw = 2 * lane < TSG_MAXM;
-#pragma unroll
-    for (int r0 = 0; r0 < 32; r0 += 16) {
-        float v0[16], v1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = rt * 32 + r0 + r;
-            const float *px = X + (row < n ? row : 0) * ldx;
-            v0[r] = (row < n && c0) ? px[2 * lane] : 0.f;
-            v1[r] = (row < n && c1) ? px[2 * lane + 1] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (cw) { T[(r0 + r) * TSG_LDA + 2 * lane] = v0[r]; T[(r0 + r) * TSG_LDA + 2 * lane + 1] = v1[r]; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int h = lane >> 5, rr = lane & 31;
-    const float *Ta = T + rr * TSG_LDA + 4 * h;                  // this lane's A fragments: 16 bytes per 8 columns (columns >= m hold zeros)
-    const int nct = (b2 + 31) / 32, ks = (m + 7) / 8;
-    for (int ct = 0; ct < nct; ct += 2) {
-        const int j0 = ct * 32 + rr, j1 = j0 + 32;
-        const bool v0 = j0 < b2, v1 = j1 < b2;
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
-#pragma unroll 2
-        for (int s = 0; s < ks; ++s) {
-            float a[4], b0[4], b1[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int k = s * 8 + 4 * h + t;
-                a[t] = Ta[s * 8 + t];
-                b0[t] = (v0 && k < m) ? Cm[(int64_t)k * ldc + j0] : 0.f;
-                b1[t] = (v1 && k < m) ? Cm[(int64_t)k * ldc + j1] : 0.f;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc1, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int64_t row = rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (row < n) {
-                if (v0) { const float sv = Src ? Src[row * lds_ + j0] : 0.f; Out[row * ldo + j0] = sv + alpha * acc0[q]; }
-                if (v1) { const float sv = Src ? Src[row * lds_ + j1] : 0.f; Out[row * ldo + j1] = sv + alpha * acc1[q]; }
-            }
-        }
-    }
-}
 __global__ __launch_bounds__(256) void hope_tsgemm_kernel(int64_t n, const float *__restrict__ X, int ldx, int m, const float *__restrict__ Cm,
                                                           int ldc, int b2, float alpha, const float *Src, int lds_,
                                                           float *Out, int ldo, int ct_count)
@@ -844,19 +775,6 @@ void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int
 }
 
 // Out[:, :b2] = (Src ? Src : 0) + alpha * X[:, :m] * C   (C host fp64 m x b2 row-major)
-inline bool tsgemm_rows_ok(int m) { static const int on = getenv("GEMHIP_HOPE_TSGEMM_LDS") ? atoi(getenv("GEMHIP_HOPE_TSGEMM_LDS")) : 1; return on && m <= TSG_MAXM; }
-// Out = Src + alpha X[:, :m] C  (C: m x b2 on the device).  m <= 96: the LDS-staged row-tile kernel (X read once, Out may alias X); else one wavefront per 32 x 32 tile.
-void tsgemm_launch(Hope &H, const float *X, int ldx, int m, const float *Cd, int ldc, int b2, float alpha, const float *Src, int lds_, float *Out, int ldo)
-{
-    if (tsgemm_rows_ok(m)) {
-        hipLaunchKernelGGL(hope_tsgemm_lds_kernel, dim3((unsigned)(((H.n + 31) / 32 + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, Cd, ldc, b2, alpha, Src, lds_, Out, ldo);
-        return;
-    }
-    const int ct = (b2 + 31) / 32;
-    const int64_t tiles = ((H.n + 31) / 32) * ct;
-    hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, Cd, ldc, b2, alpha, Src, lds_, Out, ldo, ct);
-}
-
 void tsgemm(Hope &H, const float *X, int ldx, int m, const std::vector<double> &Ch, int b2, float alpha, const float *Src, int lds_, float *Out, int ldo)
 {
     if (H.err || b2 == 0) return;
@@ -876,16 +794,11 @@ void tsgemm(Hope &H, const float *X, int ldx, int m, const std::vector<double> &
     if (H.err) return;
     for (size_t i = 0; i < (size_t)m * b2; ++i) slot.h[i] = (float)Ch[i];
     HOPE_TRY(H, hipMemcpyAsync(slot.d, slot.h, (size_t)m * b2 * sizeof(float), hipMemcpyHostToDevice, H.s));
-    tsgemm_launch(H, X, ldx, m, slot.d, b2, b2, alpha, Src, lds_, Out, ldo);
+    const int ct = (b2 + 31) / 32;
+    const int64_t tiles = ((H.n + 31) / 32) * ct;
+    hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, slot.d, b2, b2, alpha, Src, lds_, Out,
+                       ldo, ct);
     HOPE_TRY(H, hipEventRecord(slot.done, H.s));
-}
-
-// Y[:, :b2] <- Y[:, :m] C: in place where the row-tile kernel applies, through the scratch block otherwise
-void tsgemm_inplace(Hope &H, float *Y, int ld, int m, const std::vector<double> &Ch, int b2, float *Tmp, int ldt)
-{
-    if (tsgemm_rows_ok(m)) { tsgemm(H, Y, ld, m, Ch, b2, 1.0f, nullptr, 0, Y, ld); return; }
-    tsgemm(H, Y, ld, m, Ch, b2, 1.0f, nullptr, 0, Tmp, ldt);
-    HOPE_TRY(H, hipMemcpy2DAsync(Y, (size_t)ld * sizeof(float), Tmp, (size_t)ldt * sizeof(float), (size_t)b2 * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
 }
 
 // W[:, :cols] -= V[:, :m] (V[:, :m]^T W[:, :cols]) with the coefficients kept in HBM: Gram, fp64 slab reduction, fp32 rounding and
@@ -898,7 +811,10 @@ void project_out(Hope &H, const float *V, int ldv, int m, float *W, int ldw, int
     if (H.err) return;
     gram_launch(H, V, ldv, m, W, ldw, cols, H.Csmall);
     if (H.err) return;
-    tsgemm_launch(H, V, ldv, m, H.Csmall, cols, cols, -1.0f, W, ldw, W, ldw);
+    const int ct = (cols + 31) / 32;
+    const int64_t tiles = ((H.n + 31) / 32) * ct;
+    hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, V, ldv, m, H.Csmall, cols, cols, -1.0f, W, ldw, W,
+                       ldw, ct);
 }
 
 // Upper-triangular Cholesky G = R^T R in fp64 with a pivot floor; on success C = R^-1 (so that (Y C)^T (Y C) = I).
@@ -958,7 +874,8 @@ int orth(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, double tol, doub
             for (int i = 0; i < keep; ++i)
                 for (int j = 0; j < nk; ++j) C[(size_t)i * nk + j] = G[(size_t)i * keep + (keep - 1 - j)] / std::sqrt(w[keep - 1 - j]);
         }
-        tsgemm_inplace(H, Y, ld, keep, C, nk, Tmp, ldt);
+        tsgemm(H, Y, ld, keep, C, nk, 1.0f, nullptr, 0, Tmp, ldt);
+        HOPE_TRY(H, hipMemcpy2DAsync(Y, (size_t)ld * sizeof(float), Tmp, (size_t)ldt * sizeof(float), (size_t)nk * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
         keep = nk;
         tol = 1e-12; abs_floor = 0.0;                          // second pass only polishes
     }
@@ -1295,7 +1212,8 @@ int orth_scaled(Hope &H, float *Y, int ld, int b, float *Tmp, int ldt, int passe
         }
         for (int i = 0; i < keep; ++i)
             for (int j = 0; j < nk; ++j) C[(size_t)i * nk + j] *= dinv[i];
-        tsgemm_inplace(H, Y, ld, keep, C, nk, Tmp, ldt);
+        tsgemm(H, Y, ld, keep, C, nk, 1.0f, nullptr, 0, Tmp, ldt);
+        HOPE_TRY(H, hipMemcpy2DAsync(Y, (size_t)ld * sizeof(float), Tmp, (size_t)ldt * sizeof(float), (size_t)nk * sizeof(float), H.n, hipMemcpyDeviceToDevice, H.s));
         keep = nk;
     }
     return keep;
@@ -1458,7 +1376,8 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         // residuals R = B C - V C diag(theta) (into F[0]), then the block becomes its Ritz vectors V C
         tsgemm(H, Va, ldv, ma, Ct, ma, 1.0f, nullptr, 0, F[0], ldv);
         tsgemm(H, Bm, ldv, ma, C, ma, 1.0f, F[0], ldv, F[0], ldv);
-        tsgemm_inplace(H, Va, ldv, ma, C, ma, Tmp, ldv);
+        tsgemm(H, Va, ldv, ma, C, ma, 1.0f, nullptr, 0, Tmp, ldv);
+        HOPE_TRY(H, hipMemcpy2DAsync(Va, (size_t)ldv * sizeof(float), Tmp, (size_t)ldv * sizeof(float), (size_t)ma * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
         std::vector<double> RR;
         gram(H, F[0], ldv, ma, F[0], ldv, ma, RR);
         if (H.err) break;
