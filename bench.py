@@ -350,7 +350,7 @@ class N2VWorkload(object):
         out = []
         gdir = os.path.join(ROOT, 'tests', 'golden')
         for f in sorted(os.listdir(gdir)):
-            if f.startswith('n2v_ref_') and f.endswith('k.json') and ('snap' in f or 'oracle' in f):
+            if f.startswith('n2v_ref_') and f.endswith('.json') and ('snap_1' in f or 'oracle_1' in f):       # the 100k / 1000k runs (race-free, 4-thread, oracle)
                 try:
                     j = json.load(open(os.path.join(gdir, f)))
                     out.append({'file': 'tests/golden/' + f, 'engine': j['engine'], 'nodes': j['params']['n'], 'edges_per_s': j['edges_per_s'],
