@@ -75,7 +75,7 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
         0.35 %, plus 0.4 % (1024-node sample) / 0.2 % (4096) sampling error of the gap that the three runs share: the bar is > 2 s.d. away on
         either side, P(flake) < 2 %.  (Round 2's default sat at -0.74 % and needed "+2 s.e.".)
       * SNAP binary: its seed is time(), so the comparison is UNPAIRED in the walks: seed-to-seed the MAP of either implementation moves by
-        ~0.5 % (s.d.; HIP 0.498-0.508 over four seeds), so two HIP seeds are averaged against the binary's single run; the expected s.d. of
+        ~0.5 % (s.d.; HIP 0.498-0.508 over four seeds), so three HIP seeds are averaged against the binary's single run (measured +0.59, +1.05, +1.62 %: mean +1.1 %, s.d. of the mean ~0.3 %); the expected s.d. of
         that gap is ~0.7 % even for identical algorithms, hence this leg asserts 2 % (a 1 % bar would flake in ~15 % of the runs) and bench.py
         prints the measured gap (`quality.map_minus_reference_map`) for the record."""
     refs = {e: golden_path(f) for e, f in (('snap', 'n2v_ref_snap_1000k.json'), ('oracle', 'n2v_ref_oracle_1000k_s4096.json'), ('oracle1k', 'n2v_ref_oracle_1000k.json'))}
@@ -105,7 +105,7 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
         ref = refs['snap']
         k = len(ref['ap'])                             # the whole 4096-node sample: over its first 2048 nodes alone the same two runs sit at +2.1 % (sampling)
         aps = np.asarray(ref['ap'])[:k]
-        gaps = [float((run(seed, k) - aps).mean() / aps.mean()) for seed in (1, 2)]
+        gaps = [float((run(seed, k) - aps).mean() / aps.mean()) for seed in (20260923, 1, 2)]
         print('1M parity, SNAP leg (unpaired seeds): gaps %s over %d nodes' % (np.round(gaps, 4).tolist(), k))
         assert abs(np.mean(gaps)) <= 0.02, (gaps, ref['MAP'])
 
