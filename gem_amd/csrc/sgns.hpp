@@ -1,0 +1,942 @@
+// sgns.hpp -- skip-gram with negative sampling on gfx950: TrainModel of the SNAP node2vec binary (ELF @0x40d6a0) as device code.
+// Shared by the three translation units that carry it:
+//   sgns_hogwild.hip  sgns_win_kernel<.., DELTA = true, ..>   the shipped Hogwild path (delta write-back, reload-on-update, hot rows)
+//   sgns_det.hip      sgns_win_kernel<.., DELTA = false, ..> + sgns_kernel   deterministic / single-wavefront launches and d >= 384
+//   n2v.hip           the C ABI (gemhip_sgns_train picks a launcher), walks, alias tables, and sgns_pairs_kernel of the partitioned schedule
+// Every kernel template is instantiated in exactly one of them; the helpers below are inlined wherever they are used.
+#pragma once
+#include "common.hpp"
+#include <type_traits>
+#include <cstdint>
+
+namespace gemhip {
+
+struct SgnsArgs {
+    const int32_t *walks; int64_t walk_lo, walk_hi; int32_t walk_len; int32_t window;
+    float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
+    const float *UT; const int32_t *KT; const uint2 *UK; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
+    float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs;
+    float *dummy;               // sgns_win_kernel: nwaves rows, never read for their value
+    unsigned long long *prof;   // GEMHIP_SGNS_PROFILE builds only: per-phase cycle sums (s_memtime)
+    int32_t cache_radius;       // sgns_win_kernel: tokens within this many positions of the centre keep their SynPos row in LDS
+    int32_t prefetch;           // sgns_win_kernel: pairs whose negative rows are requested ahead (2, or 1)
+    int32_t reload;             // sgns_win_kernel<RELOAD>: negative rows updated as they are at store time, centre row by atomic add
+    const int32_t *counts; int32_t hot_thr;   // sgns_win_kernel<!ALLC>: nodes with counts[v] >= hot_thr > 0 never enter the LDS window (HOT ROWS below)
+};
+
+using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
+sgns_fn pick_sgns(int d);                    // sgns_det.hip: sgns_kernel (no LDS window), nullptr when d is unsupported (even d <= 512, odd d <= 256)
+sgns_fn pick_sgns_win_det(int d);            // sgns_det.hip: sgns_win_kernel, overwrite on leave (bit-compatible with sgns_kernel on one wavefront)
+sgns_fn pick_sgns_win_hogwild(int d);        // sgns_hogwild.hip: sgns_win_kernel, delta write-back
+// floats one cached row occupies in LDS (the wave's footprint of a row, see sgns_win_kernel)
+inline int sgns_win_row_floats(int d) { return d % 2 == 0 ? ((d + 127) / 128) * 128 : ((d + 63) / 64) * 64; }
+}  // namespace gemhip
+
+using namespace gemhip;
+
+namespace {
+enum { TAG_WALK = 1, TAG_WIN = 2, TAG_NEG = 3, TAG_INIT = 4 };
+constexpr int SGNS_NEG = 5;             // SNAP: NegSamN = 5 (compile-time constant there too)
+constexpr float SGNS_MAX_EXP = 6.0f;    // SNAP: MaxExp
+constexpr int HOGWILD_ROWS_PER_WAVE = 128;
+
+__host__ __device__ __forceinline__ uint32_t mulhi_range(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
+
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+
+// Embedding rows are shared, concurrently updated state (Hogwild).  gfx950 has one L1 per CU that is
+// never refreshed by other CUs' stores and one write-back L2 per XCD that is not coherent with the
+// other seven, so PLAIN loads/stores let every CU train on its own stale copy of the table (measured:
+// SBM-1024 MAP 0.177 on one CU -> 0.09 on many).  All row traffic therefore uses relaxed AGENT-scope
+// atomic accesses (global_load/store ... sc1): they bypass L1, are coherent across XCDs per location,
+// and cost the same bytes.  8 bytes per lane when d is even, 4 otherwise.
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gu32 = __attribute__((address_space(1))) unsigned int;
+
+template <int VEC>
+__device__ __forceinline__ void ld_row(const float *p, int d, int lane, int c, float (&v)[VEC])
+{
+    const int idx = (c * WAVE + lane) * VEC;
+    if constexpr (VEC == 2) {
+        if (idx < d) {
+            const unsigned long long t = __hip_atomic_load((gu64 *)(p + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[0] = __builtin_bit_cast(float, (unsigned int)t);
+            v[1] = __builtin_bit_cast(float, (unsigned int)(t >> 32));
+        } else { v[0] = 0.f; v[1] = 0.f; }
+    } else {
+        v[0] = idx < d ? __builtin_bit_cast(float, __hip_atomic_load((gu32 *)(p + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void st_row(float *p, int d, int lane, int c, const float (&v)[VEC])
+{
+    const int idx = (c * WAVE + lane) * VEC;
+    if (idx < d) {
+        if constexpr (VEC == 2) {
+            const unsigned long long t = (unsigned long long)__builtin_bit_cast(unsigned int, v[0]) |
+                                         ((unsigned long long)__builtin_bit_cast(unsigned int, v[1]) << 32);
+            __hip_atomic_store((gu64 *)(p + idx), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store((gu32 *)(p + idx), __builtin_bit_cast(unsigned int, v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// this lane's VEC floats of a row, to an address the caller already holds (same relaxed agent-scope store as st_row)
+template <int VEC>
+__device__ __forceinline__ void st_lane(float *q, const float (&v)[VEC])
+{
+    if constexpr (VEC == 2) {
+        const unsigned long long t = (unsigned long long)__builtin_bit_cast(unsigned int, v[0]) | ((unsigned long long)__builtin_bit_cast(unsigned int, v[1]) << 32);
+        __hip_atomic_store((gu64 *)q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else __hip_atomic_store((gu32 *)q, __builtin_bit_cast(unsigned int, v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+// gradient scale of TrainModel: (label - sigma(f)) * alpha with the +-MaxExp clamps
+__device__ __forceinline__ float sgns_grad(float f, float label, float alpha)
+{
+    if (f > SGNS_MAX_EXP) return (label - 1.0f) * alpha;
+    if (f < -SGNS_MAX_EXP) return label * alpha;
+    return (label - 1.0f + 1.0f / (1.0f + expf(f))) * alpha;
+}
+
+// The same quantity without branches and with the hardware's 1-ulp exp / reciprocal (v_exp_f32, v_rcp_f32) instead of the IEEE expf and
+// division sequences (~45 instructions, three exec-mask branches): (label - sigma(f)) * alpha, sigma forced to 1 / 0 beyond +-MaxExp exactly
+// like TrainModel's clamps.  Differs from sgns_grad by ~2e-7 relative -- three orders below the 2e-4 bar against the oracle (whose own
+// reference, SNAP, reads sigma from a 1000-entry table).  Used by the window kernels' lane-parallel sigmoid.
+__device__ __forceinline__ float sgns_grad_fast(float f, float label, float alpha)
+{
+    const float e = __expf(f);                                    // v_exp_f32(f * log2 e)
+    float one_minus_sigma = __builtin_amdgcn_rcpf(1.0f + e);      // 1 / (1 + e^f) = 1 - sigma(f)  (v_rcp_f32, 1 ulp; __frcp_rn compiles to the 10-instruction IEEE division)
+    one_minus_sigma = f > SGNS_MAX_EXP ? 0.0f : one_minus_sigma;
+    one_minus_sigma = f < -SGNS_MAX_EXP ? 1.0f : one_minus_sigma;
+    return (label - 1.0f + one_minus_sigma) * alpha;
+}
+
+// TrainModel (ELF @0x40d6a0).  One wavefront owns one walk: tokens and the pre-drawn
+// negative targets of the current centre sit in LDS; the centre's positive row SynNeg[word]
+// stays in registers across all its contexts; per context the context row and the five
+// negative rows are fetched together (6 coalesced 4d-byte reads in flight), reduced with
+// DPP wave sums, and written back.  Hogwild across wavefronts, exactly sequential inside one.
+template <int VEC, int NV>
+__global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int per_wave = A.walk_len + 2 * A.window * SGNS_NEG;
+    int32_t *tok = lds + wave * per_wave;
+    int32_t *negs = tok + A.walk_len;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (gw >= A.nwaves) return;
+    const int d = A.d;
+    const int win = A.window;
+    const bool quirk = (A.flags & 2) != 0;
+
+    unsigned long long npairs = 0;
+    for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
+        const int32_t *walk = A.walks + wl * A.walk_len;
+        for (int k = lane; k < A.walk_len; k += WAVE) tok[k] = walk[k];
+        __builtin_amdgcn_wave_barrier();
+        const int64_t wid = A.walk_id_offset + wl;
+        const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
+
+        for (int pos = 0; pos < A.walk_len; ++pos) {
+            const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
+            if (word < 0) continue;
+            // alpha: refreshed every 10000 words of the global count (TrainModel)
+            const int64_t t = A.token_offset + wl * A.walk_len + pos;
+            const int64_t tq = t - (t % 10000);
+            float alpha = A.alpha0 * (1.0f - (float)((double)tq / (double)A.denom));
+            alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
+            const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
+            const int b = (int)(rw.x % (uint32_t)win);
+            // draw every negative target of this centre at once: sample s = (a, j) -> lane-parallel table lookups
+            const int nsamp = 2 * win * SGNS_NEG;
+            for (int s = lane; s < nsamp; s += WAVE) {
+                const int ai = s / SGNS_NEG;                 // 0 .. 2*win-1  (context slot, skipping the centre)
+                const int a = ai < win ? ai : ai + 1;
+                const int j = s - ai * SGNS_NEG + 1;
+                const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos | ((uint32_t)a << 16),
+                                               (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
+                const uint32_t slot = mulhi_range(rn.x, A.n);
+                const int32_t X = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
+                negs[s] = (u01(rn.y) < A.UT[X]) ? X : A.KT[X];
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            float yp[NV][VEC];                               // SynNeg[word]: positive target of every context of this centre
+            float *pp = A.SynNeg + (int64_t)word * d;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
+
+            for (int a = b; a < 2 * win + 1 - b; ++a) {
+                if (a == win) continue;
+                const int cp = pos - win + a;
+                if (cp < 0 || cp >= A.walk_len) continue;
+                const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[cp]);
+                if (ctx < 0) continue;
+                const int ai = a < win ? a : a - 1;
+                ++npairs;
+                int32_t tgt[SGNS_NEG];
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readfirstlane(negs[ai * SGNS_NEG + j]);
+
+                float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
+                float *pc = A.SynPos + (int64_t)ctx * d;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) {
+                    const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
+                }
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) neu[c][v] = 0.f;
+
+                {   // j = 0: positive target (label 1), row lives in registers
+                    float part = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yp[c][v], part);
+                    const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yp[c][v], neu[c][v]); yp[c][v] = fmaf(g, xc[c][v], yp[c][v]); }
+                }
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) {
+                    if (tgt[j] == word) continue;                        // TrainModel: `if (Target == Word) continue`
+                    // a target drawn twice for this context must see the first update (sequential semantics)
+#pragma unroll
+                    for (int jp = 0; jp < j; ++jp)
+                        if (tgt[jp] == tgt[j] && tgt[jp] != word) {
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int v = 0; v < VEC; ++v) yn[j][c][v] = yn[jp][c][v];
+                        }
+                    float part = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yn[j][c][v], part);
+                    const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
+                    float *pn = A.SynNeg + (int64_t)tgt[j] * d;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
+                }
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
+                    st_row<VEC>(pc, d, lane, c, xc[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NV; ++c) st_row<VEC>(pp, d, lane, c, yp[c]);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
+}
+
+#ifdef GEMHIP_SGNS_PROFILE
+#define PROF_T() ({ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long _t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); _t; })
+#define PROF_DECL unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t = 0
+#define PROF_START() prof_t = PROF_T()
+#define PROF_LAP(k) do { const unsigned long long _n = PROF_T(); prof_acc[k] += _n - prof_t; prof_t = _n; } while (0)
+#define PROF_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_LAP(k)
+#define PROF_WAIT_VM(n)
+#endif
+
+// ---- window-cached TrainModel (default since round 2) ------------------------------------------------------------
+// Same arithmetic, same order and same Philox draws as sgns_kernel; what changes is WHERE the context rows live.
+// A token is a context of every centre within `window` positions, so sgns_kernel moves its SynPos row 2 x ~11 times.
+// Here one wavefront (= one 64-thread block = one walk at a time) keeps the rows of the tokens within `R` positions
+// of the centre in LDS: a token's row is read once when it enters the window and written once when it leaves
+// (2R+1 slots; repeated nodes share a slot through a (node -> slot) directory held across the lanes, so the sequence of
+// values every row takes inside one wavefront is exactly TrainModel's).  Contexts farther than R (only possible when
+// R < window) go straight to memory as before -- the directory lookup precedes every access, so cached and direct
+// accesses never alias.
+// Hogwild: other wavefronts may update a cached row while it sits in LDS.  DELTA mode (multi-wave launches) keeps the
+// row as loaded next to the working copy and leaves with `row_now + (working - loaded)`: nothing another wavefront
+// wrote in between is lost (the read-modify-write window is one centre step, as short as sgns_kernel's per-pair
+// windows); a single-wave (deterministic) launch writes the working copy back as is.
+// Latency at 1 wave per SIMD-ish occupancy (the LDS window bounds residency at ~7-13 waves per CU): the negative rows of
+// the next TWO (centre, context) pairs are in flight while a pair is computed (targets equal to a row updated in
+// between are re-forwarded from registers: exact), and the negative targets are drawn two centres ahead.
+// Six dot products at once.  Every lane holds its partial sums p[0..5]; on return lane l holds the WAVE TOTAL of value
+// idx(l) = (l & 4) ? 4 + (l & 1) : (l & 3)  (so lanes 0..5 hold totals 0..5).  Transposing while reducing (each lane keeps the half
+// of the values its lane bit selects and hands the other half to its partner) costs 22 lane operations for all six sums,
+// against 6 x 11 for six wave_sum calls -- and leaves the six totals in six LANES, so the sigmoid of TrainModel runs once,
+// lane-parallel, instead of six times.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+typedef unsigned int n2v_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float wave_sum6(const float (&p)[6], int lane)
+{
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+    // lane bit 0 (partner l^1): values (0,1) (2,3) (4,5)
+    const float a0 = (b0 ? p[1] : p[0]) + dpp_mov<0xB1>(b0 ? p[0] : p[1]);
+    const float a1 = (b0 ? p[3] : p[2]) + dpp_mov<0xB1>(b0 ? p[2] : p[3]);
+    const float a2 = (b0 ? p[5] : p[4]) + dpp_mov<0xB1>(b0 ? p[4] : p[5]);
+    // lane bit 1 (partner l^2): quad totals; value index 2*b1 + b0 in c0, 4 + b0 in c1
+    float c0 = (b1 ? a1 : a0) + dpp_mov<0x4E>(b1 ? a0 : a1);
+    float c1 = a2 + dpp_mov<0x4E>(a2);
+    // the four quads of a row of 16 lanes: rotate by 4 and by 8
+    c0 += dpp_mov<0x124>(c0); c0 += dpp_mov<0x128>(c0);
+    c1 += dpp_mov<0x124>(c1); c1 += dpp_mov<0x128>(c1);
+    float m = b2 ? c1 : c0;
+    // the four rows: v_permlane16_swap / v_permlane32_swap of (m, m) give {even-row copy, odd-row copy}
+    // (elements are copied to scalars first: __builtin_bit_cast applied directly to `r.y` reads element 0 with this compiler)
+    n2v_u32x2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    unsigned lo = r.x, hi = r.y;
+    m = __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
+    r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    lo = r.x; hi = r.y;
+    return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
+}
+
+template <int VEC, int NV>
+struct NegSet {
+    int32_t tv;                 // lanes 0..4: the five targets (lane form, for the any-match test)
+    int32_t cnt;                // lanes 0..4: their token counts (instantiations that handle hot rows: fetched with the rows)
+    int32_t tgt[SGNS_NEG];
+    float y[SGNS_NEG][NV][VEC]; // their SynNeg rows (in flight, then updated in place)
+};
+
+// FULL: d == NV * VEC * 64, rows need no tail guard.  ALLC: R >= window, every context row is in the LDS window.
+// With both, the pair loop has a STATIC number of memory operations per pair (skipped targets and exhausted prefetch slots
+// go to a per-wave dummy row instead of branching), which is what lets the compiler keep two pairs' rows in flight with
+// counted s_waitcnt vmcnt(N) instead of draining to vmcnt(0) at every control-flow merge.
+// PF: pairs whose negative rows are requested ahead (2 by default; 1 keeps 10 instead of 15 rows of a wavefront open between load and store).
+// RELOAD (Hogwild launches, default): the update of a negative row is applied to the row AS IT IS NOW -- the five rows are fetched again
+// right after the dot products (the gradient still uses the copy requested PF pairs ahead) and leave as `row_now + g * xc` -- and the centre's
+// positive row leaves as an atomic add of what this centre changed.  A store another wavefront makes between a row's first load and its
+// store is no longer overwritten: the window in which it can be lost shrinks from (PF + 1) pair steps to one reload round trip.  The CPU
+// replay of this kernel's concurrency (scripts/hogwild_emul) attributes ~90 % of Hogwild's MAP loss to those overwritten negative-row
+// updates and the rest to the centre row's; stale gradients themselves cost nothing.
+// HOT ROWS (power-law graphs; !ALLC instantiations with A.hot_thr > 0).  A node that makes up the fraction p of all tokens sits in
+// W x (2R+1) x p LDS windows at once; every one of those copies trains for ~2R+1 centres on a stale base and leaves as a delta -- for a
+// hub that is hundreds of concurrent copies whose deltas ADD UP (measured on R-MAT scale 17, 985 wavefronts: MAP -15 % against the sequential
+// algorithm, with or without RELOAD; the SBM graphs have no such node).  Nodes whose expected number of concurrent copies reaches 1
+// (counts[v] >= tokens / (W x (2R+1))) therefore never enter the window: as a context their row is fetched for the pair and takes its
+// neu1e by atomic add (RELOAD) or a plain store, like the contexts beyond the cached radius.
+template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC, int PF = 2, bool RELOAD = false>
+__global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
+{
+    static_assert(PF == 1 || PF == 2, "prefetch distance");
+    static_assert(!RELOAD || DELTA, "RELOAD is a Hogwild (delta write-back) mode");
+    static_assert(PF == 2 || (FULL && ALLC), "the shorter prefetch exists for the all-cached full-row kernel only");
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    constexpr int RW = NV * VEC * WAVE;              // floats per cached row (row padded to the wave's footprint)
+    constexpr int NS = 2;                            // negative samples per lane and centre: 2*window*5 <= 128
+    const int lane = lane_id();
+    const int64_t gw = blockIdx.x;
+    if (gw >= A.nwaves) return;
+    const int d = A.d, win = A.window, len = A.walk_len, R = A.cache_radius, S = 2 * R + 1;
+    const int nsamp = 2 * win * SGNS_NEG;
+    const bool quirk = (A.flags & 2) != 0;
+    int32_t *tok = lds;
+    int32_t *negs = tok + len;                       // [2][nsamp]
+    float *rowsL = reinterpret_cast<float *>(lds + ((len + 2 * nsamp + 3) & ~3));
+    float *rowsO = rowsL + (size_t)(S + 1) * RW;     // DELTA only; slot S of rowsL stages a context row that is not cached
+
+    auto lds_ld = [&](const float *row, float (&v)[NV][VEC]) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[c][k] = row[(c * WAVE + lane) * VEC + k];
+    };
+    auto lds_st = [&](float *row, const float (&v)[NV][VEC]) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) row[(c * WAVE + lane) * VEC + k] = v[c][k];
+    };
+    const int dg = FULL ? NV * VEC * WAVE : d;       // guard bound of ld_row/st_row: a compile-time constant when FULL
+    auto g_ld = [&](const float *p, float (&v)[NV][VEC]) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) ld_row<VEC>(p, dg, lane, c, v[c]);
+    };
+    auto g_st = [&](float *p, const float (&v)[NV][VEC]) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) st_row<VEC>(p, dg, lane, c, v[c]);
+    };
+
+    float *dummy = A.dummy + (size_t)gw * RW;        // this wave's private sink / source for predicated-off row traffic
+    auto is_hot = [&](int32_t v) -> bool {           // (wave-uniform v: a scalar load)
+        if constexpr (ALLC) return false;
+        else return A.hot_thr > 0 && A.counts[v] >= A.hot_thr;
+    };
+    auto o_st = [&](int slot, const float (&v)[NV][VEC]) {            // the row as loaded (delta write-back)
+        lds_st(rowsO + (size_t)slot * RW, v);
+    };
+    auto o_ld = [&](int slot, float (&v)[NV][VEC]) {
+        lds_ld(rowsO + (size_t)slot * RW, v);
+    };
+    unsigned long long npairs = 0;
+    PROF_DECL;
+    PROF_START();
+    for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
+        const int32_t *walk = A.walks + wl * len;
+        for (int k = lane; k < len; k += WAVE) tok[k] = walk[k];
+        __builtin_amdgcn_wave_barrier();
+        const int64_t wid = A.walk_id_offset + wl;
+        const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
+
+        // slot directory: lane s < S describes slot s
+        int32_t slot_node = -1, slot_ref = 0;
+
+        // --- negative-target pipeline: stage A (table slot -> X) for centre p, stage B (UT[X], KT[X]), finalize -> LDS
+        int32_t XA[NS], XB[NS], KTv[NS]; float uA[NS], uB[NS], UTv[NS];
+        // Only the samples of contexts the centre will train on are drawn: the window shrink b of centre p is itself a Philox draw, the
+        // draws are counter-based (skipping one changes no other), and the 2 x 3 uncoalesced table gathers per centre turned out to be what
+        // caps the kernel (scripts/microbench/rows.hip "mix": 6.2 -> 4.5 G rows/s with them) -- 45 % of the slots are never used.
+        bool liveA[NS], liveB[NS];
+        auto stage_a = [&](int p) {
+            int bp = 0;
+            if (p < len) {
+                const u32x4 rwp = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
+                bp = (int)(rwp.x % (uint32_t)win);
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = lane + k * WAVE;
+                XA[k] = 0; uA[k] = 0.f; liveA[k] = false;
+                if (p < len && s < nsamp) {
+                    const int ai = s / SGNS_NEG;
+                    const int a = ai < win ? ai : ai + 1;
+                    const int cp = p - win + a;
+                    if (a >= bp && a < 2 * win + 1 - bp && cp >= 0 && cp < len) {
+                        liveA[k] = true;
+                        const int j = s - ai * SGNS_NEG + 1;
+                        const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p | ((uint32_t)a << 16),
+                                                       (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
+                        const uint32_t slot = mulhi_range(rn.x, A.n);
+                        XA[k] = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
+                        uA[k] = u01(rn.y);
+                    }
+                }
+            }
+        };
+        auto stage_b = [&]() {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                XB[k] = XA[k]; uB[k] = uA[k]; liveB[k] = liveA[k]; UTv[k] = 2.f; KTv[k] = 0;
+                if (liveB[k]) { const uint2 uk = A.UK[XB[k]]; UTv[k] = __builtin_bit_cast(float, uk.x); KTv[k] = (int32_t)uk.y; }   // one 8-byte gather
+            }
+        };
+        // ... and the "special" mask of centre p: bit ai is set when the (centre, context) pair of slot ai cannot take the
+        // all-targets-independent fast path -- a target equals the centre word (TrainModel skips it), a target was drawn twice
+        // (the second use must see the first update), or a target also occurs in one of the previous two slots (this slot's rows
+        // were requested before those slots' updates were stored, so the slow path fetches them again).  One lane per slot,
+        // once per centre; at n = 1M it is set for ~1e-4 of the pairs, on karate (n = 34) for nearly all.
+        auto stage_fin = [&](int p) -> uint32_t {
+            int32_t *dst = negs + (p & 1) * nsamp;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = lane + k * WAVE;
+                if (s < nsamp) dst[s] = (uB[k] < UTv[k]) ? XB[k] : KTv[k];
+            }
+            if (p >= len) return 0u;
+            const int32_t wordn = __builtin_amdgcn_readfirstlane(tok[p]);
+            bool sp = false;
+            if (lane < 2 * win) {
+                int32_t t[SGNS_NEG];
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j) { t[j] = dst[lane * SGNS_NEG + j]; sp = sp || t[j] == wordn; }
+#pragma unroll
+                for (int j = 0; j < SGNS_NEG; ++j)
+#pragma unroll
+                    for (int jp = 0; jp < j; ++jp) sp = sp || t[j] == t[jp];
+#pragma unroll
+                for (int k = 0; k < 2 * SGNS_NEG; ++k) {
+                    const int idx = (lane - 2) * SGNS_NEG + k;
+                    const int32_t u = dst[idx >= 0 ? idx : 0];
+#pragma unroll
+                    for (int j = 0; j < SGNS_NEG; ++j) sp = sp || (idx >= 0 && t[j] == u);
+                }
+            }
+            return (uint32_t)__builtin_amdgcn_ballot_w64(sp);
+        };
+        stage_a(0); stage_b();
+        uint32_t spec_next = stage_fin(0);
+        stage_a(1);
+
+        // --- cache: enter token q (directory now, row through `rowE` -> LDS by the caller), leave token q
+        // rows of tokens 0 .. R-1 enter before the first centre
+        for (int q = 0; q < R && q < len; ++q) {
+            const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
+            if (v < 0 || is_hot(v)) continue;
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
+            if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; continue; }
+            const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node < 0 && lane < S));
+            float r[NV][VEC];
+            g_ld(A.SynPos + (int64_t)v * d, r);
+            lds_st(rowsL + (size_t)s * RW, r);
+            if constexpr (DELTA) o_st(s, r);
+            if (lane == s) { slot_node = v; slot_ref = 1; }
+        }
+
+        // data and address registers of the stores a centre ends with.  They are kept alive (empty asm "uses" inside the next centre's pair steps) so
+        // that the register allocator cannot hand them out again right away: overwriting the source registers of a store that is still in flight is
+        // a write-after-read hazard the compiler guards with s_waitcnt vmcnt(0) -- a full drain that waits for the store's acknowledgement (seen in the
+        // ISA: three such drains per centre, ~a quarter of the kernel's time)
+        float tail_d0[NV][VEC], tail_d1[NV][VEC]; float *tail_p0[NV], *tail_p1[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            tail_p0[c] = tail_p1[c] = nullptr;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) tail_d0[c][k] = tail_d1[c][k] = 0.f;
+        }
+        auto tail_keep = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                asm volatile("" ::"v"(tail_p0[c]), "v"(tail_p1[c]));
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(tail_d0[c][k]), "v"(tail_d1[c][k]));
+            }
+        };
+        for (int pos = 0; pos < len; ++pos) {
+            const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
+            uint32_t spec_cur = spec_next;
+            bool fin_done = false;
+            // token pos+R enters
+            float rowE[NV][VEC]; int sE = -1;
+            if (pos + R < len) {
+                const int32_t v = __builtin_amdgcn_readfirstlane(tok[pos + R]);
+                if (v >= 0 && !is_hot(v)) {
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
+                    if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; }
+                    else {
+                        sE = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node < 0 && lane < S));
+                        g_ld(A.SynPos + (int64_t)v * d, rowE);
+                        if (lane == sE) { slot_node = v; slot_ref = 1; }
+                    }
+                }
+            }
+            // token pos-R leaves after this centre: when it is the last holder of its slot, fetch the row as it is NOW
+            float rowG[NV][VEC], rowO[NV][VEC]; int sX = -1; int32_t vX = -1;
+            if (pos - R >= 0) {
+                vX = __builtin_amdgcn_readfirstlane(tok[pos - R]);
+                const unsigned long long hx = vX >= 0 ? __builtin_amdgcn_ballot_w64(slot_node == vX) : 0ull;     // (no slot: a hot row, never cached)
+                if (hx) {
+                    const int s = (int)__builtin_ctzll(hx);
+                    const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
+                    if (lane == s) slot_ref = refc;
+                    if (refc == 0) {
+                        sX = s;
+                        if constexpr (DELTA && !RELOAD) g_ld(A.SynPos + (int64_t)vX * d, rowG);      // (RELOAD: the row leaves as an atomic add of its change)
+                    }
+                }
+            }
+            // negatives: B for centre pos+1, A for centre pos+2
+            PROF_LAP(0);
+            stage_b();
+            stage_a(pos + 2);
+            PROF_LAP(5);                                             // negative-target pipeline: stage B gathers, stage A Philox + table gather
+
+            float yp[NV][VEC], yp0[NV][VEC];                         // the centre's positive row SynNeg[word] (and, RELOAD, as it was loaded)
+            float *pp = A.SynNeg + (int64_t)(word >= 0 ? word : 0) * d;
+            if (word >= 0) {
+                const int64_t t = A.token_offset + wl * len + pos;
+                const int64_t tq = t - (t % 10000);
+                float alpha = A.alpha0 * (1.0f - (float)((double)tq / (double)A.denom));
+                alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
+                const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
+                const int b = (int)(rw.x % (uint32_t)win);
+                const int32_t *ncur = negs + (pos & 1) * nsamp;
+
+                g_ld(pp, yp);
+                if constexpr (RELOAD) {
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) yp0[c][k] = yp[c][k];
+                }
+
+                // the contexts of this centre, ascending (TrainModel's order): bit a <-> position pos - win + a
+                bool valid = false;
+                {
+                    const int a = lane, cp = pos - win + a;
+                    if (a >= b && a < 2 * win + 1 - b && a != win && cp >= 0 && cp < len) valid = tok[cp] >= 0;
+                }
+                unsigned long long m_proc = __builtin_amdgcn_ballot_w64(valid), m_iss = m_proc;
+                npairs += (unsigned long long)__builtin_popcountll(m_proc);
+                {   // the slots after ai in flight are ai+1, ai+2 only if the valid contexts are contiguous (always, but for padded walks)
+                    const unsigned long long lowm = (1ull << win) - 1ull;
+                    const unsigned long long mai = (m_proc & lowm) | ((m_proc >> (win + 1)) << win);
+                    const unsigned long long sh = mai ? (mai >> __builtin_ctzll(mai)) : 0ull;
+                    if (sh & (sh + 1ull)) spec_cur = 0xFFFFFFFFu;
+                }
+
+                NegSet<VEC, NV> q0, q1, q2;          // three register sets rotate: processed now / next / the one after
+                auto issue = [&](NegSet<VEC, NV> &Q) __attribute__((always_inline)) {
+                    const bool live = m_iss != 0;                   // exhausted: the same five loads, from the dummy row
+                    const int a = live ? (int)__builtin_ctzll(m_iss) : 0;
+                    m_iss &= m_iss - 1;
+                    const int ai = a < win ? a : a - 1;
+                    Q.tv = ncur[ai * SGNS_NEG + (lane < SGNS_NEG ? lane : 0)];
+                    if (lane >= SGNS_NEG || !live) Q.tv = -1;
+                    if constexpr (!ALLC && RELOAD) Q.cnt = A.counts[Q.tv >= 0 ? Q.tv : 0];      // one 4-byte gather per pair, in flight with the rows
+#pragma unroll
+                    for (int j = 0; j < SGNS_NEG; ++j) {
+                        Q.tgt[j] = __builtin_amdgcn_readlane(Q.tv, j);
+                        g_ld(live ? A.SynNeg + (int64_t)Q.tgt[j] * d : dummy, Q.y[j]);
+                    }
+                };
+                issue(q0);
+                if constexpr (PF == 2) issue(q1);
+
+                if (sE >= 0) {               // the entering row has landed by now (requested before everything above)
+                    lds_st(rowsL + (size_t)sE * RW, rowE);
+                    if constexpr (DELTA) o_st(sE, rowE);
+                }
+                // the centre row is needed by the first pair anyway; "using" it here pins its wait BEFORE the pair loop (a counted wait: the prefetches just
+                // issued stay in flight), so that the compiler does not have to drain everything when it meets yp again after a loop it cannot count through
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(yp[c][k]));
+                PROF_LAP(6);                                         // centre set-up: alpha, window draw, masks, centre row request, first prefetches, entering row -> LDS
+
+                // one (centre, context) pair: C holds its negative rows, the sets in between are in flight, P2 is free
+                auto step = [&](NegSet<VEC, NV> &C, NegSet<VEC, NV> &P2) __attribute__((always_inline)) {
+                    PROF_LAP(0);                                     // outside the pair steps (per-centre work, loop control)
+                    const int a = (int)__builtin_ctzll(m_proc);
+                    m_proc &= m_proc - 1;
+                    issue(P2);
+                    PROF_LAP(1);                                     // issue of the prefetch
+
+                    const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[pos - win + a]);
+                    const unsigned long long chit = __builtin_amdgcn_ballot_w64(slot_node == ctx);
+                    float *lrow = rowsL + (size_t)((ALLC || chit) ? (int)__builtin_ctzll(chit) : S) * RW;
+                    float *pc = A.SynPos + (int64_t)ctx * d;
+                    float xc[NV][VEC], neu[NV][VEC];
+                    if constexpr (!ALLC)
+                        if (!chit) {        // beyond the cached radius: stage through LDS so that the wait for this row stays inside the branch
+                            float t[NV][VEC];
+                            g_ld(pc, t);
+                            lds_st(lrow, t);
+                        }
+                    lds_ld(lrow, xc);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) neu[c][k] = 0.f;
+                    const int ai_c = a < win ? a : a - 1;
+                    PROF_LAP(2);                                     // context lookup + LDS read (includes its lgkmcnt wait)
+                    if constexpr (PF == 2) PROF_WAIT_VM(10); else PROF_WAIT_VM(5);
+                    PROF_LAP(3);                                     // waiting for this pair's rows (the younger prefetches may stay in flight)
+                    tail_keep();                                     // (no instruction: the previous centre's store registers stay reserved up to here)
+                    if (!fin_done) {
+                        // the negative targets of the NEXT centre: their table gather (stage_b, issued before this centre's first prefetch) is older than
+                        // the rows just waited for, so consuming it HERE costs no wait; after the pair loop it would be a full drain
+                        spec_next = stage_fin(pos + 1);
+                        fin_done = true;
+                    }
+                    if (!((spec_cur >> ai_c) & 1u)) {
+                        // fast path: the six targets are distinct rows and none is the centre word -> six independent updates
+                        float part[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) part[j] = 0.f;
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) {
+                                part[0] = fmaf(xc[c][k], yp[c][k], part[0]);
+#pragma unroll
+                                for (int j = 0; j < SGNS_NEG; ++j) part[j + 1] = fmaf(xc[c][k], C.y[j][c][k], part[j + 1]);
+                            }
+                        float Rn[RELOAD ? SGNS_NEG : 1][NV][VEC];
+                        if constexpr (RELOAD) {      // the five rows as they are NOW (requested here, needed after the sigmoid)
+#pragma unroll
+                            for (int j = 0; j < SGNS_NEG; ++j) g_ld(A.SynNeg + (int64_t)C.tgt[j] * d, Rn[j]);
+                        }
+                        const float f = wave_sum6(part, lane);
+                        const float gl = sgns_grad_fast(f, (lane & 7) == 0 ? 1.0f : 0.0f, alpha);     // lanes 0..5: g of target 0..5
+                        float g[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) g[j] = bcast_lane(gl, j);
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) {
+                                neu[c][k] = fmaf(g[0], yp[c][k], neu[c][k]);
+                                yp[c][k] = fmaf(g[0], xc[c][k], yp[c][k]);
+                            }
+                        if constexpr (RELOAD) {
+#pragma unroll
+                            for (int j = 0; j < SGNS_NEG; ++j)
+#pragma unroll
+                                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                    for (int k = 0; k < VEC; ++k) neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
+                            // hot negative rows (hubs drawn as negatives by many wavefronts at once): their update is an atomic add of g * xc -- no
+                            // window at all -- and the row-sized store goes to the scratch row instead (the number of loads / stores per pair stays static)
+                            unsigned hotm = 0u;
+                            if constexpr (!ALLC) hotm = A.hot_thr > 0 ? (unsigned)__builtin_amdgcn_ballot_w64(lane < SGNS_NEG && C.cnt >= A.hot_thr) : 0u;
+#pragma unroll
+                            for (int j = 0; j < SGNS_NEG; ++j) {
+                                const bool hotj = (hotm >> j) & 1u;
+                                float *pj = A.SynNeg + (int64_t)C.tgt[j] * d;
+                                if (hotj) {
+#pragma unroll
+                                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                        for (int k = 0; k < VEC; ++k)
+                                            if ((c * WAVE + lane) * VEC + k < dg)
+                                                __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pj + (c * WAVE + lane) * VEC + k), g[j + 1] * xc[c][k]);
+                                }
+#pragma unroll
+                                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                    for (int k = 0; k < VEC; ++k) Rn[j][c][k] = fmaf(g[j + 1], xc[c][k], Rn[j][c][k]);
+                                g_st(hotj ? dummy : pj, Rn[j]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < SGNS_NEG; ++j) {
+#pragma unroll
+                                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                    for (int k = 0; k < VEC; ++k) {
+                                        neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
+                                        C.y[j][c][k] = fmaf(g[j + 1], xc[c][k], C.y[j][c][k]);
+                                    }
+                                g_st(A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                            }
+                        }
+                    } else {
+                        // slow path (exact sequential semantics): the rows may have been requested before an update of the same row by
+                        // one of the two previous pairs was stored -- fetch them again (program order after those stores)
+#pragma unroll
+                        for (int j = 0; j < SGNS_NEG; ++j) g_ld(C.tgt[j] < 0 ? dummy : A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                        {   // positive target (label 1), row lives in registers
+                            float part = 0.f;
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) part = fmaf(xc[c][k], yp[c][k], part);
+                            const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) { neu[c][k] = fmaf(g, yp[c][k], neu[c][k]); yp[c][k] = fmaf(g, xc[c][k], yp[c][k]); }
+                        }
+#pragma unroll
+                        for (int j = 0; j < SGNS_NEG; ++j) {
+                            const bool skip = C.tgt[j] == word || C.tgt[j] < 0;  // TrainModel: `if (Target == Word) continue` (predicated: g = 0, row -> dummy)
+#pragma unroll
+                            for (int jp = 0; jp < j; ++jp)                       // a target drawn twice sees the first update
+                                if (C.tgt[jp] == C.tgt[j]) {
+#pragma unroll
+                                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                        for (int k = 0; k < VEC; ++k) C.y[j][c][k] = C.y[jp][c][k];
+                                }
+                            float part = 0.f;
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) part = fmaf(xc[c][k], C.y[j][c][k], part);
+                            float g = sgns_grad(wave_sum(part), 0.0f, alpha);
+                            g = skip ? 0.f : g;
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) { neu[c][k] = fmaf(g, C.y[j][c][k], neu[c][k]); C.y[j][c][k] = fmaf(g, xc[c][k], C.y[j][c][k]); }
+                            g_st(skip ? dummy : A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) xc[c][k] += neu[c][k];
+                    if (ALLC || chit) lds_st(lrow, xc);
+                    else if constexpr (RELOAD) {                     // uncached context row (beyond the radius, or a hot row): its neu1e by atomic add
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k)
+                                if ((c * WAVE + lane) * VEC + k < dg)
+                                    __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pc + (c * WAVE + lane) * VEC + k), neu[c][k]);
+                    } else g_st(pc, xc);
+                    PROF_LAP(4);                                     // arithmetic + stores
+                };
+                if constexpr (PF == 2) {
+                    while (true) {
+                        if (!m_proc) break;
+                        step(q0, q2);
+                        if (!m_proc) break;
+                        step(q1, q0);
+                        if (!m_proc) break;
+                        step(q2, q1);
+                    }
+                } else {
+                    while (true) {
+                        if (!m_proc) break;
+                        step(q0, q1);
+                        if (!m_proc) break;
+                        step(q1, q0);
+                    }
+                }
+                // (the prefetch slots filled past the last pair are dead: nothing consumes them, nothing waits for them -- round 2 "retired" them here,
+                // which was a full drain including the last pair's stores)
+                PROF_LAP(0);
+            } else if (sE >= 0) {
+                lds_st(rowsL + (size_t)sE * RW, rowE);
+                if constexpr (DELTA) o_st(sE, rowE);
+            }
+
+            // End of the centre.  vmcnt counts loads and stores in order and the compiler cannot count across the pair loop, so every use of an
+            // older load here is a full drain (s_waitcnt vmcnt(0)) that also waits for the acknowledgement of whatever was stored last.  Hence:
+            // first everything that CONSUMES loads (the negative targets of the next centre, the leaving row as it is now) -- one drain, of
+            // the last pair's stores -- and only then the centre's own stores, after which nothing waits until the next centre's first pair
+            // (round 2 stored the centre row, then consumed, then stored the leaving row: three exposed round trips per centre).
+            if (!fin_done) spec_next = stage_fin(pos + 1);          // (a centre without pairs; otherwise done inside its first pair step)
+            if (sX >= 0) {
+                float l[NV][VEC];
+                lds_ld(rowsL + (size_t)sX * RW, l);
+                if constexpr (DELTA) {
+                    o_ld(sX, rowO);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) l[c][k] = RELOAD ? l[c][k] - rowO[c][k] : rowG[c][k] + (l[c][k] - rowO[c][k]);
+                }
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    tail_p1[c] = A.SynPos + (int64_t)vX * d + (c * WAVE + lane) * VEC;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) tail_d1[c][k] = l[c][k];
+                }
+            }
+            if (word >= 0) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    tail_p0[c] = pp + (c * WAVE + lane) * VEC;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) tail_d0[c][k] = RELOAD ? yp[c][k] - yp0[c][k] : yp[c][k];
+                }
+            }
+            // ---- stores only from here on
+            if (word >= 0) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    if ((c * WAVE + lane) * VEC < dg) {
+                        if constexpr (RELOAD) {      // what this centre changed, added to the row as it is now (global_atomic_add_f32: nothing another wavefront stored is lost)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(tail_p0[c] + k), tail_d0[c][k]);
+                        } else st_lane<VEC>(tail_p0[c], tail_d0[c]);
+                    }
+                }
+            }
+            if (sX >= 0) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+                    if ((c * WAVE + lane) * VEC < dg) {
+                        if constexpr (RELOAD) {      // the leaving window row: what this wavefront changed, added to the row as it is now
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(tail_p1[c] + k), tail_d1[c][k]);
+                        } else st_lane<VEC>(tail_p1[c], tail_d1[c]);
+                    }
+                if (lane == sX) slot_node = -1;
+            }
+            PROF_LAP(7);                                             // end of the centre: consume, then the centre's stores
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the last R tokens are still in the window
+        for (int q = (len - R > 0 ? len - R : 0); q < len; ++q) {
+            const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
+            if (v < 0) continue;
+            const unsigned long long hq = __builtin_amdgcn_ballot_w64(slot_node == v);
+            if (!hq) continue;                                   // a hot row: never cached
+            const int s = (int)__builtin_ctzll(hq);
+            const int refc = __builtin_amdgcn_readlane(slot_ref, s) - 1;
+            if (lane == s) slot_ref = refc;
+            if (refc != 0) continue;
+            float l[NV][VEC];
+            lds_ld(rowsL + (size_t)s * RW, l);
+            if constexpr (DELTA) {
+                float o[NV][VEC], g[NV][VEC];
+                o_ld(s, o);
+                g_ld(A.SynPos + (int64_t)v * d, g);
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) l[c][k] = g[c][k] + (l[c][k] - o[c][k]);
+            }
+            g_st(A.SynPos + (int64_t)v * d, l);
+            if (lane == s) slot_node = -1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && A.pairs) atomicAdd(A.pairs, npairs);
+#ifdef GEMHIP_SGNS_PROFILE
+    PROF_LAP(0);
+    if (lane == 0 && A.prof) for (int k = 0; k < 8; ++k) atomicAdd(A.prof + k, prof_acc[k]);
+#endif
+}
+
+template <int VEC, int NV>
+void launch_sgns(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL((sgns_kernel<VEC, NV>), dim3(blocks), dim3(threads), lds, s, A);
+}
+template <int VEC, int NV, bool DELTA>
+void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
+{
+    const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window && A.hot_thr == 0;
+#define GEMHIP_LAUNCH_WIN(F, C, P, R) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, F, C, P, R>), dim3(blocks), dim3(threads), lds, s, A)
+    // instantiations: the A/B knobs (prefetch distance 1, Hogwild WITHOUT reload-on-update) exist for the benchmark shape only (d = 128: VEC 2, NV 1, whole
+    // window cached); every other Hogwild launch is reload-on-update with prefetch distance 2
+    constexpr bool AB = VEC == 2 && NV == 1;
+    const bool reload = DELTA && (A.reload || !(AB && full && allc));
+    if constexpr (DELTA) {
+        if (reload) {
+            if constexpr (AB) { if (full && allc && A.prefetch == 1) { GEMHIP_LAUNCH_WIN(true, true, 1, true); return; } }
+            if (full && allc) GEMHIP_LAUNCH_WIN(true, true, 2, true);
+            else if (full) GEMHIP_LAUNCH_WIN(true, false, 2, true);
+            else if (allc) GEMHIP_LAUNCH_WIN(false, true, 2, true);
+            else GEMHIP_LAUNCH_WIN(false, false, 2, true);
+            return;
+        }
+        if constexpr (AB) {      // (only reached with full && allc)
+            if (A.prefetch == 1) GEMHIP_LAUNCH_WIN(true, true, 1, false); else GEMHIP_LAUNCH_WIN(true, true, 2, false);
+        }
+        return;
+    } else {
+        if constexpr (AB) { if (full && allc && A.prefetch == 1) { GEMHIP_LAUNCH_WIN(true, true, 1, false); return; } }
+        if (full && allc) GEMHIP_LAUNCH_WIN(true, true, 2, false);
+        else if (full) GEMHIP_LAUNCH_WIN(true, false, 2, false);
+        else if (allc) GEMHIP_LAUNCH_WIN(false, true, 2, false);
+        else GEMHIP_LAUNCH_WIN(false, false, 2, false);
+    }
+#undef GEMHIP_LAUNCH_WIN
+}
+}  // namespace

@@ -3,8 +3,8 @@
 gem/c_exe/node2vec with `-i -o -d -l -r -k -e -p -q -v -dr -w`.
 
 Here the same three phases (transition tables, biased walks, skip-gram with negative
-sampling) run in libgem_hip.so: gem_amd/csrc/n2v.hip (n2v_alias_rows_kernel, n2v_walk_kernel, n2v_vocab_kernel,
-sgns_win_kernel) through gemhip_n2v_train (include/gem_hip.h).
+sampling) run in libgem_hip.so: gem_amd/csrc/n2v.hip (n2v_alias_rows_kernel, n2v_walk_kernel, n2v_vocab_kernel) and
+gem_amd/csrc/sgns.hpp (sgns_win_kernel) through gemhip_n2v_train (include/gem_hip.h).
 """
 import numpy as np
 

@@ -43,6 +43,7 @@ typedef struct {
     int64_t n; int32_t d; int64_t nwalks; int32_t walk_len; const int32_t *walks; int32_t window; float alpha0;
     int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch; const float *UT; const int32_t *KT; uint64_t seed; int32_t flags;
     float *SynPos, *SynNeg; int W, L, R, ctr_mode, ctx_mode, neg_mode;
+    const int32_t *counts; int32_t hot_thr;      /* nodes with counts[v] >= hot_thr > 0: never cached as contexts, negative updates applied at store time */
     int64_t stat_pairs, stat_neg_lost, stat_ctr_lost;
 } Cfg;
 
@@ -98,9 +99,10 @@ static Slot *slot_find(Wave *w, int32_t node)
     for (int i = 0; i < w->nslots; ++i) if (w->slots[i].node == node) return &w->slots[i];
     return NULL;
 }
+static int is_hot(const Cfg *c, int32_t node) { return c->hot_thr > 0 && node >= 0 && c->counts[node] >= c->hot_thr; }
 static void slot_enter(Cfg *c, Wave *w, int32_t node)
 {
-    if (node < 0) return;
+    if (node < 0 || is_hot(c, node)) return;
     Slot *s = slot_find(w, node);
     if (s) { ++s->ref; return; }
     for (int i = 0; i < w->nslots; ++i) if (w->slots[i].node < 0) { s = &w->slots[i]; break; }
@@ -110,7 +112,7 @@ static void slot_enter(Cfg *c, Wave *w, int32_t node)
 }
 static void slot_leave(Cfg *c, Wave *w, int32_t node)
 {
-    if (node < 0) return;
+    if (node < 0 || is_hot(c, node)) return;
     Slot *s = slot_find(w, node);
     if (--s->ref == 0) slot_writeback(c, s);
 }
@@ -149,10 +151,11 @@ static float grad(float f, float label, float alpha)
 void hogwild_emul_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, int32_t window, float alpha0,
                         int32_t epochs, int32_t epoch, int64_t tokens_total, int64_t token_offset, int64_t walk_id_offset,
                         const float *UT, const int32_t *KT, uint64_t seed, int32_t flags, float *SynPos, float *SynNeg,
-                        int32_t W, int32_t L, int32_t R, int32_t ctr_mode, int32_t ctx_mode, int32_t neg_mode, int64_t *stats)
+                        int32_t W, int32_t L, int32_t R, int32_t ctr_mode, int32_t ctx_mode, int32_t neg_mode, int64_t *stats,
+                        const int32_t *counts, int32_t hot_thr)
 {
     Cfg c = {n, d, nwalks, walk_len, walks, window, alpha0, (int64_t)epochs * tokens_total + 1, token_offset, walk_id_offset, epoch, UT, KT,
-             seed, flags, SynPos, SynNeg, W, L, R, ctr_mode, ctx_mode, neg_mode, 0, 0, 0};
+             seed, flags, SynPos, SynNeg, W, L, R, ctr_mode, ctx_mode, neg_mode, counts, counts ? hot_thr : 0, 0, 0, 0};
     if (L > MAXL) L = c.L = MAXL;
     Wave *wv = (Wave *)calloc((size_t)W, sizeof(Wave));
     int64_t *cur_wl = (int64_t *)malloc(sizeof(int64_t) * (size_t)W);
@@ -203,8 +206,8 @@ void hogwild_emul_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, 
             if (ctx_mode == 0) xc = SynPos + (size_t)p->ctx * d;
             else {
                 if (p->first) window_move(&c, w, p->wl, p->pos, &cur_wl[g]);
-                Slot *s = slot_find(w, p->ctx);
-                xc = s->work;        /* R >= window: every context is cached */
+                Slot *s = is_hot(&c, p->ctx) ? NULL : slot_find(w, p->ctx);
+                xc = s ? s->work : SynPos + (size_t)p->ctx * d;        /* a hot row: fetched for the pair, updated in place (atomic add of neu1e) */
             }
             for (int k = 0; k < d; ++k) neu[k] = 0.0f;
             {   /* positive target */
@@ -238,8 +241,8 @@ void hogwild_emul_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, 
                     for (int k = 0; k < d; ++k) f += xc[k] * y[k];
                     const float gg = grad(f, 0.0f, p->alpha);
                     for (int k = 0; k < d; ++k) neu[k] += gg * y[k];
-                    if (neg_mode == 1) for (int k = 0; k < d; ++k) gy[k] = y[k] + gg * xc[k];
-                    else               for (int k = 0; k < d; ++k) gy[k] = gy[k] + gg * xc[k];
+                    if (neg_mode == 1 && !is_hot(&c, tg)) for (int k = 0; k < d; ++k) gy[k] = y[k] + gg * xc[k];
+                    else                                  for (int k = 0; k < d; ++k) gy[k] = gy[k] + gg * xc[k];     /* delta at store time / hot row: atomic add */
                 }
             }
             for (int k = 0; k < d; ++k) xc[k] += neu[k];

@@ -5,7 +5,8 @@
     python scripts/hogwild_emul/run.py --nodes 16384 --edges 163840 --blocks 16 --walks 4 --cfg seq W64:L2:ctr1:ctx2:neg1 ...
 
 A configuration is `seq` (oracle_sgns_train) or W<waves>:L<prefetch distance>:ctr<m>:ctx<m>:neg<m>[:R<radius>] with the modes of
-hogwild_emul.c (0 direct, 1 private copy + overwrite, 2 private copy + delta).  The kernel as shipped in round 2 is
+hogwild_emul.c (0 direct, 1 private copy + overwrite, 2 private copy + delta); `:hot1` keeps the nodes expected in another
+wavefront's window (count >= tokens / ((W-1)(2R+1)); hotK: K times that many copies) out of the window caches and applies their negative updates at store time.  The kernel as shipped in round 2 is
 ctr1:ctx2:neg1:L2.  Prints one JSON line per configuration: MAP over a fixed node sample (paired across configurations: same
 walks, same draws), the fraction of negative-row / centre-row stores that overwrote a foreign update.
 """
@@ -28,7 +29,7 @@ def emul_lib():
     L.hogwild_emul_train.restype = None
     L.hogwild_emul_train.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int32, i32p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int64,
                                      C.c_int64, C.c_int64, f32p, i32p, C.c_uint64, C.c_int32, f32p, f32p, C.c_int32, C.c_int32, C.c_int32,
-                                     C.c_int32, C.c_int32, C.c_int32, i64p]
+                                     C.c_int32, C.c_int32, C.c_int32, i64p, i32p, C.c_int32]
     return L
 
 
@@ -39,9 +40,9 @@ def p(a, t):
 def parse_cfg(s, window):
     if s == 'seq':
         return None
-    o = dict(W=1, L=2, ctr=1, ctx=2, neg=1, R=window)
+    o = dict(W=1, L=2, ctr=1, ctx=2, neg=1, R=window, hot=0)
     for part in s.split(':'):
-        for k in ('ctr', 'ctx', 'neg', 'W', 'L', 'R'):
+        for k in ('ctr', 'ctx', 'neg', 'hot', 'W', 'L', 'R'):
             if part.startswith(k) and part[len(k):].isdigit():
                 o[k] = int(part[len(k):]); break
         else:
@@ -98,7 +99,8 @@ def main():
     row_ptr, col, ww = oracle.sorted_csr(n, src, dst, w)
     flags = 11
     walks = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, a.walks, a.walk_len, a.seed, flags)
-    UT, KT = oracle.unigram_build(oracle.n2v_vocab(n, walks))
+    counts = np.ascontiguousarray(oracle.n2v_vocab(n, walks), dtype=np.int32)
+    UT, KT = oracle.unigram_build(counts)
     UT = np.ascontiguousarray(UT, dtype=np.float32); KT = np.ascontiguousarray(KT, dtype=np.int32)
     walks = np.ascontiguousarray(walks, dtype=np.int32)
     nodes = np.random.RandomState(0).choice(n, size=min(a.sample, n), replace=False)
@@ -114,7 +116,8 @@ def main():
         else:
             L.hogwild_emul_train(n, a.d, walks.shape[0], walks.shape[1], p(walks, C.c_int32), a.window, 0.025, 1, 0, walks.size, 0, 0,
                                  p(UT, C.c_float), p(KT, C.c_int32), a.seed, flags, p(P, C.c_float), p(N, C.c_float),
-                                 cfg['W'], cfg['L'], cfg['R'], cfg['ctr'], cfg['ctx'], cfg['neg'], st)
+                                 cfg['W'], cfg['L'], cfg['R'], cfg['ctr'], cfg['ctx'], cfg['neg'], st, p(counts, C.c_int32),
+                                 0 if not cfg['hot'] else max(2, int(np.ceil(walks.size / ((cfg['W'] - 1) * (2 * cfg['R'] + 1) * cfg['hot'])))))
         el = time.time() - t
         aps = sampled_aps(g, P, nodes)
         if base is None:
