@@ -93,6 +93,7 @@ _SIGS = {
     'gemhip_sgns_set_window_cache': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_sgns_set_hogwild': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_sgns_set_hot_rows': (C.c_int, [C.c_void_p, C.c_int32]),
+    'gemhip_sgns_plan_launch': (C.c_int, [i32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, i32p, i32p, i32p, f64p, f64p]),
     'gemhip_test_wave_sum6': (C.c_int, [f32p, f32p]),
     'gemhip_sgns_set_tables': (C.c_int, [C.c_void_p, f32p, f32p]),
     'gemhip_sgns_get_tables': (C.c_int, [C.c_void_p, f32p, f32p]),

@@ -43,6 +43,64 @@ __host__ __device__ __forceinline__ uint32_t perm_node(uint32_t j, uint32_t n, u
 }
 }  // namespace
 
+// How concentrated the row traffic of TrainModel is: what the Hogwild launch rule (plan_sgns_launch) needs to know about the vocabulary.
+struct VocabStats {
+    double n = 0.0, total = 0.0, max = 0.0, active = 0.0;     // table rows, tokens, largest count, nodes that occur at all
+    double z = 0.0;                    // sum of count^0.75
+    double n_eff = 0.0;                // 1 / sum_v q_v^2, q = unigram^0.75 distribution: the table size a uniform graph with the same collision rate would have
+    std::vector<int32_t> cnt_desc;     // token counts, descending, and ...
+    std::vector<double> u2_prefix;     // ... u2_prefix[i] = sum of (count^0.75)^2 over the i largest counts
+    void build(const int32_t *cnt, int64_t len)
+    {
+        double tot = 0.0, mx = 0.0, zz = 0.0, z2 = 0.0;
+        n = (double)len; active = 0.0;
+        for (int64_t i = 0; i < len; ++i) {
+            const int32_t c = cnt[i];
+            if (c <= 0) continue;
+            tot += c; mx = std::max(mx, (double)c); active += 1.0;
+            const double u = std::pow((double)c, 0.75);
+            zz += u; z2 += u * u;
+        }
+        total = tot; max = mx; z = zz;
+        n_eff = z2 > 0.0 ? zz * zz / z2 : n;
+        cnt_desc.assign(cnt, cnt + len);
+        std::sort(cnt_desc.begin(), cnt_desc.end(), std::greater<int32_t>());
+        u2_prefix.assign((size_t)len + 1, 0.0);
+        for (size_t i = 0; i < cnt_desc.size(); ++i) {
+            const double u = cnt_desc[i] > 0 ? std::pow((double)cnt_desc[i], 0.75) : 0.0;
+            u2_prefix[i + 1] = u2_prefix[i] + u * u;
+        }
+    }
+    // effective table size of the negative-sampling distribution over the rows that are NOT hot (count < thr): hot rows take atomic adds and lose nothing
+    double n_eff_cold(double thr) const
+    {
+        if (cnt_desc.empty() || z <= 0.0) return n;
+        const size_t nhot = (size_t)(std::lower_bound(cnt_desc.begin(), cnt_desc.end(), thr, [](int32_t c, double t) { return (double)c >= t; }) - cnt_desc.begin());
+        const double s2 = (u2_prefix.back() - u2_prefix[nhot]) / (z * z);
+        return s2 > 0.0 ? 1.0 / s2 : 1e300;
+    }
+};
+
+// The knobs of a handle that steer the SGNS launch (gemhip_n2v_set_max_waves, gemhip_sgns_set_window_cache / _hogwild / _hot_rows) ...
+struct SgnsKnobs {
+    int32_t max_waves = 0;            // 0 = auto (plan_sgns_launch)
+    int32_t cache_radius = -1;        // sgns_win_kernel LDS window radius: -1 auto, 0 = off (sgns_kernel)
+    int32_t cache_delta = -1;         // -1 auto, 0 overwrite on leave, 1 delta write-back
+    int32_t prefetch = 2;             // pairs whose negative rows are requested ahead: 2 (default) or 1 (d == 64/128/256.., whole window cached)
+    int32_t reload = 1;               // Hogwild launches: update negative rows as they are at store time (second fetch) and the centre row by atomic add
+    int32_t hot_count = -1;           // nodes with at least this many tokens never enter the LDS window: -1 auto (tokens / ((W-1) x (2R+1))), 0 off
+};
+// ... and what a launch of TrainModel over `nwalks` walks then looks like (pure host arithmetic: gemhip_sgns_plan_launch exposes it to the CPU tests)
+struct SgnsLaunchPlan {
+    bool window = false;              // sgns_win_kernel (LDS window) or sgns_kernel
+    bool delta = false;               // window kernel: delta write-back (the Hogwild instantiation)
+    int R = 0;                        // window radius
+    int64_t waves = 1;                // concurrent wavefronts = concurrent walks
+    int32_t hot_thr = 0;              // token count from which a row is "hot" (0: none)
+    size_t lds = 0;                   // dynamic LDS bytes per workgroup
+    int blocks = 1, threads = 64;
+};
+
 struct gemhip_n2v {
     int64_t n = 0, nnz = 0;
     int device = 0;
@@ -72,18 +130,8 @@ struct gemhip_n2v {
     int32_t d = 0;
     float *SynPos = nullptr, *SynNeg = nullptr;
     bool own_syn = false;
-    int32_t max_waves = 0;            // 0 = auto (see gemhip_sgns_train)
-    int32_t cache_radius = -1;        // sgns_win_kernel LDS window radius: -1 auto, 0 = off (sgns_kernel)
-    int32_t cache_delta = -1;         // -1 auto, 0 overwrite on leave, 1 delta write-back
-    int32_t prefetch = 2;             // pairs whose negative rows are requested ahead: 2 (default) or 1 (d == 64/128/256.., whole window cached)
-    int32_t reload = 1;               // Hogwild launches: update negative rows as they are at store time (second fetch) and the centre row by atomic add
-    int32_t hot_count = -1;           // nodes with at least this many tokens never enter the LDS window: -1 auto (tokens / ((W-1) x (2R+1))), 0 off
-    // vocabulary statistics (gemhip_n2v_build_unigram*): how concentrated the row traffic is
-    double vocab_total = 0.0, vocab_max = 0.0, vocab_active = 0.0;     // tokens, largest count, nodes that occur at all
-    double n_eff_neg = 0.0;           // 1 / sum_v q_v^2, q = unigram^0.75 distribution: the table size a uniform graph with the same collision rate would have
-    std::vector<int32_t> cnt_desc;    // token counts, descending, and ...
-    std::vector<double> u2_prefix;    // ... u2_prefix[i] = sum of (count^0.75)^2 over the i largest counts; vocab_z = sum of count^0.75
-    double vocab_z = 0.0;
+    SgnsKnobs kn;                     // launch knobs (setters below; environment overrides read once in gemhip_n2v_create)
+    VocabStats vs;                    // vocabulary statistics (gemhip_n2v_build_unigram*): how concentrated the row traffic is -> plan_sgns_launch
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
     unsigned long long *d_bcnt = nullptr;               // emit_pairs_bucketed: bucket sizes [64*64] + cursors [64*64]
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
@@ -647,12 +695,12 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     auto *h = new gemhip_n2v();
     h->n = n; h->nnz = nnz; h->uniform_rows = uniform; h->m_start = (int64_t)start.size();
     // A/B knobs: read ONCE, here (the launch path reads no environment); the setters below override them per handle
-    if (const char *e = getenv("GEMHIP_SGNS_MAX_WAVES")) h->max_waves = std::max(0, atoi(e));
-    if (const char *e = getenv("GEMHIP_SGNS_CACHE_R")) h->cache_radius = std::min(31, std::max(-1, atoi(e)));
-    if (const char *e = getenv("GEMHIP_SGNS_CACHE_DELTA")) h->cache_delta = std::min(1, std::max(-1, atoi(e)));
-    if (const char *e = getenv("GEMHIP_SGNS_PREFETCH")) h->prefetch = std::min(2, std::max(1, atoi(e)));
-    if (const char *e = getenv("GEMHIP_SGNS_RELOAD")) h->reload = atoi(e) != 0;
-    if (const char *e = getenv("GEMHIP_SGNS_HOT_COUNT")) h->hot_count = std::max(-1, atoi(e));
+    if (const char *e = getenv("GEMHIP_SGNS_MAX_WAVES")) h->kn.max_waves = std::max(0, atoi(e));
+    if (const char *e = getenv("GEMHIP_SGNS_CACHE_R")) h->kn.cache_radius = std::min(31, std::max(-1, atoi(e)));
+    if (const char *e = getenv("GEMHIP_SGNS_CACHE_DELTA")) h->kn.cache_delta = std::min(1, std::max(-1, atoi(e)));
+    if (const char *e = getenv("GEMHIP_SGNS_PREFETCH")) h->kn.prefetch = std::min(2, std::max(1, atoi(e)));
+    if (const char *e = getenv("GEMHIP_SGNS_RELOAD")) h->kn.reload = atoi(e) != 0;
+    if (const char *e = getenv("GEMHIP_SGNS_HOT_COUNT")) h->kn.hot_count = std::max(-1, atoi(e));
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
     hipError_t e = hipMalloc((void **)&h->d_row_ptr, (n + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMemcpy(h->d_row_ptr, row_ptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
@@ -858,35 +906,6 @@ static bool vose_unigram(const int32_t *cnt, int64_t n, int64_t stride, std::vec
     return true;
 }
 
-static void vocab_stats(gemhip_n2v_t h, const std::vector<int32_t> &cnt)
-{
-    double tot = 0.0, mx = 0.0, z = 0.0, z2 = 0.0;
-    h->vocab_active = 0.0;
-    for (int32_t c : cnt) {
-        if (c <= 0) continue;
-        tot += c; mx = std::max(mx, (double)c); h->vocab_active += 1.0;
-        const double u = std::pow((double)c, 0.75);
-        z += u; z2 += u * u;
-    }
-    h->vocab_total = tot; h->vocab_max = mx; h->vocab_z = z;
-    h->n_eff_neg = z2 > 0.0 ? z * z / z2 : (double)h->n;
-    h->cnt_desc.assign(cnt.begin(), cnt.end());
-    std::sort(h->cnt_desc.begin(), h->cnt_desc.end(), std::greater<int32_t>());
-    h->u2_prefix.assign(cnt.size() + 1, 0.0);
-    for (size_t i = 0; i < h->cnt_desc.size(); ++i) {
-        const double u = h->cnt_desc[i] > 0 ? std::pow((double)h->cnt_desc[i], 0.75) : 0.0;
-        h->u2_prefix[i + 1] = h->u2_prefix[i] + u * u;
-    }
-}
-// effective table size of the negative-sampling distribution over the rows that are NOT hot (count < thr): hot rows take atomic adds and lose nothing
-static double n_eff_cold(const gemhip_n2v *h, double thr)
-{
-    if (h->cnt_desc.empty() || h->vocab_z <= 0.0) return (double)h->n;
-    const size_t nhot = (size_t)(std::lower_bound(h->cnt_desc.begin(), h->cnt_desc.end(), thr, [](int32_t c, double t) { return (double)c >= t; }) - h->cnt_desc.begin());
-    const double s2 = (h->u2_prefix.back() - h->u2_prefix[nhot]) / (h->vocab_z * h->vocab_z);
-    return s2 > 0.0 ? 1.0 / s2 : 1e300;
-}
-
 extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, float *UT_out, int32_t *KT_out)
 {
     GEMHIP_REQUIRE(h, "n2v_build_unigram: NULL handle");
@@ -896,7 +915,7 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
     std::vector<float> Uf;
     GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     GEMHIP_REQUIRE(vose_unigram(cnt.data(), n, 1, Uf, K), "n2v_build_unigram: empty vocabulary (no walks?)");
-    vocab_stats(h, cnt);
+    h->vs.build(cnt.data(), (int64_t)cnt.size());
     if (!h->d_UT) GEMHIP_CHECK(hipMalloc((void **)&h->d_UT, n * sizeof(float)));
     if (!h->d_KT) GEMHIP_CHECK(hipMalloc((void **)&h->d_KT, n * sizeof(int32_t)));
     GEMHIP_CHECK(hipMemcpy(h->d_UT, Uf.data(), n * sizeof(float), hipMemcpyHostToDevice));
@@ -922,7 +941,7 @@ extern "C" int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, flo
     const int64_t n = h->n;
     std::vector<int32_t> cnt(n);
     GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    vocab_stats(h, cnt);
+    h->vs.build(cnt.data(), (int64_t)cnt.size());
     std::vector<float> Uall(n);
     std::vector<int32_t> Kall(n);
     h->part_off.assign(parts + 1, 0);
@@ -1014,7 +1033,7 @@ extern "C" int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int6
         // of stores that overwrite another wavefront's, rho = W x 5 x w / n_partition with w ~ 0.4 pair steps (negative rows are fetched again
         // right before their update, context and centre rows take atomic adds: sgns_pairs_kernel<SAFE>), stays <= 1.5 %  ->  n_partition / 133
         // (round 2 ran n_partition / 32 wavefronts on plain read-modify-write rows: rho ~ 20 %)
-        int64_t cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, A.n_local_neg / 133);
+        int64_t cap = h->kn.max_waves > 0 ? h->kn.max_waves : std::max<int64_t>(1, A.n_local_neg / 133);
         cap = std::min<int64_t>(cap, 256 * 16);
         const int64_t waves = std::min<int64_t>(cap, npairs);
         threads = 256; blocks = (int)((waves + 3) / 4); A.nwaves = (int32_t)waves;
@@ -1048,7 +1067,7 @@ extern "C" int gemhip_sgns_init(gemhip_n2v_t h, int32_t d, uint64_t seed, void *
 extern "C" int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves)
 {
     GEMHIP_REQUIRE(h && max_waves >= 0, "n2v_set_max_waves: bad arguments");
-    h->max_waves = max_waves;
+    h->kn.max_waves = max_waves;
     return GEMHIP_OK;
 }
 
@@ -1071,6 +1090,84 @@ extern "C" int gemhip_sgns_get_tables(gemhip_n2v_t h, float *SynPos_host, float 
     return GEMHIP_OK;
 }
 
+// Which kernel, how many concurrent wavefronts and which rows are "hot" for one pass of TrainModel over `nwalks` walks.  Pure host arithmetic.
+//
+// Concurrency against quality -- the rule and where it comes from.  What Hogwild costs here is LOST UPDATES: every wavefront
+// keeps its 5 negative rows per pair open from their load to their store; a store another wavefront makes to such a row in between is
+// overwritten.  The CPU replay of this kernel's concurrency (scripts/hogwild_emul: W virtual wavefronts, the kernel's private copies) puts
+// ~90 % of the MAP loss on those overwritten negative-row updates, ~10 % on the centre row's, none on stale gradients; the expected fraction
+// of overwriting stores is  rho = W x 5 x w / n_eff  with w = the window in pair steps (prefetch + 1 without RELOAD; ~0.4 with it: one reload
+// round trip, ~0.5 us against a 1.35 us step) and n_eff = 1 / sum_v q_v^2 the EFFECTIVE table size of the negative-sampling distribution
+// (unigram^0.75): n on a graph whose nodes are equally frequent (SBM: n / 1.06), far smaller on a power-law graph (R-MAT scale 17: 11 316 of
+// 131 072 nodes).  Measured at SBM 1M/10M against the sequential oracle (same seed, paired per-node AP): without RELOAD rho = 1.1 % / 1.5 % /
+// 2.3 % (768 / 1024 / 1536 wavefronts) cost -0.1 % / -0.4..-0.9 % / -0.8..-1.3 % of MAP, and 1536 wavefronts with prefetch 1 (rho 1.5 %)
+// -0.5 %: the loss follows rho, not the wavefront count; with RELOAD 1536 wavefronts (rho 0.3 %) measure +0.15 +- 0.25 %.  Default: rho <= 1.5 %.
+static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn, int64_t n, int32_t d, int32_t window, int32_t walk_len,
+                                       int64_t nwalks, int32_t flags)
+{
+    SgnsLaunchPlan P;
+    const bool deterministic = (flags & 4) != 0;
+    // window-cached kernel (default): radius R = tokens either side of the centre whose SynPos row stays in LDS
+    int R = kn.cache_radius < 0 ? 10 : kn.cache_radius;
+    R = std::min(R, std::min(window, 31));
+    const int rw = sgns_win_row_floats(d);
+    const size_t ints = (size_t)((walk_len + 4 * window * SGNS_NEG + 3) & ~3);
+    auto lds_bytes = [&](bool delta) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * (delta ? 2 : 1) + 1) * rw * sizeof(float); };
+    // the window (2R+1 rows, twice with the delta write-back) has to fit a block's LDS: wide rows / long walks fall back to sgns_kernel
+    P.window = R > 0 && !(flags & GEMHIP_N2V_NO_WINDOW_CACHE) && 2 * window * SGNS_NEG <= 2 * WAVE && walk_len >= 2 && lds_bytes(true) <= 64 * 1024 &&
+               (d % 2 == 0 ? d <= 512 : d <= 256);
+    if (!P.window) {
+        // sgns_kernel: four wavefronts per workgroup, no private copies beyond the pair in flight.  Small graphs: when the open rows approach n,
+        // concurrent writers overwrite each other's updates and the embedding degrades (tests/test_n2v_gpu.py): n / 128 wavefronts
+        const size_t per_wave = (size_t)(walk_len + 2 * window * SGNS_NEG) * sizeof(int32_t);
+        if (!deterministic) {
+            const int64_t hog_cap = kn.max_waves > 0 ? kn.max_waves : std::max<int64_t>(1, n / HOGWILD_ROWS_PER_WAVE);
+            P.waves = std::min<int64_t>(std::min<int64_t>(hog_cap, 256 * 16), nwalks);          // 16 waves/CU already saturate the fabric (scripts/ab_sgns_waves.py)
+            P.threads = 256; P.blocks = (int)((P.waves + 3) / 4);
+        }
+        P.lds = per_wave * (P.threads / 64);
+        return P;
+    }
+    P.R = R;
+    const int mode = kn.cache_delta;                 // -1 auto: delta write-back whenever other wavefronts train concurrently
+    P.delta = deterministic && mode == 1;            // (cache_delta 1 on a deterministic launch: the Hogwild code path on ONE wavefront, for the parity tests)
+    if (!deterministic) {
+        P.delta = mode != 0;
+        const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta) + 512)));   // 184 VGPRs: 2 per SIMD
+        const double w_steps = (P.delta && kn.reload) ? 0.4 : (double)(kn.prefetch + 1);
+        const double n_eff = vs.n_eff > 0.0 ? vs.n_eff : (double)n;
+        int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
+        // graphs below 8192 nodes: the window rows themselves (2R+1 per wavefront) are a sizeable part of the table -- SBM-1024 (d=16) loses
+        // 3.5 % of MAP at 8 wavefronts and nothing at 2: bound the open fraction of the table at 1/16
+        const int64_t hog_tiny = std::max<int64_t>(1, n / (16 * (8 + 2 * R + 1)));
+        const int64_t w_dev = std::min<int64_t>(256 * per_cu, nwalks);
+        // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
+        // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
+        // ... but never more wavefronts than 2 % of the rows that occur at all: that is as far as the measurements behind this rule reach (stale
+        // gradients cost nothing up to there -- CPU replay at 0.4 %, SBM 100k at 0.8 %, R-MAT scale 17 at 2.0 % of the active rows; R-MAT scale 13 with
+        // 26 % of its 5 936 active rows open ended 21 % ABOVE the sequential algorithm's MAP: its hubs under-trained)
+        const int64_t w_act = std::max<int64_t>(1, (int64_t)((vs.active > 0.0 ? vs.active : (double)n) / 50.0));
+        if (P.delta && kn.reload && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(w_dev, w_act) && vs.total > 0.0) {
+            for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
+                const double thr = std::max(2.0, std::ceil(vs.total / ((double)(wtry - 1) * (2 * R + 1))));
+                if (0.015 * vs.n_eff_cold(thr) / (5.0 * w_steps) >= (double)wtry) { hog_rho = wtry; break; }
+            }
+        }
+        const int64_t hog_win = kn.max_waves > 0 ? kn.max_waves : n >= 8192 ? hog_rho : std::min(hog_rho, hog_tiny);
+        P.waves = std::min<int64_t>(hog_win, w_dev);
+        if (P.waves == 1 && mode < 0) P.delta = false;
+    }
+    P.lds = lds_bytes(P.delta);
+    P.blocks = (int)P.waves; P.threads = 64;
+    // a node expected to sit in another wavefront's window at any time -- (W - 1) x (2R + 1) x count / tokens >= 1 -- is hot
+    if (kn.hot_count > 0) P.hot_thr = kn.hot_count;
+    else if (kn.hot_count < 0 && P.waves > 1 && vs.total > 0.0) {
+        const double thr = vs.total / ((double)(P.waves - 1) * (2 * R + 1));
+        if (vs.max >= thr) P.hot_thr = (int32_t)std::max(2.0, std::ceil(thr));
+    }
+    return P;
+}
+
 extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0, int32_t epochs, int32_t epoch,
                                  int64_t walk_lo, int64_t walk_hi, int64_t tokens_total, int64_t token_offset, uint64_t seed,
                                  int32_t flags, void *stream)
@@ -1090,77 +1187,14 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.token_offset = token_offset; A.walk_id_offset = h->walk_id_offset; A.epoch = epoch;
     A.UT = h->d_UT; A.KT = h->d_KT; A.UK = h->d_UK; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
-    A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->prefetch; A.reload = h->reload; A.counts = nullptr; A.hot_thr = 0;
-    const bool deterministic = (flags & 4) != 0;
-    // Hogwild concurrency on small graphs: every in-flight wavefront has rows open (read-modify-write); when the open rows approach n,
-    // concurrent writers overwrite each other's updates and the embedding degrades (tests/test_n2v_gpu.py).  sgns_kernel: n/128.
-    const int64_t hog_cap = h->max_waves > 0 ? h->max_waves : std::max<int64_t>(1, h->n / HOGWILD_ROWS_PER_WAVE);
-
-    // window-cached kernel (default): radius R = tokens either side of the centre whose SynPos row stays in LDS
-    int R = h->cache_radius < 0 ? 10 : h->cache_radius;
-    R = std::min(R, std::min(window, 31));
-    bool win_ok = R > 0 && !(flags & GEMHIP_N2V_NO_WINDOW_CACHE) && 2 * window * SGNS_NEG <= 2 * WAVE && h->walk_len >= 2;
-    if (win_ok) {      // the window (2R+1 rows, twice with the delta write-back) has to fit a block's LDS: wide rows / long walks fall back to sgns_kernel
-        const size_t rwb = (size_t)sgns_win_row_floats(h->d) * sizeof(float);
-        const size_t worst = (size_t)((h->walk_len + 4 * window * SGNS_NEG + 3) & ~3) * sizeof(int32_t) + (size_t)((2 * R + 1) * 2 + 1) * rwb;
-        win_ok = worst <= 64 * 1024 && (h->d % 2 == 0 ? h->d <= 512 : h->d <= 256);
-    }
-    if (win_ok) {
-        const int mode = h->cache_delta;                 // -1 auto: delta write-back whenever other wavefronts train concurrently
-        const int rw = sgns_win_row_floats(h->d);
-        const size_t ints = (size_t)((h->walk_len + 4 * window * SGNS_NEG + 3) & ~3);
-        auto lds_bytes = [&](bool delta) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * (delta ? 2 : 1) + 1) * rw * sizeof(float); };
-        int64_t waves = 1;
-        bool delta = deterministic && mode == 1;          // (cache_delta 1 on a deterministic launch: the Hogwild code path on ONE wavefront, for the parity tests)
-        if (!deterministic) {
-            delta = mode != 0;
-            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(delta) + 512)));   // 184 VGPRs: 2 per SIMD
-            // Concurrency against quality -- the rule and where it comes from.  What Hogwild costs here is LOST UPDATES: every
-            // wavefront keeps its 5 negative rows per pair open from their load to their store; a store another wavefront makes to such a row
-            // in between is overwritten.  The CPU replay of this kernel's concurrency (scripts/hogwild_emul: W virtual wavefronts, the kernel's
-            // private copies) puts ~90 % of the MAP loss on those overwritten negative-row updates, ~10 % on the centre row's, none on stale
-            // gradients; the expected fraction of overwriting stores is  rho = W x 5 x w / n  with w = the window in pair steps
-            // (prefetch + 1 without RELOAD; ~0.4 with it: one reload round trip, ~0.5 us against a 1.35 us step).  Measured at SBM 1M/10M against
-            // the sequential oracle (same seed, paired per-node AP): without RELOAD rho = 1.1 % / 1.5 % / 2.3 % (768 / 1024 / 1536 wavefronts)
-            // cost -0.1 % / -0.4..-0.9 % / -0.8..-1.3 % of MAP, and 1536 wavefronts with prefetch 1 (rho 1.5 %) -0.5 %: the loss follows rho, not
-            // the wavefront count; with RELOAD 1536 wavefronts (rho 0.3 %) measure +0.15 +- 0.25 %.  Default: rho <= 1.5 %.
-            const double w_steps = (delta && h->reload) ? 0.4 : (double)(h->prefetch + 1);
-            // n -> the EFFECTIVE table size 1 / sum_v q_v^2 of the negative-sampling distribution (unigram^0.75): equal to n on a graph whose
-            // nodes are equally frequent (SBM: n / 1.06), far smaller on a power-law graph (R-MAT scale 17: 11 316 of 131 072 nodes)
-            const double n_eff = h->n_eff_neg > 0.0 ? h->n_eff_neg : (double)h->n;
-            int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
-            // graphs below 8192 nodes: the window rows themselves (2R+1 per wavefront) are a sizeable part of the table -- SBM-1024 (d=16) loses
-            // 3.5 % of MAP at 8 wavefronts and nothing at 2: bound the open fraction of the table at 1/16
-            const int64_t hog_tiny = std::max<int64_t>(1, h->n / (16 * (8 + 2 * R + 1)));
-            const int64_t w_dev = std::min<int64_t>(256 * per_cu, walk_hi - walk_lo);
-            // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
-            // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
-            // ... but never more wavefronts than 2 % of the rows that occur at all: that is as far as the measurements behind this rule reach (stale
-            // gradients cost nothing up to there -- CPU replay at 0.4 %, SBM 100k at 0.8 %, R-MAT scale 17 at 2.0 % of the active rows; R-MAT scale 13 with
-            // 26 % of its 5 936 active rows open ended 21 % ABOVE the sequential algorithm's MAP: its hubs under-trained)
-            const int64_t w_act = std::max<int64_t>(1, (int64_t)((h->vocab_active > 0.0 ? h->vocab_active : (double)h->n) / 50.0));
-            if (delta && h->reload && h->hot_count < 0 && h->n >= 8192 && hog_rho < std::min(w_dev, w_act) && h->vocab_total > 0.0) {
-                for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
-                    const double thr = std::max(2.0, std::ceil(h->vocab_total / ((double)(wtry - 1) * (2 * R + 1))));
-                    if (0.015 * n_eff_cold(h, thr) / (5.0 * w_steps) >= (double)wtry) { hog_rho = wtry; break; }
-                }
-            }
-            const int64_t hog_win = h->max_waves > 0 ? h->max_waves : h->n >= 8192 ? hog_rho : std::min(hog_rho, hog_tiny);
-            waves = std::min<int64_t>(hog_win, w_dev);
-            if (waves == 1 && mode < 0) delta = false;
-        }
-        const size_t lds = lds_bytes(delta);
-        GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for the LDS window (%zu bytes)", lds);
-        A.nwaves = (int32_t)waves; A.cache_radius = R;
-        // hot rows (sgns_win_kernel): a node expected to sit in another wavefront's window at any time -- (W - 1) x (2R + 1) x count / tokens >= 1 -- is
-        // never cached; the launch then takes the instantiation that handles uncached contexts (R is reported to the launcher as "not all cached")
-        A.counts = h->d_counts; A.hot_thr = 0;
-        if (h->hot_count > 0) A.hot_thr = h->hot_count;
-        else if (h->hot_count < 0 && waves > 1 && h->vocab_total > 0.0) {
-            const double thr = h->vocab_total / ((double)(waves - 1) * (2 * R + 1));
-            if (h->vocab_max >= thr) A.hot_thr = (int32_t)std::max(2.0, std::ceil(thr));
-        }
-        const size_t need = (size_t)waves * rw * sizeof(float);
+    A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->kn.prefetch; A.reload = h->kn.reload; A.counts = nullptr; A.hot_thr = 0;
+    const SgnsLaunchPlan P = plan_sgns_launch(h->vs, h->kn, h->n, h->d, window, h->walk_len, walk_hi - walk_lo, flags);
+    GEMHIP_REQUIRE(P.lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for LDS staging (%zu bytes)", P.lds);
+    A.nwaves = (int32_t)P.waves; A.cache_radius = P.R;
+    if (P.window) {
+        // hot rows (sgns_win_kernel): never cached; the launch then takes the instantiation that handles uncached contexts
+        A.counts = h->d_counts; A.hot_thr = P.hot_thr;
+        const size_t need = (size_t)P.waves * sgns_win_row_floats(h->d) * sizeof(float);
         if (need > h->dummy_bytes) {
             if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
             GEMHIP_CHECK(hipMalloc(&h->d_dummy, need));
@@ -1168,46 +1202,42 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             h->dummy_bytes = need;
         }
         A.dummy = h->d_dummy;
-        A.prof = nullptr;
 #ifdef GEMHIP_SGNS_PROFILE
         static unsigned long long *d_prof = nullptr;
         if (!d_prof) GEMHIP_CHECK(hipMalloc(&d_prof, 64));
         GEMHIP_CHECK(hipMemset(d_prof, 0, 64));
         A.prof = d_prof;
 #endif
-        sgns_fn fn = delta ? pick_sgns_win_hogwild(h->d) : pick_sgns_win_det(h->d);
-        GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
-        fn(A, (int)waves, 64, lds, (hipStream_t)stream);
-        GEMHIP_CHECK(hipGetLastError());
-#ifdef GEMHIP_SGNS_PROFILE
-        {
-            unsigned long long hp[8];
-            GEMHIP_CHECK(hipDeviceSynchronize());
-            GEMHIP_CHECK(hipMemcpy(hp, A.prof, 64, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[sgns profile] waves=%lld cycles: other=%llu issue=%llu ctx_lds=%llu wait_rows=%llu compute_store=%llu neg_pipeline=%llu centre_setup=%llu centre_end=%llu\n",
-                    (long long)waves, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
-        }
-#endif
-        return GEMHIP_OK;
     }
-
-    const size_t per_wave = (size_t)(h->walk_len + 2 * window * SGNS_NEG) * sizeof(int32_t);
-    int blocks, threads;
-    A.cache_radius = 0; A.dummy = nullptr; A.prof = nullptr;
-    if (deterministic) { blocks = 1; threads = 64; A.nwaves = 1; }
-    else {
-        threads = 256;
-        const int64_t cap = std::min<int64_t>(hog_cap, 256 * 16);          // 16 waves/CU already saturate the fabric (scripts/ab_sgns_waves.py)
-        const int64_t waves = std::min<int64_t>(cap, walk_hi - walk_lo);
-        blocks = (int)((waves + 3) / 4);
-        A.nwaves = (int32_t)waves;
-    }
-    const size_t lds = per_wave * (threads / 64);
-    GEMHIP_REQUIRE(lds <= 64 * 1024, "sgns_train: walk_len/window too large for LDS staging (%zu bytes)", lds);
-    sgns_fn fn = pick_sgns(h->d);
+    sgns_fn fn = !P.window ? pick_sgns(h->d) : P.delta ? pick_sgns_win_hogwild(h->d) : pick_sgns_win_det(h->d);
     GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
-    fn(A, blocks, threads, lds, (hipStream_t)stream);
+    fn(A, P.blocks, P.threads, P.lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());
+#ifdef GEMHIP_SGNS_PROFILE
+    if (P.window) {
+        unsigned long long hp[8];
+        GEMHIP_CHECK(hipDeviceSynchronize());
+        GEMHIP_CHECK(hipMemcpy(hp, A.prof, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[sgns profile] waves=%lld cycles: other=%llu issue=%llu ctx_lds=%llu wait_rows=%llu compute_store=%llu neg_pipeline=%llu centre_setup=%llu centre_end=%llu\n",
+                (long long)P.waves, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
+    }
+#endif
+    return GEMHIP_OK;
+}
+
+// The launch plan for the given token counts, without a device: what gemhip_sgns_train would do on a handle with default knobs (tests/test_sgns_plan.py).
+extern "C" int gemhip_sgns_plan_launch(const int32_t *counts, int64_t n, int32_t d, int32_t window, int32_t walk_len, int64_t nwalks, int32_t flags,
+                                       int32_t *kernel, int32_t *waves, int32_t *hot_threshold, double *n_eff, double *n_eff_cold)
+{
+    GEMHIP_REQUIRE(counts && n >= 1 && d >= 1 && window >= 1 && walk_len >= 1 && nwalks >= 1, "sgns_plan_launch: bad arguments");
+    VocabStats vs;
+    vs.build(counts, n);
+    const SgnsLaunchPlan P = plan_sgns_launch(vs, SgnsKnobs(), n, d, window, walk_len, nwalks, flags);
+    if (kernel) *kernel = !P.window ? 0 : P.delta ? 2 : 1;          // 0 sgns_kernel, 1 sgns_win_kernel (overwrite on leave), 2 sgns_win_kernel (Hogwild: delta write-back)
+    if (waves) *waves = (int32_t)P.waves;
+    if (hot_threshold) *hot_threshold = P.hot_thr;
+    if (n_eff) *n_eff = vs.n_eff;
+    if (n_eff_cold) *n_eff_cold = P.hot_thr > 0 ? vs.n_eff_cold((double)P.hot_thr) : vs.n_eff;
     return GEMHIP_OK;
 }
 
@@ -1239,23 +1269,23 @@ extern "C" int gemhip_test_wave_sum6(const float *in_host, float *out_host)
 extern "C" int gemhip_sgns_set_hogwild(gemhip_n2v_t h, int32_t prefetch_pairs, int32_t reload_on_update)
 {
     GEMHIP_REQUIRE(h && prefetch_pairs >= 0 && prefetch_pairs <= 2 && reload_on_update >= -1 && reload_on_update <= 1, "sgns_set_hogwild: bad arguments");
-    if (prefetch_pairs) h->prefetch = prefetch_pairs;
-    if (reload_on_update >= 0) h->reload = reload_on_update;
+    if (prefetch_pairs) h->kn.prefetch = prefetch_pairs;
+    if (reload_on_update >= 0) h->kn.reload = reload_on_update;
     return GEMHIP_OK;
 }
 
 extern "C" int gemhip_sgns_set_hot_rows(gemhip_n2v_t h, int32_t min_count)
 {
     GEMHIP_REQUIRE(h && min_count >= -1, "sgns_set_hot_rows: bad arguments");
-    h->hot_count = min_count;
+    h->kn.hot_count = min_count;
     return GEMHIP_OK;
 }
 
 extern "C" int gemhip_sgns_set_window_cache(gemhip_n2v_t h, int32_t radius, int32_t delta_writeback)
 {
     GEMHIP_REQUIRE(h && radius >= -1 && radius <= 31 && delta_writeback >= -1 && delta_writeback <= 1, "sgns_set_window_cache: bad arguments");
-    h->cache_radius = radius;
-    h->cache_delta = delta_writeback;
+    h->kn.cache_radius = radius;
+    h->kn.cache_delta = delta_writeback;
     return GEMHIP_OK;
 }
 

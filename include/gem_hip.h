@@ -206,6 +206,14 @@ int gemhip_sgns_set_hogwild(gemhip_n2v_t h, int32_t prefetch_pairs, int32_t relo
  * copies leave with add up.  -1 = auto: the nodes expected to be in another wavefront's window at any time, tokens / ((W-1) x (2R+1));
  * 0 = off.  No reference counterpart. */
 int gemhip_sgns_set_hot_rows(gemhip_n2v_t h, int32_t min_count);
+/* The launch gemhip_sgns_train would choose for one pass over `nwalks` walks of a corpus with these token counts (counts[n], as
+ * gemhip_n2v_build_unigram returns them) on a handle with default knobs -- host arithmetic only, no device needed: which kernel (0 = no LDS
+ * window, 1 = window with overwrite on leave, 2 = window with delta write-back: the Hogwild path), how many concurrent wavefronts (= walks
+ * trained at once; the rule rho = W x 5 x w / n_eff <= 1.5 % of DESIGN.md 3.3), the hot-row token threshold (0: none), the effective table
+ * size n_eff = 1 / sum q_v^2 of the unigram^0.75 distribution and the same over the cold rows only.  Any out pointer may be NULL.  No
+ * reference counterpart (the binary runs as many threads as the machine has cores). */
+int gemhip_sgns_plan_launch(const int32_t *counts, int64_t n, int32_t d, int32_t window, int32_t walk_len, int64_t nwalks, int32_t flags,
+                            int32_t *kernel, int32_t *waves, int32_t *hot_threshold, double *n_eff, double *n_eff_cold);
 /* Building block of the SGNS kernel, exposed for its own parity test: in[64][6] per-lane partial sums -> out[64], lane l
  * receiving the wave total of value (l & 4) ? 4 + (l & 1) : (l & 3). */
 int gemhip_test_wave_sum6(const float *in_host, float *out_host);

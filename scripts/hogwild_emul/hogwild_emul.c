@@ -236,7 +236,7 @@ void hogwild_emul_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, 
                         for (int jp = 0; jp < NEG; ++jp) own |= e->tgt[jp] == tg;
                     }
                     if (own) { memcpy(y, gy, sizeof(float) * d); memcpy(yl, gy, sizeof(float) * d); }
-                    if (memcmp(yl, gy, sizeof(float) * d) != 0) ++c.stat_neg_lost;      /* someone else stored this row since we read it */
+                    if (memcmp(yl, gy, sizeof(float) * d) != 0 && !(neg_mode == 1 && is_hot(&c, tg))) ++c.stat_neg_lost;      /* someone else stored this row since we read it */
                     float f = 0.0f;
                     for (int k = 0; k < d; ++k) f += xc[k] * y[k];
                     const float gg = grad(f, 0.0f, p->alpha);

@@ -1,0 +1,88 @@
+"""CPU tests of the SGNS launch rule (gemhip_sgns_plan_launch, gem_amd/csrc/n2v.hip::plan_sgns_launch): host arithmetic, no device.
+
+The reference has nothing to compare with -- the SNAP binary runs one Hogwild thread per core (gem/embedding/node2vec.py:34-53 passes no thread
+count) -- so what is pinned here is the rule DESIGN.md 3.3 derives and the settings the GPU parity tests were measured at:
+rho = W x 5 x w / n_eff <= 1.5 % (w = 0.4 pair steps with reload-on-update), n_eff over the cold rows once hot rows take atomic adds,
+W <= 2 % of the rows that occur, n / (16 x 29) below 8192 nodes, at most 6 wavefronts per CU (LDS) x 256 CUs.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gem_amd import _hip
+
+
+def plan(counts, d=128, window=10, walk_len=80, nwalks=None, flags=11):
+    L = _hip.lib()
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    k, w, hot = C.c_int32(), C.c_int32(), C.c_int32()
+    ne, nec = C.c_double(), C.c_double()
+    nwalks = int(counts.sum() // walk_len) if nwalks is None else nwalks
+    _hip.check(L.gemhip_sgns_plan_launch(_hip.ptr(counts, C.c_int32), counts.size, d, window, walk_len, max(1, nwalks), flags,
+                                         C.byref(k), C.byref(w), C.byref(hot), C.byref(ne), C.byref(nec)))
+    return dict(kernel=k.value, waves=w.value, hot=hot.value, n_eff=ne.value, n_eff_cold=nec.value)
+
+
+def zipf_counts(n, tokens, s=1.0, seed=0):
+    r = np.random.RandomState(seed).permutation(n) + 1.0
+    c = 1.0 / r ** s
+    return np.maximum(1, np.round(c / c.sum() * tokens)).astype(np.int32)
+
+
+def test_benchmark_shape_fills_the_device_without_hot_rows():
+    """SBM 1M/10M (BASELINE configs[3]): equally frequent nodes -> n_eff = n, the rule allows 7500 wavefronts, the device holds 1536."""
+    p = plan(np.full(1000000, 800), nwalks=10000000)
+    assert p == dict(kernel=2, waves=1536, hot=0, n_eff=pytest.approx(1e6), n_eff_cold=pytest.approx(1e6))
+    # fewer walks than wavefronts: one wavefront per walk
+    assert plan(np.full(1000000, 800), nwalks=100)['waves'] == 100
+
+
+@pytest.mark.parametrize('n,waves', [(1024, 2), (4096, 8), (8192, 61), (16384, 122), (100000, 750), (400000, 1536)])
+def test_uniform_graphs_follow_rho_and_the_small_graph_bound(n, waves):
+    """rho <= 1.5 %: W = 0.015 n / (5 x 0.4); below 8192 nodes additionally n / (16 x 29) (tests/test_n2v_gpu.py measured SBM-1024 there)."""
+    p = plan(np.full(n, 800))
+    assert (p['kernel'], p['hot']) == (2, 0) and abs(p['waves'] - waves) <= 1        # (n_eff = z^2 / z2 rounds a hair below n)
+    assert p['waves'] * 5 * 0.4 / p['n_eff'] <= 0.015 + 1e-12
+
+
+def test_power_law_counts_get_hot_rows_and_the_rule_holds_over_the_cold_ones():
+    """R-MAT-like counts: the whole-distribution n_eff would allow a few dozen wavefronts; with the hubs out of the windows the cold rows carry
+    the rule at full width (tests/test_rmat_gpu.py measures the MAP this buys)."""
+    n, tokens = 131072, 131072 * 800
+    c = zipf_counts(n, tokens, 1.0)
+    p = plan(c)
+    assert p['kernel'] == 2 and p['hot'] >= 2
+    assert p['n_eff'] < 0.2 * n < p['n_eff_cold']                       # the hubs dominate the collision rate
+    assert 0.015 * p['n_eff'] / 2 < p['waves'] <= 0.015 * p['n_eff_cold'] / 2 + 1
+    assert p['waves'] <= 0.02 * np.count_nonzero(c) + 1                 # never more than 2 % of the rows that occur
+    # hot = expected to sit in another wavefront's window: count >= tokens / ((W - 1)(2R + 1))
+    assert p['hot'] == max(2, int(np.ceil(c.sum() / ((p['waves'] - 1) * 21.0))))
+    assert (c >= p['hot']).sum() < 0.02 * n
+
+
+def test_rows_that_never_occur_do_not_count():
+    """Half of the table never appears in a walk (isolated nodes): the 2 % bound is over the active rows."""
+    c = np.zeros(200000, dtype=np.int32)
+    c[::2] = 800
+    p = plan(c)
+    assert p['n_eff'] == pytest.approx(100000.0) and abs(p['waves'] - 750) <= 1
+
+
+def test_deterministic_and_fallback_launches():
+    c = np.full(20000, 800)
+    assert plan(c, flags=11 | 4) == dict(kernel=1, waves=1, hot=0, n_eff=pytest.approx(20000.0), n_eff_cold=pytest.approx(20000.0))
+    # rows too wide for two copies of a 21-row window in 64 KB of LDS: the kernel without the window, n / 128 wavefronts
+    p = plan(c, d=384)
+    assert (p['kernel'], p['waves']) == (0, 20000 // 128)
+    assert plan(c, d=256)['kernel'] == 2 and plan(c, d=182)['kernel'] == 2 and plan(c, d=255)['kernel'] == 2
+    # the window-cache opt-out flag of gem_hip.h
+    assert plan(c, flags=11 | _hip.N2V_NO_WINDOW_CACHE)["kernel"] == 0
+
+
+def test_bad_arguments():
+    L = _hip.lib()
+    assert L.gemhip_sgns_plan_launch(None, 10, 128, 10, 80, 1, 11, None, None, None, None, None) != 0
+    c = np.ones(4, dtype=np.int32)
+    assert L.gemhip_sgns_plan_launch(_hip.ptr(c, C.c_int32), 4, 0, 10, 80, 1, 11, None, None, None, None, None) != 0
+    assert L.gemhip_sgns_plan_launch(_hip.ptr(c, C.c_int32), 4, 16, 10, 80, 1, 11, None, None, None, None, None) == 0
