@@ -1112,9 +1112,11 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
     R = std::min(R, std::min(window, 31));
     const int rw = sgns_win_row_floats(d);
     const size_t ints = (size_t)((walk_len + 4 * window * SGNS_NEG + 3) & ~3);
-    auto lds_bytes = [&](bool delta) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * (delta ? 2 : 1) + 1) * rw * sizeof(float); };
-    // the window (2R+1 rows, twice with the delta write-back) has to fit a block's LDS: wide rows / long walks fall back to sgns_kernel
-    P.window = R > 0 && !(flags & GEMHIP_N2V_NO_WINDOW_CACHE) && 2 * window * SGNS_NEG <= 2 * WAVE && walk_len >= 2 && lds_bytes(true) <= 64 * 1024 &&
+    // tokens + negative targets of two centres, the window rows (twice with the delta write-back: as trained / as loaded) and -- unless every context
+    // row is cached (`allc`: R >= window and no hot rows, the launcher's ALLC instantiations) -- one staging row for an uncached context
+    auto lds_bytes = [&](bool delta, bool allc) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * (delta ? 2 : 1) + (allc ? 0 : 1)) * rw * sizeof(float); };
+    // the window has to fit a block's LDS: wide rows / long walks fall back to sgns_kernel
+    P.window = R > 0 && !(flags & GEMHIP_N2V_NO_WINDOW_CACHE) && 2 * window * SGNS_NEG <= 2 * WAVE && walk_len >= 2 && lds_bytes(true, false) <= 64 * 1024 &&
                (d % 2 == 0 ? d <= 512 : d <= 256);
     if (!P.window) {
         // sgns_kernel: four wavefronts per workgroup, no private copies beyond the pair in flight.  Small graphs: when the open rows approach n,
@@ -1131,40 +1133,51 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
     P.R = R;
     const int mode = kn.cache_delta;                 // -1 auto: delta write-back whenever other wavefronts train concurrently
     P.delta = deterministic && mode == 1;            // (cache_delta 1 on a deterministic launch: the Hogwild code path on ONE wavefront, for the parity tests)
+    // a node expected to sit in another wavefront's window at any time -- (W - 1) x (2R + 1) x count / tokens >= 1 -- is hot
+    auto hot_threshold = [&](int64_t waves) -> int32_t {
+        if (kn.hot_count > 0) return kn.hot_count;
+        if (kn.hot_count < 0 && waves > 1 && vs.total > 0.0) {
+            const double thr = vs.total / ((double)(waves - 1) * (2 * R + 1));
+            if (vs.max >= thr) return (int32_t)std::max(2.0, std::ceil(thr));
+        }
+        return 0;
+    };
+    bool allc = R >= window;
     if (!deterministic) {
         P.delta = mode != 0;
-        const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta) + 512)));   // 184 VGPRs: 2 per SIMD
         const double w_steps = (P.delta && kn.reload) ? 0.4 : (double)(kn.prefetch + 1);
         const double n_eff = vs.n_eff > 0.0 ? vs.n_eff : (double)n;
-        int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
         // graphs below 8192 nodes: the window rows themselves (2R+1 per wavefront) are a sizeable part of the table -- SBM-1024 (d=16) loses
         // 3.5 % of MAP at 8 wavefronts and nothing at 2: bound the open fraction of the table at 1/16
         const int64_t hog_tiny = std::max<int64_t>(1, n / (16 * (8 + 2 * R + 1)));
-        const int64_t w_dev = std::min<int64_t>(256 * per_cu, nwalks);
-        // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
-        // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
         // ... but never more wavefronts than 2 % of the rows that occur at all: that is as far as the measurements behind this rule reach (stale
         // gradients cost nothing up to there -- CPU replay at 0.4 %, SBM 100k at 0.8 %, R-MAT scale 17 at 2.0 % of the active rows; R-MAT scale 13 with
         // 26 % of its 5 936 active rows open ended 21 % ABOVE the sequential algorithm's MAP: its hubs under-trained)
         const int64_t w_act = std::max<int64_t>(1, (int64_t)((vs.active > 0.0 ? vs.active : (double)n) / 50.0));
-        if (P.delta && kn.reload && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(w_dev, w_act) && vs.total > 0.0) {
-            for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
-                const double thr = std::max(2.0, std::ceil(vs.total / ((double)(wtry - 1) * (2 * R + 1))));
-                if (0.015 * vs.n_eff_cold(thr) / (5.0 * w_steps) >= (double)wtry) { hog_rho = wtry; break; }
+        auto width = [&](bool all_cached) -> int64_t {
+            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta, all_cached) + 512)));   // 184 VGPRs: 2 per SIMD
+            const int64_t w_dev = std::min<int64_t>(256 * per_cu, nwalks);
+            int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
+            // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
+            // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
+            if (P.delta && kn.reload && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(w_dev, w_act) && vs.total > 0.0) {
+                for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
+                    const double thr = std::max(2.0, std::ceil(vs.total / ((double)(wtry - 1) * (2 * R + 1))));
+                    if (0.015 * vs.n_eff_cold(thr) / (5.0 * w_steps) >= (double)wtry) { hog_rho = wtry; break; }
+                }
             }
-        }
-        const int64_t hog_win = kn.max_waves > 0 ? kn.max_waves : n >= 8192 ? hog_rho : std::min(hog_rho, hog_tiny);
-        P.waves = std::min<int64_t>(hog_win, w_dev);
+            const int64_t hog_win = kn.max_waves > 0 ? kn.max_waves : n >= 8192 ? hog_rho : std::min(hog_rho, hog_tiny);
+            return std::min<int64_t>(hog_win, w_dev);
+        };
+        // the launch without the staging row holds one more wavefront per CU at d = 128 -- but only exists when no row is hot AT THAT WIDTH
+        P.waves = width(allc);
+        if (allc && hot_threshold(P.waves) != 0) { allc = false; P.waves = width(false); }
         if (P.waves == 1 && mode < 0) P.delta = false;
     }
-    P.lds = lds_bytes(P.delta);
+    P.hot_thr = hot_threshold(P.waves);
+    // (the launcher takes an ALLC instantiation iff R >= window && hot_thr == 0: `allc` false with hot_thr 0 only gives that kernel a row it does not use)
+    P.lds = lds_bytes(P.delta, allc && P.hot_thr == 0);
     P.blocks = (int)P.waves; P.threads = 64;
-    // a node expected to sit in another wavefront's window at any time -- (W - 1) x (2R + 1) x count / tokens >= 1 -- is hot
-    if (kn.hot_count > 0) P.hot_thr = kn.hot_count;
-    else if (kn.hot_count < 0 && P.waves > 1 && vs.total > 0.0) {
-        const double thr = vs.total / ((double)(P.waves - 1) * (2 * R + 1));
-        if (vs.max >= thr) P.hot_thr = (int32_t)std::max(2.0, std::ceil(thr));
-    }
     return P;
 }
 

@@ -363,7 +363,9 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     int32_t *tok = lds;
     int32_t *negs = tok + len;                       // [2][nsamp]
     float *rowsL = reinterpret_cast<float *>(lds + ((len + 2 * nsamp + 3) & ~3));
-    float *rowsO = rowsL + (size_t)(S + 1) * RW;     // DELTA only; slot S of rowsL stages a context row that is not cached
+    // slot S of rowsL stages a context row that is not cached -- instantiations that cache every context (ALLC) do not carry it: at d = 128, R = 10 that
+    // brings a wavefront's LDS from 23 136 to 22 624 bytes, i.e. from six to SEVEN wavefronts per CU (plan_sgns_launch sizes the launch the same way)
+    float *rowsO = rowsL + (size_t)(S + (ALLC ? 0 : 1)) * RW;     // DELTA only: the rows as loaded
 
     auto lds_ld = [&](const float *row, float (&v)[NV][VEC]) {
 #pragma unroll

@@ -3,7 +3,8 @@
 The reference has nothing to compare with -- the SNAP binary runs one Hogwild thread per core (gem/embedding/node2vec.py:34-53 passes no thread
 count) -- so what is pinned here is the rule DESIGN.md 3.3 derives and the settings the GPU parity tests were measured at:
 rho = W x 5 x w / n_eff <= 1.5 % (w = 0.4 pair steps with reload-on-update), n_eff over the cold rows once hot rows take atomic adds,
-W <= 2 % of the rows that occur, n / (16 x 29) below 8192 nodes, at most 6 wavefronts per CU (LDS) x 256 CUs.
+W <= 2 % of the rows that occur, n / (16 x 29) below 8192 nodes, at most 7 wavefronts per CU (LDS; 6 when a staging row for uncached contexts
+is needed) x 256 CUs.
 """
 import ctypes as C
 
@@ -31,14 +32,17 @@ def zipf_counts(n, tokens, s=1.0, seed=0):
 
 
 def test_benchmark_shape_fills_the_device_without_hot_rows():
-    """SBM 1M/10M (BASELINE configs[3]): equally frequent nodes -> n_eff = n, the rule allows 7500 wavefronts, the device holds 1536."""
+    """SBM 1M/10M (BASELINE configs[3]): equally frequent nodes -> n_eff = n, the rule allows 7500 wavefronts, the device holds 1792: with every
+    context row cached the kernel needs 22 624 bytes of LDS per wavefront (tokens, targets, 21 rows as trained + 21 as loaded), seven per CU."""
     p = plan(np.full(1000000, 800), nwalks=10000000)
-    assert p == dict(kernel=2, waves=1536, hot=0, n_eff=pytest.approx(1e6), n_eff_cold=pytest.approx(1e6))
+    assert p == dict(kernel=2, waves=1792, hot=0, n_eff=pytest.approx(1e6), n_eff_cold=pytest.approx(1e6))
+    # a window shorter than the context radius needs the staging row for uncached contexts: six per CU
+    assert plan(np.full(1000000, 800), nwalks=10000000, window=12)['waves'] == 1536
     # fewer walks than wavefronts: one wavefront per walk
     assert plan(np.full(1000000, 800), nwalks=100)['waves'] == 100
 
 
-@pytest.mark.parametrize('n,waves', [(1024, 2), (4096, 8), (8192, 61), (16384, 122), (100000, 750), (400000, 1536)])
+@pytest.mark.parametrize('n,waves', [(1024, 2), (4096, 8), (8192, 61), (16384, 122), (100000, 750), (400000, 1792)])
 def test_uniform_graphs_follow_rho_and_the_small_graph_bound(n, waves):
     """rho <= 1.5 %: W = 0.015 n / (5 x 0.4); below 8192 nodes additionally n / (16 x 29) (tests/test_n2v_gpu.py measured SBM-1024 there)."""
     p = plan(np.full(n, 800))
