@@ -288,12 +288,31 @@ class N2VWorkload(object):
         per_pair, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_pair')
         traffic = None if per_pair is None else per_pair * pairs / launches
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                'launch_plan': self.launch_plan(),
                 'traffic': traffic, 'traffic_source': tsrc, 'achieved_traffic_GBs': None if traffic is None else traffic / avg_s / 1e9,
                 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
                 'pairs_per_launch': pairs / launches, 'tokens_per_launch': tokens,
                 'sgns_fraction_of_step': ms / dev_ms_total,
                 'note': 'algorithmic = 7168+24 B per (centre,context) pair at d=128 (SynPos r+w, 6 x SynNeg r+w); the kernel keeps the '
                         'positive SynNeg row in registers across a centre\'s contexts (12/14 of that reaches memory)'}
+
+    def launch_plan(self):
+        """What gemhip_sgns_train chose for this corpus (the rule of DESIGN.md 3.3, recomputed from the token counts by gemhip_sgns_plan_launch;
+        environment overrides of the knobs are not reflected)."""
+        try:
+            if self.world != 1:
+                return None
+            cnt = np.ascontiguousarray(self.b.counts.cpu().numpy(), dtype=np.int32)
+            k, w, hot, ne, nec = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double(), C.c_double()
+            a = self.args
+            _hip.check(_hip.lib().gemhip_sgns_plan_launch(_hip.ptr(cnt, C.c_int32), cnt.size, a.d, a.window, a.walk_len, self.job.hi - self.job.lo,
+                                                          _hip.N2V_SNAP_COMPAT, C.byref(k), C.byref(w), C.byref(hot), C.byref(ne), C.byref(nec)))
+            return {'kernel': ['sgns_kernel', 'sgns_win_kernel (overwrite on leave)', 'sgns_win_kernel (Hogwild: delta write-back, reload-on-update)'][k.value],
+                    'concurrent_wavefronts': w.value, 'hot_row_min_count': hot.value, 'hot_rows': int((cnt >= hot.value).sum()) if hot.value > 0 else 0,
+                    'n_eff': ne.value, 'n_eff_cold': nec.value,
+                    'rho': w.value * 5 * 0.4 / nec.value}
+        except Exception as e:           # (an A/B library without the entry point)
+            return {'error': str(e)[:200]}
 
     def cpu_baseline(self, budget_s=25.0):
         """The real reference binary (oracle/_ref/node2vec = gem/c_exe/node2vec) on a bounded sample: a 2048-node SBM of the same
