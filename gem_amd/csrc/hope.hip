@@ -95,13 +95,22 @@ __global__ __launch_bounds__(256) void hope_spmm16_kernel(int64_t n, const int64
     float acc[CPL16];
 #pragma unroll
     for (int c = 0; c < CPL16; ++c) acc[c] = 0.f;
-    for (int64_t e = e0; e < e1; e += U) {
-        int32_t cj[U]; float vj[U];
+    // the (column, value) pairs of the NEXT U neighbours are requested before the gathers of the current ones: the row's dependent chain
+    // row_ptr -> col/val -> gathers loses one memory round trip per U neighbours (same arithmetic, same order)
+    int32_t cn[U]; float vn[U];
+    auto fetch_edges = [&](int64_t e) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t ee = (e + u) < e1 ? (e + u) : (e1 - 1);
-            cj[u] = col[ee]; vj[u] = (e + u) < e1 ? val[ee] : 0.f;
+            cn[u] = col[ee]; vn[u] = (e + u) < e1 ? val[ee] : 0.f;
         }
+    };
+    if (e0 < e1) fetch_edges(e0);
+    for (int64_t e = e0; e < e1; e += U) {
+        int32_t cj[U]; float vj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { cj[u] = cn[u]; vj[u] = vn[u]; }
+        if (e + U < e1) fetch_edges(e + U);
         float xr[U][CPL16];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -720,13 +729,18 @@ void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const f
         const dim3 grid16((unsigned)((blocks16 + NUM_XCD - 1) / NUM_XCD * NUM_XCD));
         const int c16 = (b + 15) / 16;
 #define SPMM16(C, U) hipLaunchKernelGGL((hope_spmm16_kernel<C, U>), grid16, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
-        static const int uu = getenv("GEMHIP_HOPE_SPMM16_U") ? atoi(getenv("GEMHIP_HOPE_SPMM16_U")) : 8;     // neighbours in flight per row (measured 4 / 8 / 16: 5.5 / 5.2 / 5.8 ms of SpMM per eigen-path solve)
-        if (c16 <= 1) SPMM16(1, 8);
-        else if (c16 <= 2) { if (uu >= 16) SPMM16(2, 16); else SPMM16(2, 8); }
-        else if (c16 <= 3) { if (uu >= 16) SPMM16(3, 16); else if (uu >= 8) SPMM16(3, 8); else SPMM16(3, 4); }
-        else if (c16 <= 4) { if (uu >= 16) SPMM16(4, 16); else if (uu >= 8) SPMM16(4, 8); else SPMM16(4, 4); }
-        else if (c16 <= 5) { if (uu >= 8) SPMM16(5, 8); else SPMM16(5, 4); }
-        else if (c16 <= 6) SPMM16(6, 4); else SPMM16(8, 2);
+        // neighbours in flight per row and round.  With the next round's (column, value) pairs prefetched, short rounds win: measured 2 / 4 / 8 / 16 at
+        // SBM 100k/1M (about 20 neighbours per row): see the dispatch below; round 2, without the prefetch: 4 / 8 / 16 = 5.5 / 5.2 / 5.8 ms of SpMM per solve
+        static const int uu = getenv("GEMHIP_HOPE_SPMM16_U") ? atoi(getenv("GEMHIP_HOPE_SPMM16_U")) : 4;
+#define SPMM16_BY_U(C) do { if (uu >= 8) SPMM16(C, 8); else if (uu >= 4) SPMM16(C, 4); else SPMM16(C, 2); } while (0)
+        if (c16 <= 1) SPMM16_BY_U(1);
+        else if (c16 <= 2) SPMM16_BY_U(2);
+        else if (c16 <= 3) SPMM16_BY_U(3);
+        else if (c16 <= 4) SPMM16_BY_U(4);
+        else if (c16 <= 5) SPMM16_BY_U(5);
+        else if (c16 <= 6) { if (uu >= 4) SPMM16(6, 4); else SPMM16(6, 2); }
+        else SPMM16(8, 2);
+#undef SPMM16_BY_U
 #undef SPMM16
         H.spmm_count += 1; H.spmm_cols += b;
         return;
