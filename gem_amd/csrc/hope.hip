@@ -1329,7 +1329,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
 
     const int64_t threads = (n * (int64_t)b + 3) / 4;
     hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, H.s, Vall, n, b, ldv, seed);
-    int ma = orth_scaled(H, Vall, ldv, b, Tmp, ldv, 2), nl = 0;
+    int ma = orth_scaled(H, Vall, ldv, b, Tmp, ldv, 1), nl = 0;      // (one CholeskyQR pass: a Gaussian block is well conditioned, and the first filter is followed by the full CholeskyQR2)
 
     const double L = kind == 1 ? 1.0001 : kind == 2 ? beta : br / std::fabs(beta);   // |lambda| <= L: power-iteration estimate + margin
     const double smin = kind == 2 ? 0.0 : -L, smax = L;                // the operator's spectrum lies in [smin, smax]
