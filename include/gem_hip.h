@@ -187,7 +187,8 @@ int gemhip_sgns_pairs(gemhip_n2v_t h, int64_t *pairs, int32_t reset);
  * row stores that overwrite another wavefront's store, rho = W x 5 x w / n_eff (w = the load-to-store window of a negative row in pair
  * steps: ~0.4 with reload-on-update, prefetch + 1 without; n_eff = 1 / sum q_v^2 over the negative-sampling distribution: n on a
  * uniform graph, far less with hubs), stays <= 1.5 % -- n_eff/133 with reload-on-update, n_eff/1000 without -- never more than the
- * device holds (1536 on MI355X); graphs below 8192 nodes: 1/16 of the table open at most.  Derivation and the
+ * device holds (on MI355X 1792 = seven per CU when every context row is cached, 1536 otherwise), over the cold rows only once hot rows take
+ * atomic adds (gemhip_sgns_set_hot_rows), at most 2 % of the rows that occur; graphs below 8192 nodes: 1/16 of the table open at most.  Derivation and the
  * measurements behind it: DESIGN.md 3.3, scripts/hogwild_emul. */
 int gemhip_n2v_set_max_waves(gemhip_n2v_t h, int32_t max_waves);
 /* LDS window of TrainModel's context rows (no reference counterpart: the binary keeps its tables in host RAM).
