@@ -48,8 +48,8 @@ struct VocabStats {
     double n = 0.0, total = 0.0, max = 0.0, active = 0.0;     // table rows, tokens, largest count, nodes that occur at all
     double z = 0.0;                    // sum of count^0.75
     double n_eff = 0.0;                // 1 / sum_v q_v^2, q = unigram^0.75 distribution: the table size a uniform graph with the same collision rate would have
-    std::vector<int32_t> cnt_desc;     // token counts, descending, and ...
-    std::vector<double> u2_prefix;     // ... u2_prefix[i] = sum of (count^0.75)^2 over the i largest counts
+    mutable std::vector<int32_t> cnt_desc;     // token counts, descending (after sort_once), and ...
+    mutable std::vector<double> u2_prefix;     // ... u2_prefix[i] = sum of (count^0.75)^2 over the i largest counts
     void build(const int32_t *cnt, int64_t len)
     {
         double tot = 0.0, mx = 0.0, zz = 0.0, z2 = 0.0;
@@ -63,9 +63,14 @@ struct VocabStats {
         }
         total = tot; max = mx; z = zz;
         n_eff = z2 > 0.0 ? zz * zz / z2 : n;
-        cnt_desc.assign(cnt, cnt + len);
+        cnt_desc.assign(cnt, cnt + len);                     // sorted (and the prefix sums formed) only if the rule has to look at the cold rows
+        u2_prefix.clear();
+    }
+    void sort_once() const
+    {
+        if (!u2_prefix.empty()) return;
         std::sort(cnt_desc.begin(), cnt_desc.end(), std::greater<int32_t>());
-        u2_prefix.assign((size_t)len + 1, 0.0);
+        u2_prefix.assign(cnt_desc.size() + 1, 0.0);
         for (size_t i = 0; i < cnt_desc.size(); ++i) {
             const double u = cnt_desc[i] > 0 ? std::pow((double)cnt_desc[i], 0.75) : 0.0;
             u2_prefix[i + 1] = u2_prefix[i] + u * u;
@@ -75,6 +80,7 @@ struct VocabStats {
     double n_eff_cold(double thr) const
     {
         if (cnt_desc.empty() || z <= 0.0) return n;
+        sort_once();
         const size_t nhot = (size_t)(std::lower_bound(cnt_desc.begin(), cnt_desc.end(), thr, [](int32_t c, double t) { return (double)c >= t; }) - cnt_desc.begin());
         const double s2 = (u2_prefix.back() - u2_prefix[nhot]) / (z * z);
         return s2 > 0.0 ? 1.0 / s2 : 1e300;
