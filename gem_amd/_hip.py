@@ -49,6 +49,7 @@ _SIGS = {
     'gemhip_gf_objective': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, f32p, f64p]),
     'gemhip_hope_plan_create': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.POINTER(C.c_void_p)]),
     'gemhip_hope_plan_solve': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64, f32p, f32p, f32p, f64p]),
+    'gemhip_hope_plan_solve_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, f32p, f64p]),
     'gemhip_hope_plan_destroy': (C.c_int, [C.c_void_p]),
     'gemhip_hope': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_float, C.c_uint64, f32p, f32p, f32p, f64p]),

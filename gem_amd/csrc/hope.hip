@@ -1151,28 +1151,32 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
                     Cu[(size_t)(nl + i) * k + j] = wv * su; Cv[(size_t)(nl + i) * k + j] = wv * sv;
                 }
         }
-        if (U_sqrtS) {
-            tsgemm(H, Ball, ldm, mc, Cu, k, 1.0f, nullptr, 0, Tmp, k);           // compact [n][k]: one contiguous download
-            HOPE_TRY(H, hipMemcpy(U_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
+        // deterministic sign: largest-magnitude entry of each left vector positive (svds signs are arbitrary; the first such row on ties).  The
+        // arg-maxima are taken on the device from the compact [n][k] product, the signs go into the coefficients and the product is formed again
+        // (one more 36 us GEMM; rounds 1-2 flipped the n x k outputs in two host passes -- ~10 ms at 100k x 64, and impossible for device outputs)
+        float *d_cm = nullptr;
+        HOPE_TRY(H, hipMalloc((void **)&d_cm, 512 * sizeof(float)));
+        const std::vector<double> &Cref = U_sqrtS ? Cu : Cv;
+        if (!H.err) tsgemm(H, U_sqrtS ? Ball : Vall, ldm, mc, Cref, k, 1.0f, nullptr, 0, Tmp, k);           // compact [n][k]
+        std::vector<float> cm(k, 0.f);
+        if (!H.err) {
+            hipLaunchKernelGGL(hope_colmax_kernel, dim3(k), dim3(256), 0, H.s, n, Tmp, k, d_cm);
+            HOPE_TRY(H, hipMemcpyAsync(cm.data(), d_cm, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, H.s));
+            HOPE_TRY(H, hipStreamSynchronize(H.s));
         }
-        tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, k);
-        HOPE_TRY(H, hipMemcpy(V_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
-        // deterministic sign: largest-magnitude entry of each left vector positive (svds signs are arbitrary).  One
-        // row-major pass for the k arg-maxima and one for the flips (the tables are n x k, 25 MB each at 100k x 64).
-        {
-            const float *ref = U_sqrtS ? U_sqrtS : V_sqrtS;
-            std::vector<float> best(k, 0.f), val(k, 0.f);
-            for (int64_t i = 0; i < n; ++i) {
-                const float *row = ref + i * k;
-                for (int j = 0; j < k; ++j) { const float a = std::fabs(row[j]); if (a > best[j]) { best[j] = a; val[j] = row[j]; } }
+        bool any = false;
+        for (int j = 0; j < k; ++j)
+            if (cm[j] < 0.f) {
+                any = true;
+                for (int i = 0; i < mc; ++i) { Cu[(size_t)i * k + j] = -Cu[(size_t)i * k + j]; Cv[(size_t)i * k + j] = -Cv[(size_t)i * k + j]; }
             }
-            bool any = false;
-            std::vector<float> sgn(k, 1.f);
-            for (int j = 0; j < k; ++j) if (val[j] < 0.f) { sgn[j] = -1.f; any = true; }
-            if (any)
-                for (int64_t i = 0; i < n; ++i)
-                    for (int j = 0; j < k; ++j) { if (U_sqrtS) U_sqrtS[i * k + j] *= sgn[j]; V_sqrtS[i * k + j] *= sgn[j]; }
-        }
+        if (U_sqrtS) {
+            if (any) tsgemm(H, Ball, ldm, mc, Cu, k, 1.0f, nullptr, 0, Tmp, k);
+            HOPE_TRY(H, hipMemcpy(U_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDefault /* host (gemhip_hope_plan_solve) or device (.._solve_device) destination */));
+            tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, k);
+        } else if (any) tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, k);
+        HOPE_TRY(H, hipMemcpy(V_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDefault /* host (gemhip_hope_plan_solve) or device (.._solve_device) destination */));
+        if (d_cm) hipFree(d_cm);
     }
     float ms = 0.f;
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
@@ -1465,10 +1469,10 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         }
         if (U_sqrtS) {
             tsgemm(H, Vall, ldv, mc, Cu, k, 1.0f, nullptr, 0, Tmp, k);
-            HOPE_TRY(H, hipMemcpy(U_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
+            HOPE_TRY(H, hipMemcpy(U_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDefault /* host (gemhip_hope_plan_solve) or device (.._solve_device) destination */));
         }
         tsgemm(H, Vall, ldv, mc, Cv, k, 1.0f, nullptr, 0, Tmp, k);
-        HOPE_TRY(H, hipMemcpy(V_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost));
+        HOPE_TRY(H, hipMemcpy(V_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDefault /* host (gemhip_hope_plan_solve) or device (.._solve_device) destination */));
         // (measured: forming both outputs first and copying them out from two host threads side by side is 0.3 ms SLOWER per solve)
     }
     float ms = 0.f;
@@ -1622,6 +1626,20 @@ extern "C" int gemhip_hope_plan_solve(gemhip_hope_plan_t P, int32_t k, int32_t o
         g_eig_seconds = 0.0; g_eig_calls = 0.0;
     }
     return krylov_svd(H, H.n, k, oversample, krylov_steps, max_restarts, tol, seed, P->terms, P->br, 0, U_sqrtS, V_sqrtS, sigma, stats);
+}
+
+// The same solve with U sqrt(S) and V sqrt(S) left in device memory (n x k floats each, row-major; sigma and stats stay host pointers): for callers
+// that keep the embedding in HBM (evaluation on the device, a following GPU stage) -- the two 4nk-byte PCIe copies into pageable host memory are
+// 1.9 ms of a 13.5 ms solve at n = 100k, k = 64.  The output copies above use hipMemcpyDefault, so this is the same code path.
+extern "C" int gemhip_hope_plan_solve_device(gemhip_hope_plan_t P, int32_t k, int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol,
+                                             uint64_t seed, void *dU_sqrtS, void *dV_sqrtS, float *sigma, double *stats)
+{
+    hipPointerAttribute_t au, av;
+    GEMHIP_REQUIRE(dU_sqrtS && dV_sqrtS, "hope_plan_solve_device: output pointers are NULL");
+    GEMHIP_REQUIRE(hipPointerGetAttributes(&au, dU_sqrtS) == hipSuccess && au.type == hipMemoryTypeDevice &&
+                   hipPointerGetAttributes(&av, dV_sqrtS) == hipSuccess && av.type == hipMemoryTypeDevice,
+                   "hope_plan_solve_device: U / V must be device pointers (use gemhip_hope_plan_solve for host buffers)");
+    return gemhip_hope_plan_solve(P, k, oversample, krylov_steps, max_restarts, tol, seed, (float *)dU_sqrtS, (float *)dV_sqrtS, sigma, stats);
 }
 
 extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,

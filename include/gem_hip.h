@@ -278,6 +278,10 @@ int gemhip_hope_plan_create(int64_t n, int64_t nnz, const int64_t *row_ptr, cons
 int gemhip_hope_plan_solve(gemhip_hope_plan_t plan, int32_t k, int32_t oversample, int32_t krylov_steps,
                            int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS, float *V_sqrtS,
                            float *sigma, double *stats);
+/* gemhip_hope_plan_solve with U sqrt(S) / V sqrt(S) written to DEVICE memory (n x k floats each; sigma, stats: host): the embedding stays in HBM
+ * for a caller that evaluates or post-processes it there.  No reference counterpart (hope.py returns numpy arrays). */
+int gemhip_hope_plan_solve_device(gemhip_hope_plan_t P, int32_t k, int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol,
+                                  uint64_t seed, void *dU_sqrtS, void *dV_sqrtS, float *sigma, double *stats);
 int gemhip_hope_plan_destroy(gemhip_hope_plan_t plan);
 int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
                 float beta, int32_t k, int32_t oversample, int32_t krylov_steps,

@@ -219,3 +219,31 @@ def test_symmetric_eigen_path_two_sided_spectrum(monkeypatch):
     assert np.allclose(Y[:, k - 1], Y[:, 2 * k - 1], atol=1e-6) and np.allclose(Y[:, k - 2], -Y[:, 2 * k - 2], atol=1e-6)
     lam = s / (0.01 * (1 + s))                                   # f^-1 on the positive side
     assert abs(s[k - 2] - 0.01 * lam[k - 1] / (1 + 0.01 * lam[k - 1])) <= 1e-5 * s[k - 2]   # |f(-lambda_max)|
+
+
+@pytest.mark.parametrize('sym', ['0', '1'])
+def test_device_output_solve_equals_the_host_output_solve(sbm1024, sym, monkeypatch):
+    """gemhip_hope_plan_solve_device leaves U sqrt(S) / V sqrt(S) in HBM (what bench.py times: outputs resident); it is the same solve as
+    gemhip_hope_plan_solve (hope.py:33-36 semantics, numpy out) -- both solvers (block Krylov, eigen-path), bit for bit -- and it refuses host
+    pointers instead of writing through them."""
+    import ctypes as C
+    from gem_amd import _hip
+    from gem_amd.graph import to_csr
+    monkeypatch.setenv('GEMHIP_HOPE_SYM', sym)
+    L = _hip.lib()
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    row_ptr, col, _ = to_csr(n, src, dst, None)
+    k = 8
+    plan = C.c_void_p()
+    _hip.check(L.gemhip_hope_plan_create(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, 0.01, C.byref(plan)))
+    U = np.empty((n, k), np.float32); V = np.empty_like(U); s1 = np.empty(k, np.float32); s2 = np.empty(k, np.float32)
+    _hip.check(L.gemhip_hope_plan_solve(plan, k, 16, 3, 20, 1e-5, 7, _hip.ptr(U, C.c_float), _hip.ptr(V, C.c_float), _hip.ptr(s1, C.c_float), None))
+    dU, dV = C.c_void_p(), C.c_void_p()
+    _hip.check(L.gemhip_malloc(C.byref(dU), U.nbytes)); _hip.check(L.gemhip_malloc(C.byref(dV), V.nbytes))
+    _hip.check(L.gemhip_hope_plan_solve_device(plan, k, 16, 3, 20, 1e-5, 7, dU, dV, _hip.ptr(s2, C.c_float), None))
+    U2 = np.empty_like(U); V2 = np.empty_like(V)
+    _hip.check(L.gemhip_memcpy_d2h(U2.ctypes.data_as(C.c_void_p), dU, U.nbytes)); _hip.check(L.gemhip_memcpy_d2h(V2.ctypes.data_as(C.c_void_p), dV, V.nbytes))
+    assert np.array_equal(U, U2) and np.array_equal(V, V2) and np.array_equal(s1, s2)
+    assert L.gemhip_hope_plan_solve_device(plan, k, 16, 3, 20, 1e-5, 7, U.ctypes.data_as(C.c_void_p), dV, _hip.ptr(s2, C.c_float), None) != 0
+    _hip.check(L.gemhip_free(dU)); _hip.check(L.gemhip_free(dV))
+    _hip.check(L.gemhip_hope_plan_destroy(plan))
