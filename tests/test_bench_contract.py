@@ -75,3 +75,13 @@ def test_round3_default_line_is_one_run_with_every_baseline_config():
     q = j['quality']
     assert q['oracle_map'] and abs(q['map_minus_oracle_map']) <= 0.01 * q['oracle_map']          # north_star: MAP within 1 % (paired with the sequential algorithm)
     assert 0.5 < j['roofline']['frac'] < 1.0 and j['roofline']['achieved_traffic_GBs'] < 8000.0
+    # the launch the concurrency rule chose is part of the record: all seven wavefronts per CU on the headline graph, hot rows on the power-law one
+    lp = j['roofline']['launch_plan']
+    assert lp['concurrent_wavefronts'] == 1792 and lp['hot_rows'] == 0 and lp['rho'] < 0.015
+    lr = j['workloads']['node2vec_rmat22']['roofline']['launch_plan']
+    assert lr['hot_rows'] > 0 and lr['rho'] < 0.015 and lr['n_eff'] < lr['n_eff_cold']
+    # HOPE: `value` is the device-resident solve; the numpy-out form GEM's API needs is reported beside it and is the same solve
+    for name in ('hope_sbm100k_1m', 'hope_sbm100k_directed'):
+        w = j['workloads'][name]
+        pc = w['roofline']['pcie_inclusive']
+        assert pc['outputs_identical_to_device_form'] and pc['seconds_per_step'] >= 1e-3 * w['ms_per_step'] * 0.98
