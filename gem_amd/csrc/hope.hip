@@ -1634,10 +1634,14 @@ extern "C" int gemhip_hope_plan_solve(gemhip_hope_plan_t P, int32_t k, int32_t o
 extern "C" int gemhip_hope_plan_solve_device(gemhip_hope_plan_t P, int32_t k, int32_t oversample, int32_t krylov_steps, int32_t max_restarts, float tol,
                                              uint64_t seed, void *dU_sqrtS, void *dV_sqrtS, float *sigma, double *stats)
 {
-    hipPointerAttribute_t au, av;
     GEMHIP_REQUIRE(dU_sqrtS && dV_sqrtS, "hope_plan_solve_device: output pointers are NULL");
-    GEMHIP_REQUIRE(hipPointerGetAttributes(&au, dU_sqrtS) == hipSuccess && au.type == hipMemoryTypeDevice &&
-                   hipPointerGetAttributes(&av, dV_sqrtS) == hipSuccess && av.type == hipMemoryTypeDevice,
+    auto on_device = [](const void *p) {
+        hipPointerAttribute_t a;
+        const bool ok = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();            // a plain host pointer makes the query itself fail: do not leave that error for the next launch check
+        return ok;
+    };
+    GEMHIP_REQUIRE(on_device(dU_sqrtS) && on_device(dV_sqrtS),
                    "hope_plan_solve_device: U / V must be device pointers (use gemhip_hope_plan_solve for host buffers)");
     return gemhip_hope_plan_solve(P, k, oversample, krylov_steps, max_restarts, tol, seed, (float *)dU_sqrtS, (float *)dV_sqrtS, sigma, stats);
 }
