@@ -14,7 +14,7 @@ from test_n2v_gpu import Dev
 
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'ab_sgns_1m.jsonl')
 cfgs = sys.argv[2:] or ['1024:2:0', '1024:2:1', '1536:2:1', '1536:1:1', '1536:2:0']
-ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_oracle_1000k.json')))
+ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', os.environ.get('GEM_AB_GOLDEN', 'n2v_ref_oracle_1000k.json'))))     # (GEM_AB_GOLDEN=n2v_ref_oracle_1000k_s4096.json: the 4096-node sample)
 pr = ref['params']
 g = sbm_graph(pr['n'], pr['edges'], pr['blocks'], pr['seed'])
 nodes = np.random.RandomState(0).choice(g.n, size=len(ref['ap']), replace=False)
