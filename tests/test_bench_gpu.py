@@ -72,7 +72,7 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
       * oracle: the HIP path is run with the ORACLE'S SEED (same walks, same negative draws), so per-node AP differences are paired and what
         remains is Hogwild: three runs, their MEAN relative gap must be inside +-1 %.  Measured with the round-3 default (reload-on-update;
         1536 resident wavefronts: +0.36, -0.07, +0.51, -0.26, +0.22, +0.20 %; 1792 = seven per CU, the closing default: +0.33, +0.52, +0.21 %;
-        profiles/r03_ab_sgns_1m*.jsonl), i.e. mean +0.2 %, run-to-run s.d. 0.3 %, plus 0.4 % (1024-node sample) / 0.2 % (4096) sampling error of
+        profiles/r03_ab_sgns_1m*.jsonl; over the 4096-node golden: +0.20, +0.20, +0.06 %), i.e. mean +0.2 %, run-to-run s.d. 0.3 %, plus 0.4 % (1024-node sample) / 0.2 % (4096) sampling error of
         the gap that the three runs share: the bar is > 2 s.d. away on either side, P(flake) < 2 %.  (Round 2's default sat at -0.74 % and needed
         "+2 s.e.".)
       * SNAP binary: its seed is time(), so the comparison is UNPAIRED in the walks: seed-to-seed the MAP of either implementation moves by
