@@ -386,6 +386,15 @@ class N2VWorkload(object):
         assert bool(torch.isfinite(self.P).all()), 'non-finite embedding'
         assert float(self.P.abs().max()) > 1e-3
 
+    @staticmethod
+    def _ref_golden(engine, n):
+        """Committed reference run of `engine` ('snap' | 'oracle') on the n-node benchmark graph: the one scored over the larger node sample."""
+        gdir = os.path.join(ROOT, 'tests', 'golden')
+        for name in ('n2v_ref_%s_%dk_s4096.json' % (engine, n // 1000), 'n2v_ref_%s_%dk.json' % (engine, n // 1000)):
+            if os.path.exists(os.path.join(gdir, name)):
+                return os.path.join(gdir, name)
+        return os.path.join(gdir, 'n2v_ref_%s_%dk.json' % (engine, n // 1000))
+
     def quality(self, nsample=1024):
         """Outside the timed region: graph-reconstruction MAP of the learned table over a FIXED node sample, with the reference
         evaluator's semantics (gem_amd/csrc/eval.hip), next to the MAP the reference binary reaches on the very same graph and
@@ -393,7 +402,7 @@ class N2VWorkload(object):
         from gem_amd.evaluation import reconstruction as gr
         a = self.args
         for engine in ('snap', 'oracle'):             # score the sample the committed reference runs were scored on
-            path = os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_%s_%dk.json' % (engine, self.g.n // 1000))
+            path = self._ref_golden(engine, self.g.n)
             if a.graph == 'sbm' and os.path.exists(path):
                 nsample = max(nsample, len(json.load(open(path))['ap']))
         rng = np.random.RandomState(0)
@@ -402,7 +411,7 @@ class N2VWorkload(object):
         out = {'sampled_map': float(ap.mean()), 'sampled_map_se': float(ap.std(ddof=1) / np.sqrt(len(ap))), 'nodes_sampled': int(len(nodes)),
                'evaluator': 'metrics.computeMAP semantics on the GPU', 'reference_map': None}
         for engine, key in (('snap', 'reference_map'), ('oracle', 'oracle_map')):
-            path = os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_%s_%dk.json' % (engine, self.g.n // 1000))
+            path = self._ref_golden(engine, self.g.n)
             if a.graph == 'sbm' and os.path.exists(path):
                 ref = json.load(open(path))
                 pr = ref['params']
