@@ -23,6 +23,9 @@
 #include <cstring>
 #include <chrono>
 #include <cstdlib>
+#include <atomic>
+#include <thread>
+#include <sched.h>
 
 using namespace gemhip;
 
@@ -375,15 +378,56 @@ static const EigOps &eig_ops()
     return has ? avx2 : base;
 }
 
+// Host threads for the O(n^3) phases of the eigensolver (the reduction's matrix-vector product and rank-2 update, the
+// back-transformation of the wanted vectors).  GEMHIP_EIG_THREADS (read once) or gemhip_set_host_threads(); default
+// min(4, half the cores this process may run on).  Threads are created per call and joined before it returns: nothing outlives
+// the call, so fork() in the host program (bench.py's CPU baselines are subprocesses) never meets a live pool.
+int g_eig_threads = -1;
+static int eig_threads()
+{
+    if (g_eig_threads < 0) {
+        int t = 4;
+        if (const char *e = getenv("GEMHIP_EIG_THREADS")) t = atoi(e);
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) t = std::min(t, std::max(1, CPU_COUNT(&set) / 2));   // spin barriers want idle cores
+        g_eig_threads = std::max(1, std::min(t, 16));
+    }
+    return g_eig_threads;
+}
+
+// Sense-reversing barrier: a step of the reduction is a few microseconds of work per thread, far below what a futex
+// round trip costs, so waiters spin (and yield once the wait is long: an oversubscribed host must not live-lock).
+struct SpinBarrier {
+    std::atomic<int> count{0}, gen{0};
+    int T = 1;
+    void wait()
+    {
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) == T - 1) {
+            count.store(0, std::memory_order_relaxed);
+            gen.store(g + 1, std::memory_order_release);
+            return;
+        }
+        for (int spins = 0; gen.load(std::memory_order_acquire) == g; ++spins) {
+            if (spins < 2048) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+                __builtin_ia32_pause();
+#endif
+            } else std::this_thread::yield();
+        }
+    }
+};
+
 // Householder reduction to tridiagonal form (the first half of tred2), column-major access.  On return: the diagonal of T
 // is A(i,i), e[i] (i >= 1) couples i-1 and i, column i+1 rows 0..i hold the reflector u_{i+1} and d[i+1] its h = |u|^2/2
 // (0: no reflector), so that  Q = P_{n-1} ... P_1,  P_i = I - u_i u_i^T / h_i  on the leading i coordinates.
-static void eig_reduce(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op)
+// eig_reduce_steps runs steps i = i_from .. 1; on entry d[0..i_from) holds row i_from of the current matrix.
+static void eig_reduce_steps(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op, int i_from)
 {
     auto A = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
     auto col = [&](int j) -> double * { return V.data() + (size_t)j * n; };
-    for (int j = 0; j < n; ++j) d[j] = A(n - 1, j);
-    for (int i = n - 1; i > 0; --i) {
+    for (int i = i_from; i > 0; --i) {
         double scale = 0.0, h = 0.0;
         for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
         if (scale == 0.0) {
@@ -422,6 +466,130 @@ static void eig_reduce(int n, std::vector<double> &V, std::vector<double> &d, st
         }
         d[i] = h;
     }
+}
+
+// The same steps i = n-1 .. i_stop on T threads.  Columns are dealt to the threads in blocks of 8 (block-cyclic: the
+// active triangle shrinks from the right, so every thread keeps an equal share, and a thread always meets the same
+// columns -- they stay in its own L2).  Per step: every thread forms the scaled reflector from the shared row (O(i),
+// redundantly, on a private copy), computes its columns' share of p = A u into a private partial vector (the lower
+// triangle is read once: dot for the part below the diagonal, axpy for the mirrored part), BARRIER, sums the partials
+// (O(T i), redundantly), applies the rank-2 update to its own columns and publishes the elements of the next row it
+// owns, BARRIER.  Two barriers and no shared writes besides those rows; sums are taken in a different order than the
+// serial loop takes them, so results agree to rounding (1e-16 relative), not bit for bit.
+// Returns the last step it completed (i_stop, or an earlier one: thread 0 times every 8 steps against what ONE thread would
+// need at a pessimistic 4 GFLOP/s and calls the threaded phase off when it is not even keeping up with that -- the sign of
+// a host whose cores are taken (another library's worker threads spinning after a BLAS call make every barrier cost a
+// scheduler quantum: measured 110 ms instead of 5 ms for n = 448 on an 8-core container).  The caller finishes serially.
+static int eig_reduce_mt(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op, int T, int i_stop)
+{
+    std::atomic<int> bail{0};
+    int i_done = n;
+    const int CB = 8;                                            // column block = one cache line of the shared row
+    const size_t ldp = ((size_t)n + 15) / 8 * 8 + 8;
+    std::vector<double> parts((size_t)T * ldp, 0.0), rows(2 * ldp, 0.0);
+    for (int j = 0; j < n; ++j) rows[j] = d[j];
+    SpinBarrier bar; bar.T = T;
+    auto body = [&](int t) {
+        auto A = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
+        auto col = [&](int j) -> double * { return V.data() + (size_t)j * n; };
+        std::vector<double> dl(n, 0.0), el(n, 0.0);
+        double *mine = parts.data() + (size_t)t * ldp;
+        double *cur = rows.data(), *nxt = rows.data() + ldp;
+        bar.wait();                                              // everybody is up: thread start-up stays out of the timing below
+        auto tick = std::chrono::steady_clock::now();
+        double budget = 0.0;                                     // seconds one thread would need for the steps since `tick`
+        auto end_of_step = [&](int i) {                          // thread 0, right before the barrier that ends step i
+            budget += 4.0 * i * i / 4e9 + 1e-6;
+            if (n - 1 - i < 8 || ((n - 1 - i) & 7) == 7) {        // every step at first: a contended host shows at the first barrier
+                const auto now = std::chrono::steady_clock::now();
+                if (std::chrono::duration<double>(now - tick).count() > budget) bail.store(1, std::memory_order_relaxed);
+                tick = now; budget = 0.0;
+            }
+        };
+        int i = n - 1;
+        for (; i >= i_stop; --i) {
+            if (bail.load(std::memory_order_relaxed)) break;    // stored before the barrier that ended step i+1: all threads agree
+            double scale = 0.0, h = 0.0;
+            for (int k = 0; k < i; ++k) { dl[k] = cur[k]; scale += std::fabs(dl[k]); }
+            if (scale == 0.0) {
+                if (t == 0) { e[i] = dl[i - 1]; d[i] = 0.0; }
+                bar.wait();      // two barriers in this branch as well: thread 0 raises `bail` between the two barriers of a step, and every
+                                 // thread reads it after the second one -- with a single barrier a late thread could read it a step early
+                for (int jb = t * CB; jb < i; jb += T * CB)
+                    for (int j = jb; j < std::min(jb + CB, i); ++j) { nxt[j] = A(i - 1, j); A(i, j) = 0.0; A(j, i) = 0.0; }
+                if (t == 0) end_of_step(i);
+                bar.wait();
+                std::swap(cur, nxt);
+                continue;
+            }
+            for (int k = 0; k < i; ++k) { dl[k] /= scale; h += dl[k] * dl[k]; }
+            double f = dl[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            if (t == 0) e[i] = scale * g;
+            h -= f * g;
+            dl[i - 1] = f - g;
+            for (int k = 0; k < i; ++k) mine[k] = 0.0;
+            for (int jb = t * CB; jb < i; jb += T * CB)
+                for (int j = jb; j < std::min(jb + CB, i); ++j) {
+                    f = dl[j];
+                    A(j, i) = f;
+                    g = A(j, j) * f;
+                    const int len = i - 1 - j;
+                    if (len > 0) {
+                        g += op.dot(col(j) + j + 1, dl.data() + j + 1, len);
+                        op.axpy(mine + j + 1, f, col(j) + j + 1, len);
+                    }
+                    mine[j] += g;
+                }
+            bar.wait();
+            for (int k = 0; k < i; ++k) el[k] = parts[k];
+            for (int u = 1; u < T; ++u) {
+                const double *pu = parts.data() + (size_t)u * ldp;
+                for (int k = 0; k < i; ++k) el[k] += pu[k];
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { el[j] /= h; f += el[j] * dl[j]; }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) el[j] -= hh * dl[j];
+            for (int jb = t * CB; jb < i; jb += T * CB)
+                for (int j = jb; j < std::min(jb + CB, i); ++j) {
+                    op.axpy2(col(j) + j, dl[j], el.data() + j, el[j], dl.data() + j, i - j);
+                    nxt[j] = A(i - 1, j);
+                    A(i, j) = 0.0;
+                }
+            if (t == 0) { d[i] = h; end_of_step(i); }
+            bar.wait();
+            std::swap(cur, nxt);
+        }
+        if (t == 0) {
+            i_done = i + 1;
+            for (int k = 0; k < i_done; ++k) d[k] = cur[k];       // the state eig_reduce_steps continues from
+        }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(body, t);
+    const auto t1 = std::chrono::steady_clock::now();
+    body(0);
+    const auto t2 = std::chrono::steady_clock::now();
+    for (auto &th : pool) th.join();
+    if (getenv("GEMHIP_EIG_DEBUG")) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+        fprintf(stderr, "[eig-mt] n=%d T=%d create %.3f ms  steps %d..%d %.3f ms  join %.3f ms\n", n, T, ms(t0, t1), n - 1, i_done, ms(t1, t2),
+                ms(t2, std::chrono::steady_clock::now()));
+    }
+    return i_done;
+}
+
+static void eig_reduce(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op)
+{
+    for (int j = 0; j < n; ++j) d[j] = V[(size_t)j * n + (n - 1)];
+    const int T = eig_threads();
+    int i_from = n - 1;
+    const int i_stop = 96;                     // below this a step is shorter than its two barriers
+    if (T > 1 && n >= 2 * i_stop) i_from = eig_reduce_mt(n, V, d, e, op, T, i_stop) - 1;
+    eig_reduce_steps(n, V, d, e, op, i_from);
 }
 
 void sym_eig_impl(int n, std::vector<double> &V, std::vector<double> &d)
@@ -652,12 +820,25 @@ void sym_eig_top_impl(int n, std::vector<double> &V, int m, std::vector<double> 
     }
     const auto tD = tnow();
     // eigenvectors of A = Q z :  apply P_1, ..., P_{n-1} in that order (P_{i+1} acts on coordinates 0..i)
-    for (int j = 0; j < m; ++j) {
-        double *zj = Z.data() + (size_t)j * n;
+    // (reflector outermost: it stays in L1 while the vectors of a chunk pass under it; chunks of vectors on threads -- every
+    // vector sees the same operations in the same order as in a vector-by-vector loop, so the result does not depend on T)
+    auto back = [&](int j0, int j1) {
         for (int i = 0; i + 1 < n; ++i) {
             const double h = hh[i + 1];
-            if (h != 0.0) op.axpy(zj, -op.dot(col(i + 1), zj, i + 1) / h, col(i + 1), i + 1);
+            if (h == 0.0) continue;
+            const double *c = col(i + 1);
+            for (int j = j0; j < j1; ++j) {
+                double *zj = Z.data() + (size_t)j * n;
+                op.axpy(zj, -op.dot(c, zj, i + 1) / h, c, i + 1);
+            }
         }
+    };
+    {
+        const int T = (n >= 128 && m >= 8) ? std::min(eig_threads(), m / 4) : 1;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(back, (int)((int64_t)m * t / T), (int)((int64_t)m * (t + 1) / T));
+        back(0, T > 1 ? m / T : m);
+        for (auto &th : pool) th.join();
     }
     if (eig_dbg) fprintf(stderr, "[eig-top] n=%d m=%d reduce %.2f ms  eigenvalues %.2f ms  inverse iteration %.2f ms  back-transform %.2f ms\n", n, m,
                          tms(tA, tB), tms(tB, tC), tms(tC, tD), tms(tD, tnow()));
@@ -1810,6 +1991,15 @@ extern "C" int gemhip_lle(int64_t n, int64_t nnz, const int64_t *row_ptr, const 
 extern "C" int gemhip_set_sym_eig_callback(int (*fn)(int32_t, double *, double *))
 {
     g_eig_cb = fn;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_set_host_threads(int32_t threads, int32_t *in_effect_out)
+{
+    GEMHIP_REQUIRE(threads <= 16, "set_host_threads: at most 16 threads (got %d)", threads);
+    g_eig_threads = threads >= 1 ? threads : -1;          // <= 0: back to the default (GEMHIP_EIG_THREADS or min(4, usable cores))
+    const int t = eig_threads();
+    if (in_effect_out) *in_effect_out = t;
     return GEMHIP_OK;
 }
 

@@ -321,6 +321,12 @@ int gemhip_sym_eig_builtin(int32_t n, double *A_inout, double *w_out);
  * iteration, back-transformation of m vectors.  A destroyed; w_out: m eigenvalues DESCENDING; Z_out: m eigenvectors,
  * one after the other (n doubles each).  Host code, callable without a GPU. */
 int gemhip_sym_eig_top(int32_t n, double *A_inout, int32_t m, double *w_out, double *Z_out);
+/* Host threads of the built-in eigensolver's O(n^3) phases (Householder reduction from n = 192 on, back-transformation of the
+ * wanted vectors).  threads >= 1 (at most 16) sets the count, <= 0 restores the default: GEMHIP_EIG_THREADS, else
+ * min(4, half the cores this process may run on).  in_effect_out (may be NULL) receives the count in effect.  Results of the
+ * reduction agree between thread counts to rounding (sums are taken in a different order), not bit for bit.  There is no
+ * reference counterpart: hope.py:32 hands the whole SVD to ARPACK/LAPACK, which thread through their BLAS. */
+int gemhip_set_host_threads(int32_t threads, int32_t *in_effect_out);
 /* Optional: let the host supply a faster symmetric eigensolver for the projected problems (same contract as
  * gemhip_sym_eig: row-major symmetric A overwritten by eigenvectors in columns, w ascending, return 0).  The Python
  * layer registers numpy's LAPACK (dsyevd) here; NULL restores the built-in Householder/QL solver. */

@@ -145,6 +145,25 @@ def test_host_partial_eigensolver():
     for n, m in ((290, 80), (200, 48), (128, 30), (5, 2), (3, 3), (2, 1), (1, 1)):
         B = rng.randn(3 * n + 5, n)
         check(B.T @ B / n, m)
+    run_cases(check, rng)
+    # the same cases with the reduction and the back-transformation on ONE thread and on FOUR (gemhip_set_host_threads): from n = 192 on
+    # the Householder steps are shared between threads (block-cyclic columns, two barriers per step)
+    eff = ctypes.c_int32()
+    for T in (1, 4):
+        _hip.check(L.gemhip_set_host_threads(T, ctypes.byref(eff)))
+        assert eff.value == T
+        run_cases(check, np.random.RandomState(1))
+        for n, m in ((192, 60), (193, 20), (448, 72), (512, 80)):
+            B = rng.randn(2 * n, n)
+            check(B.T @ B / n, m)
+    _hip.check(L.gemhip_set_host_threads(0, ctypes.byref(eff)))      # back to the default
+    assert 1 <= eff.value <= 4
+    assert L.gemhip_set_host_threads(17, None) != 0
+    assert L.gemhip_sym_eig_top(4, None, 2, None, None) != 0
+
+
+def run_cases(check, rng):
+    import numpy as np
     n = 300
     Q, _ = np.linalg.qr(rng.randn(n, n))
     lam = np.concatenate([1 + 1e-4 * rng.rand(200), 2 + rng.rand(68), [5, 5, 5, 5, 7, 7, 9, 9, 9, 9, 9, 9], np.zeros(20)])
@@ -157,7 +176,6 @@ def test_host_partial_eigensolver():
     check(B.T @ B, 120)                                            # rank 100: the request reaches into the null space
     G = np.diag(np.concatenate([np.linspace(1, 0.3, 80), 0.2 * rng.rand(210)])); E = 1e-3 * rng.randn(290, 290)
     check(G + E + E.T, 80)                                         # what a restarted Rayleigh-Ritz matrix looks like
-    assert L.gemhip_sym_eig_top(4, None, 2, None, None) != 0
 
 
 def test_gf_plan_rejects_edge_orders_the_reference_loop_cannot_be_scheduled_for():
