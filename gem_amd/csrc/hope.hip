@@ -482,7 +482,7 @@ static void eig_reduce_steps(int n, std::vector<double> &V, std::vector<double> 
 // scheduler quantum: measured 110 ms instead of 5 ms for n = 448 on an 8-core container).  The caller finishes serially.
 static int eig_reduce_mt(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op, int T, int i_stop)
 {
-    std::atomic<int> bail{0};
+    std::atomic<int> bail{0}, go{0};
     int i_done = n;
     const int CB = 8;                                            // column block = one cache line of the shared row
     const size_t ldp = ((size_t)n + 15) / 8 * 8 + 8;
@@ -495,6 +495,11 @@ static int eig_reduce_mt(int n, std::vector<double> &V, std::vector<double> &d, 
         std::vector<double> dl(n, 0.0), el(n, 0.0);
         double *mine = parts.data() + (size_t)t * ldp;
         double *cur = rows.data(), *nxt = rows.data() + ldp;
+        if (t > 0) {                                             // workers wait for the verdict on thread creation (1 run, 2 abort)
+            for (int spins = 0; go.load(std::memory_order_acquire) == 0; ++spins)
+                if (spins > 2048) std::this_thread::yield();
+            if (go.load(std::memory_order_acquire) == 2) return;
+        }
         bar.wait();                                              // everybody is up: thread start-up stays out of the timing below
         auto tick = std::chrono::steady_clock::now();
         double budget = 0.0;                                     // seconds one thread would need for the steps since `tick`
@@ -569,7 +574,15 @@ static int eig_reduce_mt(int n, std::vector<double> &V, std::vector<double> &d, 
     };
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(body, t);
+    try {
+        for (int t = 1; t < T; ++t) pool.emplace_back(body, t);
+    } catch (...) {                                              // no more threads to be had (pid limit, memory): the caller's serial loop does it all
+        go.store(2, std::memory_order_release);
+        for (auto &th : pool) th.join();
+        for (int k = 0; k < n; ++k) d[k] = rows[k];
+        return n;
+    }
+    go.store(1, std::memory_order_release);
     const auto t1 = std::chrono::steady_clock::now();
     body(0);
     const auto t2 = std::chrono::steady_clock::now();
@@ -836,8 +849,12 @@ void sym_eig_top_impl(int n, std::vector<double> &V, int m, std::vector<double> 
     {
         const int T = (n >= 128 && m >= 8) ? std::min(eig_threads(), m / 4) : 1;
         std::vector<std::thread> pool;
-        for (int t = 1; t < T; ++t) pool.emplace_back(back, (int)((int64_t)m * t / T), (int)((int64_t)m * (t + 1) / T));
+        int started = 1;                                         // chunks handed out (chunk 0 is this thread's)
+        try {
+            for (int t = 1; t < T; ++t, ++started) pool.emplace_back(back, (int)((int64_t)m * t / T), (int)((int64_t)m * (t + 1) / T));
+        } catch (...) {}                                         // thread creation failed: the chunks not handed out are done here
         back(0, T > 1 ? m / T : m);
+        for (int t = started; t < T; ++t) back((int)((int64_t)m * t / T), (int)((int64_t)m * (t + 1) / T));
         for (auto &th : pool) th.join();
     }
     if (eig_dbg) fprintf(stderr, "[eig-top] n=%d m=%d reduce %.2f ms  eigenvalues %.2f ms  inverse iteration %.2f ms  back-transform %.2f ms\n", n, m,
