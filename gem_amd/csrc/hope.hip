@@ -479,11 +479,14 @@ static void eig_reduce_steps(int n, std::vector<double> &V, std::vector<double> 
 // Returns the last step it completed (i_stop, or an earlier one: thread 0 times every 8 steps against what ONE thread would
 // need at a pessimistic 4 GFLOP/s and calls the threaded phase off when it is not even keeping up with that -- the sign of
 // a host whose cores are taken (another library's worker threads spinning after a BLAS call make every barrier cost a
-// scheduler quantum: measured 110 ms instead of 5 ms for n = 448 on an 8-core container).  The caller finishes serially.
+// scheduler quantum: measured 110 ms instead of 5 ms for n = 448 on an 8-core container).  The caller finishes the steps down to i_stop with
+// eig_reduce_virtual (the same arithmetic on one thread), so WHEN the threads were called off never shows in the result.
 static int eig_reduce_mt(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op, int T, int i_stop)
 {
     std::atomic<int> bail{0}, go{0};
     int i_done = n;
+    const char *tb = getenv("GEMHIP_EIG_TEST_BAIL_AFTER");       // test hook: call the threaded phase off after this many steps
+    const int test_bail_after = tb ? atoi(tb) : -1;
     const int CB = 8;                                            // column block = one cache line of the shared row
     const size_t ldp = ((size_t)n + 15) / 8 * 8 + 8;
     std::vector<double> parts((size_t)T * ldp, 0.0), rows(2 * ldp, 0.0);
@@ -504,6 +507,7 @@ static int eig_reduce_mt(int n, std::vector<double> &V, std::vector<double> &d, 
         auto tick = std::chrono::steady_clock::now();
         double budget = 0.0;                                     // seconds one thread would need for the steps since `tick`
         auto end_of_step = [&](int i) {                          // thread 0, right before the barrier that ends step i
+            if (test_bail_after >= 0 && n - 1 - i >= test_bail_after) bail.store(1, std::memory_order_relaxed);
             budget += 4.0 * i * i / 4e9 + 1e-6;
             if (n - 1 - i < 8 || ((n - 1 - i) & 7) == 7) {        // every step at first: a contended host shows at the first barrier
                 const auto now = std::chrono::steady_clock::now();
@@ -595,13 +599,80 @@ static int eig_reduce_mt(int n, std::vector<double> &V, std::vector<double> &d, 
     return i_done;
 }
 
+// Steps i_from .. i_stop with the ARITHMETIC of eig_reduce_mt at T threads, on the calling thread: the same columns feed the same partial
+// vectors in the same order and the partials are summed in the same order, so the result is bit-identical to what the T threads would have
+// produced.  This is what continues after eig_reduce_mt called its threads off (or could not create them): the output of the reduction then
+// depends on T alone, never on when the contended-host check fired.
+static void eig_reduce_virtual(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op, int T, int i_from, int i_stop)
+{
+    const int CB = 8;
+    const size_t ldp = ((size_t)n + 15) / 8 * 8 + 8;
+    std::vector<double> parts((size_t)T * ldp, 0.0), dl(n, 0.0), el(n, 0.0), nxt(n, 0.0);
+    auto A = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
+    auto col = [&](int j) -> double * { return V.data() + (size_t)j * n; };
+    for (int i = i_from; i >= i_stop; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) { dl[k] = d[k]; scale += std::fabs(dl[k]); }
+        if (scale == 0.0) {
+            e[i] = dl[i - 1];
+            for (int j = 0; j < i; ++j) { nxt[j] = A(i - 1, j); A(i, j) = 0.0; A(j, i) = 0.0; }
+            for (int j = 0; j < i; ++j) d[j] = nxt[j];
+            d[i] = 0.0;
+            continue;
+        }
+        for (int k = 0; k < i; ++k) { dl[k] /= scale; h += dl[k] * dl[k]; }
+        double f = dl[i - 1];
+        double g = std::sqrt(h);
+        if (f > 0) g = -g;
+        e[i] = scale * g;
+        h -= f * g;
+        dl[i - 1] = f - g;
+        for (int t = 0; t < T; ++t) {
+            double *mine = parts.data() + (size_t)t * ldp;
+            for (int k = 0; k < i; ++k) mine[k] = 0.0;
+            for (int jb = t * CB; jb < i; jb += T * CB)
+                for (int j = jb; j < std::min(jb + CB, i); ++j) {
+                    f = dl[j];
+                    A(j, i) = f;
+                    g = A(j, j) * f;
+                    const int len = i - 1 - j;
+                    if (len > 0) {
+                        g += op.dot(col(j) + j + 1, dl.data() + j + 1, len);
+                        op.axpy(mine + j + 1, f, col(j) + j + 1, len);
+                    }
+                    mine[j] += g;
+                }
+        }
+        for (int k = 0; k < i; ++k) el[k] = parts[k];
+        for (int u = 1; u < T; ++u) {
+            const double *pu = parts.data() + (size_t)u * ldp;
+            for (int k = 0; k < i; ++k) el[k] += pu[k];
+        }
+        f = 0.0;
+        for (int j = 0; j < i; ++j) { el[j] /= h; f += el[j] * dl[j]; }
+        const double hh = f / (h + h);
+        for (int j = 0; j < i; ++j) el[j] -= hh * dl[j];
+        for (int j = 0; j < i; ++j) {
+            op.axpy2(col(j) + j, dl[j], el.data() + j, el[j], dl.data() + j, i - j);
+            nxt[j] = A(i - 1, j);
+            A(i, j) = 0.0;
+        }
+        for (int j = 0; j < i; ++j) d[j] = nxt[j];
+        d[i] = h;
+    }
+}
+
 static void eig_reduce(int n, std::vector<double> &V, std::vector<double> &d, std::vector<double> &e, const EigOps &op)
 {
     for (int j = 0; j < n; ++j) d[j] = V[(size_t)j * n + (n - 1)];
     const int T = eig_threads();
     int i_from = n - 1;
     const int i_stop = 96;                     // below this a step is shorter than its two barriers
-    if (T > 1 && n >= 2 * i_stop) i_from = eig_reduce_mt(n, V, d, e, op, T, i_stop) - 1;
+    if (T > 1 && n >= 2 * i_stop) {
+        const int i_done = eig_reduce_mt(n, V, d, e, op, T, i_stop);
+        if (i_done > i_stop) eig_reduce_virtual(n, V, d, e, op, T, i_done - 1, i_stop);    // threads called off early: same arithmetic, one thread
+        i_from = i_stop - 1;
+    }
     eig_reduce_steps(n, V, d, e, op, i_from);
 }
 

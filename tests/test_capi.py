@@ -162,6 +162,37 @@ def test_host_partial_eigensolver():
     assert L.gemhip_sym_eig_top(4, None, 2, None, None) != 0
 
 
+def test_threaded_reduction_does_not_depend_on_when_its_threads_are_called_off(monkeypatch):
+    """eig_reduce_mt times its steps and calls the threads off on a contended host; the remaining steps run the SAME arithmetic on one
+    thread (eig_reduce_virtual), so the result is a function of the matrix and the thread count only -- bit for bit -- wherever the switch
+    happens (GEMHIP_EIG_TEST_BAIL_AFTER forces it after k steps)."""
+    import numpy as np
+    L = _hip.lib()
+    rng = np.random.RandomState(3)
+
+    def solve(A, m):
+        n = A.shape[0]
+        V = A.copy(); w = np.zeros(m); Z = np.zeros((m, n))
+        _hip.check(L.gemhip_sym_eig_top(n, _hip.ptr(V, ctypes.c_double), m, _hip.ptr(w, ctypes.c_double), _hip.ptr(Z, ctypes.c_double)))
+        return w, Z
+    try:
+        for n in (192, 300):
+            B = rng.randn(2 * n, n)
+            half = np.zeros((n, n)); half[:n // 2, :n // 2] = (B.T @ B)[:n // 2, :n // 2]
+            for A in (B.T @ B / n, np.diag(rng.rand(n)), half):
+                for T in (2, 4):
+                    _hip.check(L.gemhip_set_host_threads(T, None))
+                    monkeypatch.delenv('GEMHIP_EIG_TEST_BAIL_AFTER', raising=False)
+                    w0, Z0 = solve(A, 40)
+                    for k in (0, 1, 7, 50):
+                        monkeypatch.setenv('GEMHIP_EIG_TEST_BAIL_AFTER', str(k))
+                        w, Z = solve(A, 40)
+                        assert np.array_equal(w, w0) and np.array_equal(Z, Z0), (n, T, k)
+    finally:
+        monkeypatch.delenv('GEMHIP_EIG_TEST_BAIL_AFTER', raising=False)
+        L.gemhip_set_host_threads(0, None)
+
+
 def run_cases(check, rng):
     import numpy as np
     n = 300
