@@ -2,9 +2,16 @@
  * oracle/n2v_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * CPU restatement of the node2vec path GEM runs through the prebuilt SNAP binary
- * gem/c_exe/node2vec (call site gem/embedding/node2vec.py:34-48).  PARITY UNPINNED at
- * the vector level: the binary seeds its RNG with time() and trains Hogwild over OpenMP
- * threads, so the reference has no reproducible output; its source is third-party
+ * gem/c_exe/node2vec (call site gem/embedding/node2vec.py:34-48).  As GEM runs it the
+ * binary seeds its RNG with time() and trains Hogwild over OpenMP threads, so it has no
+ * reproducible output.  WALK HALF PINNED at the vector level all the same: with time()
+ * fixed (oracle/shim/faketime.c) and one thread the binary is deterministic, and
+ * oracle/snap_stream.py -- the same walk semantics as this file on the binary's own
+ * sequential TRnd stream -- reproduces walk matrices dumped from the running binary bit
+ * for bit (tests/golden/n2v_snap_stream_walks.json); this file's alias tables and
+ * transition frequencies are tied to that restatement in tests/test_oracle_n2v.py.
+ * SGNS HALF: PARITY UNPINNED at the vector level (pinned through MAP against the binary's
+ * own runs up to SBM 1M/10M).  The source is third-party
  * (snap-stanford/snap, examples/node2vec + snap-adv/{n2v,biasedrandomwalk,word2vec}.cpp,
  * not vendored, not version pinned -- gem/c_exe/readme.txt:1; ELF banner "Apr 9 2017").
  * This file restates the published algorithm; constants and the sampling quirks were

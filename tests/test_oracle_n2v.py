@@ -1,7 +1,10 @@
-"""CPU tests: the node2vec oracle (oracle/n2v_oracle.c).  The reference binary is time-seeded
-and racy, so there is no vector-level pin ("parity unpinned"); these tests pin the restatement
-to the published algorithm's DISTRIBUTIONS and to the real binary's MAP (tests/golden/n2v_ref.json,
-produced by scripts/make_golden.py from gem/c_exe/node2vec)."""
+"""CPU tests: the node2vec oracle (oracle/n2v_oracle.c, oracle/snap_stream.py).  The reference binary is time-seeded and racy as
+GEM runs it; with time() pinned (oracle/shim/faketime.c) and one thread it is deterministic, and the WALK half is pinned to it at the
+vector level: oracle/snap_stream.py (TRnd stream, Shuffle, PreprocessNode / GetNodeAlias in fp64, SimulateWalk) reproduces walk
+matrices dumped from the running binary bit for bit (tests/golden/n2v_snap_stream_walks.json, scripts/make_golden_n2v_snap_stream.py).
+The counter-based oracle the kernels are compared with (n2v_oracle.c: Philox instead of a sequential stream, rejection instead of
+per-pair tables) is tied to that restatement through its alias tables and its transition frequencies; the SGNS half stays pinned
+through MAP against the real binary (tests/golden/n2v_ref.json, produced by scripts/make_golden.py from gem/c_exe/node2vec)."""
 import ctypes as C
 import json
 
@@ -157,3 +160,68 @@ def test_oracle_map_matches_single_thread_snap(karate, sbm1024):
     # and the reference's own acceptance test (tests/test_karate.py:57-60,78) holds for the restatement
     tgt = np.loadtxt(golden_path('ref_karate_node2vec.txt'))
     assert abs(np.mean(tgt - X)) < 0.3
+
+
+# ------------------------------------------------------------------ vector-level pin of the walk half to the reference binary
+def _stream_cases():
+    return json.load(open(golden_path('n2v_snap_stream_walks.json')))['cases']
+
+
+@pytest.mark.parametrize('name', ['karate_p1_q1', 'karate_p0.25_q4', 'karate_p4_q0.25', 'karate_weighted_p0.5_q2',
+                                  'directed_with_sinks_p1_q1', 'directed_with_sinks_p2_q0.5'])
+def test_snap_stream_restatement_reproduces_the_reference_binary_walk_for_walk(name):
+    """gem/c_exe/node2vec with time() pinned and OMP_NUM_THREADS=1, its walk matrix dumped at LearnEmbeddings() entry, against
+    oracle/snap_stream.py on the same edge file, (p, q) and seed: every token of every walk, including the zero padding behind sinks."""
+    from oracle import snap_stream as ss
+    c = _stream_cases()[name]
+    order, nbr, w = ss.load_edge_list(c['edge_lines'], directed=True, weighted=True)
+    mine = ss.simulate_walks(order, nbr, w, c['p'], c['q'], c['num_walks'], c['walk_len'], c['seed'])
+    ref = np.asarray(c['walks'], dtype=np.int32)
+    assert mine.shape == ref.shape and np.array_equal(mine, ref)
+    if 'sinks' in name:
+        assert (ref[:, -1] == 0).sum() > 5                       # the case does exercise early stops
+
+
+def test_counter_based_oracle_builds_the_alias_tables_the_pinned_restatement_builds():
+    """GetNodeAlias: oracle_alias_build_f32 (fp32, what the device builds bit for bit) against snap_stream.node_alias (fp64, pinned to the
+    binary through its walks): the same alias targets K -- same stacks, filled in index order, popped from the back -- and U to fp32."""
+    from oracle import snap_stream as ss
+    rng = np.random.RandomState(3)
+    for N in (1, 2, 3, 7, 33, 200):
+        w = (rng.rand(N) ** 2 + 0.05).astype(np.float32)
+        U = np.zeros(N, np.float32); K = np.zeros(N, np.int32); work = np.zeros(N, np.int32)
+        oracle.lib().oracle_alias_build_f32(N, oracle._p(w, C.c_float), oracle._p(U, C.c_float), oracle._p(K, C.c_int32), oracle._p(work, C.c_int32))
+        P = w.astype(np.float64) / w.astype(np.float64).sum()
+        K64, U64 = ss.node_alias(P.tolist())
+        if np.abs(np.asarray(U64) - 1.0).min() > 1e-5 or N == 1:      # (a U within rounding of 1 may land on the other stack in fp32)
+            assert K.tolist() == K64
+            np.testing.assert_allclose(U, U64, atol=3e-6)
+        np.testing.assert_allclose(alias_implied(U, K), alias_implied(np.asarray(U64), K64), atol=2e-6)
+
+
+def test_counter_based_oracle_walks_follow_the_pinned_transition_tables():
+    """The rejection sampler of n2v_oracle.c (what the HIP walk kernel equals bit for bit) against the per-(t, v) alias tables of the
+    restatement that reproduces the binary: the probabilities those tables encode are what its (t, v) -> x frequencies must follow."""
+    from oracle import snap_stream as ss
+    c = _stream_cases()['karate_weighted_p0.5_q2']
+    order, nbr, w = ss.load_edge_list(c['edge_lines'], directed=True, weighted=True)
+    tables = ss.preprocess_transition_probs(order, nbr, w, c['p'], c['q'])
+    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
+    wt = np.array([float(ln.split()[2]) for ln in c['edge_lines']], dtype=np.float32)
+    n = int(e.max()) + 1
+    row_ptr, col, ww = oracle.sorted_csr(n, e[:, 0], e[:, 1], wt)
+    U, K = oracle.n2v_alias_rows(row_ptr, ww)
+    walks = oracle.n2v_walks(row_ptr, col, U, K, c['p'], c['q'], 1500, 20, 5, SNAP)
+    second = {}
+    for wk in walks:
+        for k in range(2, walks.shape[1]):
+            second.setdefault((int(wk[k - 2]), int(wk[k - 1])), []).append(int(wk[k]))
+    checked = 0
+    for (t, v), xs in second.items():
+        if len(xs) < 1500:
+            continue
+        Kt, Ut = tables[(t, v)]
+        probs = alias_implied(np.asarray(Ut), Kt)
+        assert chi2_ok([xs.count(x) for x in nbr[v]], probs), (t, v)
+        checked += 1
+    assert checked >= 20
