@@ -4,14 +4,18 @@
  * CPU restatement of the node2vec path GEM runs through the prebuilt SNAP binary
  * gem/c_exe/node2vec (call site gem/embedding/node2vec.py:34-48).  As GEM runs it the
  * binary seeds its RNG with time() and trains Hogwild over OpenMP threads, so it has no
- * reproducible output.  WALK HALF PINNED at the vector level all the same: with time()
- * fixed (oracle/shim/faketime.c) and one thread the binary is deterministic, and
- * oracle/snap_stream.py -- the same walk semantics as this file on the binary's own
- * sequential TRnd stream -- reproduces walk matrices dumped from the running binary bit
- * for bit (tests/golden/n2v_snap_stream_walks.json); this file's alias tables and
- * transition frequencies are tied to that restatement in tests/test_oracle_n2v.py.
- * SGNS HALF: PARITY UNPINNED at the vector level (pinned through MAP against the binary's
- * own runs up to SBM 1M/10M).  The source is third-party
+ * reproducible output.  PINNED at the vector level all the same, through
+ * oracle/snap_stream.py: with time() fixed (oracle/shim/faketime.c) and one thread the
+ * binary is deterministic, and snap_stream.py -- the semantics of this file on the
+ * binary's own sequential TRnd stream, in its fp64 -- reproduces (i) walk matrices dumped
+ * from the running binary bit for bit and (ii) the embedding files those runs wrote to
+ * the six digits the binary prints (tests/golden/n2v_snap_stream_walks.json).  THIS file
+ * is tied to that restatement in tests/test_oracle_n2v.py: the same walk body and the
+ * same TrainModel body, fed with this file's counter-based draws, give this file's walks
+ * bit for bit and this file's embeddings to fp32 rounding (2e-5); alias targets equal;
+ * second-order frequencies follow the pinned per-pair tables.  What stays statistical is
+ * only what cannot be otherwise: Hogwild launches, and p,q != 1 walks (rejection here,
+ * per-pair tables there: same distribution, different draws).  The source is third-party
  * (snap-stanford/snap, examples/node2vec + snap-adv/{n2v,biasedrandomwalk,word2vec}.cpp,
  * not vendored, not version pinned -- gem/c_exe/readme.txt:1; ELF banner "Apr 9 2017").
  * This file restates the published algorithm; constants and the sampling quirks were

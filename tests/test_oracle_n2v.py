@@ -1,10 +1,12 @@
 """CPU tests: the node2vec oracle (oracle/n2v_oracle.c, oracle/snap_stream.py).  The reference binary is time-seeded and racy as
-GEM runs it; with time() pinned (oracle/shim/faketime.c) and one thread it is deterministic, and the WALK half is pinned to it at the
-vector level: oracle/snap_stream.py (TRnd stream, Shuffle, PreprocessNode / GetNodeAlias in fp64, SimulateWalk) reproduces walk
-matrices dumped from the running binary bit for bit (tests/golden/n2v_snap_stream_walks.json, scripts/make_golden_n2v_snap_stream.py).
+GEM runs it; with time() pinned (oracle/shim/faketime.c) and one thread it is deterministic, and BOTH halves are pinned to it at the
+vector level: oracle/snap_stream.py (TRnd stream, Shuffle, PreprocessNode / GetNodeAlias in fp64, SimulateWalk; LearnEmbeddings /
+TrainModel) reproduces walk matrices dumped from the running binary bit for bit and the embedding files the same runs wrote to the six
+digits the binary prints (tests/golden/n2v_snap_stream_walks.json, scripts/make_golden_n2v_snap_stream.py).
 The counter-based oracle the kernels are compared with (n2v_oracle.c: Philox instead of a sequential stream, rejection instead of
-per-pair tables) is tied to that restatement through its alias tables and its transition frequencies; the SGNS half stays pinned
-through MAP against the real binary (tests/golden/n2v_ref.json, produced by scripts/make_golden.py from gem/c_exe/node2vec)."""
+per-pair tables, fp32) is tied to that restatement: the same walk body and the same TrainModel body fed with its draws give its walks
+bit for bit and its embeddings to fp32 rounding; alias targets equal; second-order frequencies follow the pinned tables.  Larger
+graphs and Hogwild launches: MAP against the real binary (tests/golden/n2v_ref.json, produced by scripts/make_golden.py)."""
 import ctypes as C
 import json
 
@@ -225,3 +227,90 @@ def test_counter_based_oracle_walks_follow_the_pinned_transition_tables():
         assert chi2_ok([xs.count(x) for x in nbr[v]], probs), (t, v)
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize('name', ['karate_p1_q1', 'karate_p0.25_q4', 'karate_weighted_p0.5_q2', 'directed_with_sinks_p2_q0.5'])
+def test_snap_stream_restatement_reproduces_the_embedding_file_the_reference_binary_wrote(name):
+    """The SGNS half: from the binary's own walks, oracle/snap_stream.learn_embeddings (renaming, second TRnd, InitPosEmb, unigram alias,
+    RndUnigramInt's quirk, TrainModel with the exp table) against the .emb file of the SAME deterministic run -- same node order, every
+    number to the six significant digits `%g` prints (relative 5e-6)."""
+    from oracle import snap_stream as ss
+    c = _stream_cases()[name]
+    ids, X = ss.learn_embeddings(c['walks'], 8, 3, 1, c['seed'])
+    lines = c['emb_d8_k3'].strip().split('\n')
+    assert lines[0].split() == [str(len(ids)), '8']
+    rows = [ln.split() for ln in lines[1:]]
+    assert [int(r[0]) for r in rows] == ids
+    R = np.array([[float(x) for x in r[1:]] for r in rows])
+    assert np.all(np.abs(X - R) <= 5.5e-6 * np.abs(R) + 1e-12), float((np.abs(X - R) / np.abs(R)).max())
+    assert np.abs(R).max() > 0.1                                  # (the run did train: rows moved far from their +-1/16 initial range)
+
+
+def test_counter_based_sgns_oracle_is_the_pinned_train_model_on_other_draws():
+    """oracle_sgns_train (fp32, Philox draws; what the deterministic HIP launch is compared with) against snap_stream.train_model -- the
+    body that reproduces the binary's output -- fed with the SAME Philox draws: same window shrinks, same negative targets (incl.
+    RndUnigramInt's quirk), same update order; what remains is fp32 against fp64 and the exact sigmoid against ... the exact sigmoid."""
+    from oracle import snap_stream as ss
+    c = _stream_cases()['karate_p1_q1']
+    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
+    n, d, window, seed = int(e.max()) + 1, 8, 3, 12345
+    row_ptr, col, _ = oracle.sorted_csr(n, e[:, 0], e[:, 1], None)
+    walks = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, 3, 12, seed, SNAP)
+    UT, KT = oracle.unigram_build(oracle.n2v_vocab(n, walks))
+    P, N = oracle.sgns_init(n, d, seed)
+    P64, N64 = P.astype(np.float64), N.astype(np.float64)
+    oracle.sgns_train(walks, window, 0.025, 1, 0, walks.size, 0, 0, UT, KT, seed, SNAP, P, N)
+    L = oracle.lib()
+    buf = (C.c_uint32 * 4)()
+
+    def philox(c0, c1, c2, c3):
+        L.oracle_philox(C.c_uint64(seed), C.c_uint32(c0), C.c_uint32(c1), C.c_uint32(c2), C.c_uint32(c3), buf)
+        return buf[0], buf[1]
+
+    def offset_draw(wi, pos):
+        return philox(wi, 0, pos, 2)[0] % window                      # TAG_WIN, epoch 0
+
+    def negative_draw(wi, pos, a, j):
+        x, y = philox(wi, 0, pos | (a << 16), 3 | (j << 16))          # TAG_NEG, epoch 0
+        X = int(KT[(x * n) >> 32])                                    # SNAP's quirk: the alias of the slot
+        return X if np.float32(y >> 8) * np.float32(1.0 / 16777216.0) < UT[X] else int(KT[X])
+    ss.train_model(walks.astype(np.int64), P64, N64, window, 1, offset_draw, negative_draw, sigmoid='exact')
+    assert np.abs(P - P64).max() <= 2e-5 * np.abs(P64).max() and np.abs(N - N64).max() <= 2e-5 * np.abs(N64).max()
+    assert np.abs(P64).max() > 0.1
+
+
+@pytest.mark.parametrize('name', ['karate_p1_q1', 'directed_with_sinks_p1_q1'])
+def test_counter_based_walk_oracle_is_the_pinned_simulate_walk_on_other_draws(name):
+    """oracle_n2v_walks (what the HIP walk kernel equals bit for bit) against snap_stream.simulate_walks -- the body that reproduces the
+    binary's walks -- fed with the SAME Philox draws and the same Feistel start permutation, first-order unweighted case (the headline's):
+    identical matrices, sinks and zero padding included."""
+    from oracle import snap_stream as ss
+    c = _stream_cases()[name]
+    order, nbr, w = ss.load_edge_list(c['edge_lines'], directed=True, weighted=True)
+    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
+    n, seed, rounds, L_ = int(e.max()) + 1, 424242, 3, 14
+    row_ptr, col, _ = oracle.sorted_csr(n, e[:, 0], e[:, 1], None)
+    ref = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, rounds, L_, seed, SNAP)
+    lib = oracle.lib()
+    start = oracle.start_nodes(row_ptr, col)
+    m = len(start)
+    assert m == len(order)
+    buf = (C.c_uint32 * 4)()
+
+    class Draws(object):
+        def round_order(self, r, ids):
+            key = seed ^ (((r + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+            return [int(start[lib.oracle_perm(j, m, C.c_uint64(key))]) for j in range(m)]
+
+        def _slot(self, wid, length, deg):
+            lib.oracle_philox(C.c_uint64(seed), C.c_uint32(wid), C.c_uint32(0), C.c_uint32(length), C.c_uint32(1), buf)   # TAG_WALK, trial 0
+            return (buf[0] * deg) >> 32
+
+        def first_hop(self, wid, deg):
+            return self._slot(wid, 1, deg)
+
+        def alias_draw(self, wid, length, tab):
+            assert all(abs(u - 1.0) < 1e-12 for u in tab[1])              # unweighted, p = q = 1: every slot accepts
+            return self._slot(wid, length, len(tab[0]))
+    mine = ss.simulate_walks(order, nbr, w, 1.0, 1.0, rounds, L_, seed, draws=Draws())
+    assert np.array_equal(mine, ref)
