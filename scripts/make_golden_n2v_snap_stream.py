@@ -43,12 +43,12 @@ def edge_lines(kind):
     raise ValueError(kind)
 
 
-def run_binary(lines, d, walk_len, num_walks, window, p, q, seed):
+def run_binary(lines, d, walk_len, num_walks, window, p, q, seed, epochs=1):
     tmp = tempfile.mkdtemp()
     gfile, efile, wfile, cfile = (os.path.join(tmp, f) for f in ('g.graph', 'g.emb', 'walks.bin', 'cmds.gdb'))
     with open(gfile, 'w') as fh:
         fh.write('\n'.join(lines) + '\n')
-    argv = ['-i:' + gfile, '-o:' + efile, '-d:%d' % d, '-l:%d' % walk_len, '-r:%d' % num_walks, '-k:%d' % window, '-e:1',
+    argv = ['-i:' + gfile, '-o:' + efile, '-d:%d' % d, '-l:%d' % walk_len, '-r:%d' % num_walks, '-k:%d' % window, '-e:%d' % epochs,
             '-p:%f' % p, '-q:%f' % q, '-dr', '-w']
     with open(cfile, 'w') as fh:
         fh.write('set pagination off\nset environment GEM_FAKE_TIME %d\nset environment LD_PRELOAD %s\nset environment OMP_NUM_THREADS 1\n'
@@ -66,26 +66,28 @@ def run_binary(lines, d, walk_len, num_walks, window, p, q, seed):
 
 
 CASES = [
-    # name, graph, p, q, num_walks, walk_len, seed
-    ('karate_p1_q1', 'karate', 1.0, 1.0, 3, 12, 1000),
-    ('karate_p0.25_q4', 'karate', 0.25, 4.0, 3, 12, 1001),
-    ('karate_p4_q0.25', 'karate', 4.0, 0.25, 2, 12, 77),
-    ('karate_weighted_p0.5_q2', 'karate_weighted', 0.5, 2.0, 2, 10, 31337),
-    ('directed_with_sinks_p1_q1', 'directed_with_sinks', 1.0, 1.0, 2, 10, 4242),
-    ('directed_with_sinks_p2_q0.5', 'directed_with_sinks', 2.0, 0.5, 2, 10, 99),
+    # name, graph, p, q, num_walks, walk_len, seed, (d, window, epochs)
+    ('karate_p1_q1', 'karate', 1.0, 1.0, 3, 12, 1000, (8, 3, 1)),
+    ('karate_p0.25_q4', 'karate', 0.25, 4.0, 3, 12, 1001, (8, 3, 1)),
+    ('karate_p4_q0.25', 'karate', 4.0, 0.25, 2, 12, 77, (8, 3, 1)),
+    ('karate_weighted_p0.5_q2', 'karate_weighted', 0.5, 2.0, 2, 10, 31337, (8, 3, 1)),
+    ('directed_with_sinks_p1_q1', 'directed_with_sinks', 1.0, 1.0, 2, 10, 4242, (8, 3, 1)),
+    ('directed_with_sinks_p2_q0.5', 'directed_with_sinks', 2.0, 0.5, 2, 10, 99, (8, 3, 1)),
+    # two epochs over 10 200 words each: TrainModel refreshes alpha at words 0, 10 000 and 20 000 against 2 * 10 200 + 1
+    ('karate_two_epochs_alpha_schedule', 'karate', 1.0, 1.0, 10, 30, 2024, (4, 2, 2)),
 ]
 
 
 def main():
     out = {'_how': 'scripts/make_golden_n2v_snap_stream.py: gem/c_exe/node2vec under oracle/shim/faketime.c (GEM_FAKE_TIME = seed), OMP_NUM_THREADS=1, '
                    'walk matrix dumped with rocgdb at LearnEmbeddings() entry; flags -dr -w as gem/embedding/node2vec.py:35-46', 'cases': {}}
-    for name, graph, p, q, r, l, seed in CASES:
+    for name, graph, p, q, r, l, seed, (d, window, epochs) in CASES:
         lines = edge_lines(graph)
-        walks, emb = run_binary(lines, 8, l, r, 3, p, q, seed)
-        again, emb2 = run_binary(lines, 8, l, r, 3, p, q, seed)
+        walks, emb = run_binary(lines, d, l, r, window, p, q, seed, epochs)
+        again, emb2 = run_binary(lines, d, l, r, window, p, q, seed, epochs)
         assert np.array_equal(walks, again) and emb == emb2, 'the shimmed binary is not deterministic?'
         out['cases'][name] = {'edge_lines': lines, 'p': p, 'q': q, 'num_walks': r, 'walk_len': l, 'seed': seed,
-                              'walks': walks.tolist(), 'emb_d8_k3': emb}
+                              'walks': walks.tolist(), 'd': d, 'window': window, 'epochs': epochs, 'emb': emb}
         print(name, walks.shape, 'deterministic: yes')
     path = os.path.join(ROOT, 'tests', 'golden', 'n2v_snap_stream_walks.json')
     with open(path, 'w') as fh:

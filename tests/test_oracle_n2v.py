@@ -170,7 +170,7 @@ def _stream_cases():
 
 
 @pytest.mark.parametrize('name', ['karate_p1_q1', 'karate_p0.25_q4', 'karate_p4_q0.25', 'karate_weighted_p0.5_q2',
-                                  'directed_with_sinks_p1_q1', 'directed_with_sinks_p2_q0.5'])
+                                  'directed_with_sinks_p1_q1', 'directed_with_sinks_p2_q0.5', 'karate_two_epochs_alpha_schedule'])
 def test_snap_stream_restatement_reproduces_the_reference_binary_walk_for_walk(name):
     """gem/c_exe/node2vec with time() pinned and OMP_NUM_THREADS=1, its walk matrix dumped at LearnEmbeddings() entry, against
     oracle/snap_stream.py on the same edge file, (p, q) and seed: every token of every walk, including the zero padding behind sinks."""
@@ -229,16 +229,18 @@ def test_counter_based_oracle_walks_follow_the_pinned_transition_tables():
     assert checked >= 20
 
 
-@pytest.mark.parametrize('name', ['karate_p1_q1', 'karate_p0.25_q4', 'karate_weighted_p0.5_q2', 'directed_with_sinks_p2_q0.5'])
+@pytest.mark.parametrize('name', ['karate_p1_q1', 'karate_p0.25_q4', 'karate_weighted_p0.5_q2', 'directed_with_sinks_p2_q0.5',
+                                  'karate_two_epochs_alpha_schedule'])
 def test_snap_stream_restatement_reproduces_the_embedding_file_the_reference_binary_wrote(name):
     """The SGNS half: from the binary's own walks, oracle/snap_stream.learn_embeddings (renaming, second TRnd, InitPosEmb, unigram alias,
     RndUnigramInt's quirk, TrainModel with the exp table) against the .emb file of the SAME deterministic run -- same node order, every
-    number to the six significant digits `%g` prints (relative 5e-6)."""
+    number to the six significant digits `%g` prints (relative 5e-6).  The last case runs two epochs over 10 200 words each: the alpha
+    schedule (refreshed every 10 000 words against epochs * words + 1) is part of what it pins."""
     from oracle import snap_stream as ss
     c = _stream_cases()[name]
-    ids, X = ss.learn_embeddings(c['walks'], 8, 3, 1, c['seed'])
-    lines = c['emb_d8_k3'].strip().split('\n')
-    assert lines[0].split() == [str(len(ids)), '8']
+    ids, X = ss.learn_embeddings(c['walks'], c['d'], c['window'], c['epochs'], c['seed'])
+    lines = c['emb'].strip().split('\n')
+    assert lines[0].split() == [str(len(ids)), str(c['d'])]
     rows = [ln.split() for ln in lines[1:]]
     assert [int(r[0]) for r in rows] == ids
     R = np.array([[float(x) for x in r[1:]] for r in rows])
