@@ -273,3 +273,58 @@ def learn_embeddings(walks, d, window, iters, seed):
     train_model(walks, syn_pos, syn_neg, window, iters, lambda wi, pos: rnd.uni_dev_int() % window,
                 lambda wi, pos, a, j: rnd_unigram_int(K, U, rnd))
     return back, syn_pos
+
+
+# ------------------------------------------------------------------------------------------ C port (oracle/snap_stream.c)
+def _clib():
+    import ctypes as C
+    import oracle
+    L = oracle.lib()
+    if not getattr(L, '_snap_stream_ready', False):
+        i32p, i64p, f64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        L.snap_stream_walks.restype = C.c_int
+        L.snap_stream_walks.argtypes = [C.c_int64, C.c_int64, i32p, i64p, i32p, f64p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, i32p]
+        L.snap_stream_learn_embeddings.restype = C.c_int
+        L.snap_stream_learn_embeddings.argtypes = [C.c_int64, C.c_int32, i32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, f64p, i64p]
+        L._snap_stream_ready = True
+    return L
+
+
+def fast_walks(order, nbr, w, p, q, num_walks, walk_len, seed):
+    """simulate_walks through the C port (same arguments, same result)."""
+    import ctypes as C
+    n = max(order) + 1
+    deg = np.zeros(n, dtype=np.int64)
+    for v in order:
+        deg[v] = len(nbr[v])
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=row_ptr[1:])
+    col = np.zeros(max(int(row_ptr[-1]), 1), dtype=np.int32)
+    wt = np.zeros(max(int(row_ptr[-1]), 1), dtype=np.float64)
+    for v in order:
+        a = int(row_ptr[v])
+        for k, x in enumerate(nbr[v]):
+            col[a + k] = x
+            wt[a + k] = w[(v, x)]
+    ordr = np.ascontiguousarray(order, dtype=np.int32)
+    out = np.zeros((num_walks * len(order), walk_len), dtype=np.int32)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = _clib().snap_stream_walks(n, len(order), P(ordr, C.c_int32), P(row_ptr, C.c_int64), P(col, C.c_int32), P(wt, C.c_double), float(p), float(q),
+                                   num_walks, walk_len, int(seed), P(out, C.c_int32))
+    assert rc == 0
+    return out
+
+
+def fast_learn_embeddings(walks, d, window, iters, seed):
+    """learn_embeddings through the C port (same arguments, same result)."""
+    import ctypes as C
+    wk = np.ascontiguousarray(walks, dtype=np.int32).copy()
+    bound = int(wk.max()) + 1
+    ids = np.zeros(bound, dtype=np.int32)
+    emb = np.zeros((bound, d), dtype=np.float64)
+    n_out = C.c_int64()
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = _clib().snap_stream_learn_embeddings(wk.shape[0], wk.shape[1], P(wk, C.c_int32), bound, d, window, iters, int(seed), P(ids, C.c_int32),
+                                              P(emb, C.c_double), C.byref(n_out))
+    assert rc == 0
+    return ids[:n_out.value].tolist(), emb[:n_out.value].copy()

@@ -95,5 +95,27 @@ def main():
     print('wrote', path, os.path.getsize(path), 'bytes')
 
 
+def main_sbm1024():
+    """The reference's hyper-parameters (examples/run_sbm.py:70: walk_len 80, num_walks 10, con_size 10, p = q = 1, one epoch) at
+    BASELINE's d = 128 on the reference's own SBM-1024 graph (tests/golden/sbm1024_edges.npy = gem/data/sbm.gpickle re-encoded):
+    819 200 words.  Kept: the SHA-256 of the binary's walk matrix and its embedding file (float32: the file carries six digits)."""
+    import hashlib
+    e = np.load(os.path.join(ROOT, 'tests', 'golden', 'sbm1024_edges.npy'))
+    lines = ['%d %d %f' % (int(i), int(j), 1.0) for i, j in e.tolist()]
+    d, l, r, k, seed = 128, 80, 10, 10, 20260924
+    walks, emb = run_binary(lines, d, l, r, k, 1.0, 1.0, seed, 1)
+    rows = [ln.split() for ln in emb.strip().split('\n')[1:]]
+    ids = np.array([int(x[0]) for x in rows], dtype=np.int32)
+    X = np.array([[float(v) for v in x[1:]] for x in rows])
+    path = os.path.join(ROOT, 'tests', 'golden', 'n2v_snap_stream_sbm1024.npz')
+    np.savez_compressed(path, ids=ids, emb=X.astype(np.float32), walks_sha256=hashlib.sha256(np.ascontiguousarray(walks, dtype=np.int32).tobytes()).hexdigest(),
+                        walks_shape=np.array(walks.shape), walks_head=walks[:4], params=json.dumps({'d': d, 'walk_len': l, 'num_walks': r, 'window': k, 'epochs': 1,
+                                                                                                     'p': 1.0, 'q': 1.0, 'seed': seed, 'flags': '-dr -w'}))
+    print('wrote', path, os.path.getsize(path), 'bytes; walks', walks.shape, 'max |emb|', np.abs(X).max())
+
+
 if __name__ == '__main__':
-    main()
+    if '--sbm1024' in sys.argv:
+        main_sbm1024()
+    else:
+        main()

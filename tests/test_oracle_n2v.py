@@ -316,3 +316,37 @@ def test_counter_based_walk_oracle_is_the_pinned_simulate_walk_on_other_draws(na
             return self._slot(wid, length, len(tab[0]))
     mine = ss.simulate_walks(order, nbr, w, 1.0, 1.0, rounds, L_, seed, draws=Draws())
     assert np.array_equal(mine, ref)
+
+
+def test_c_port_of_the_pinned_restatement_equals_it():
+    """oracle/snap_stream.c against oracle/snap_stream.py on every small case: walks token for token, embeddings to rounding of the exp
+    table (numpy's exp against libm's pow)."""
+    from oracle import snap_stream as ss
+    for name, c in _stream_cases().items():
+        order, nbr, w = ss.load_edge_list(c['edge_lines'], directed=True, weighted=True)
+        assert np.array_equal(ss.fast_walks(order, nbr, w, c['p'], c['q'], c['num_walks'], c['walk_len'], c['seed']), np.asarray(c['walks'], dtype=np.int32)), name
+        if c['epochs'] == 1:
+            ids, X = ss.fast_learn_embeddings(c['walks'], c['d'], c['window'], c['epochs'], c['seed'])
+            ids2, X2 = ss.learn_embeddings(c['walks'], c['d'], c['window'], c['epochs'], c['seed'])
+            assert ids == ids2 and np.abs(X - X2).max() <= 1e-9, name
+
+
+def test_pinned_restatement_reproduces_the_binary_at_the_reference_hyper_parameters():
+    """The reference's own SBM-1024 graph, walk_len 80, num_walks 10, con_size 10, p = q = 1 (examples/run_sbm.py:70) at d = 128:
+    819 200 words, 82 refreshes of alpha, both clamp branches of the sigmoid.  gem/c_exe/node2vec under the time() shim against
+    oracle/snap_stream.c: the 10 240 x 80 walk matrix bit for bit (SHA-256), the node order of the embedding file, and each of its
+    131 072 numbers to the six digits the binary prints."""
+    import hashlib
+    from oracle import snap_stream as ss
+    g = np.load(golden_path('n2v_snap_stream_sbm1024.npz'))
+    pr = json.loads(str(g['params']))
+    e = np.load(golden_path('sbm1024_edges.npy'))
+    order, nbr, w = ss.load_edge_list(['%d %d %f' % (int(i), int(j), 1.0) for i, j in e.tolist()], directed=True, weighted=True)
+    walks = ss.fast_walks(order, nbr, w, pr['p'], pr['q'], pr['num_walks'], pr['walk_len'], pr['seed'])
+    assert walks.shape == tuple(g['walks_shape']) and np.array_equal(walks[:4], g['walks_head'])
+    assert hashlib.sha256(walks.tobytes()).hexdigest() == str(g['walks_sha256'])
+    ids, X = ss.fast_learn_embeddings(walks, pr['d'], pr['window'], pr['epochs'], pr['seed'])
+    R = g['emb'].astype(np.float64)                                        # (stored as float32: 6e-8 on top of the file's 5e-6)
+    assert np.array_equal(ids, g['ids'])
+    assert np.all(np.abs(X - R) <= 5.7e-6 * np.abs(R) + 1e-12), float((np.abs(X - R) / np.abs(R)).max())
+    assert np.abs(R).max() > 0.5
