@@ -130,14 +130,18 @@ int snap_stream_walks(int64_t n, int64_t m, const int32_t *order, const int64_t 
 /* LearnEmbeddings on one thread.  walks[nwalks][walk_len]: raw ids in [0, id_bound) on entry, RENAMED ids on return.
  * ids_out[id_bound], emb_out[id_bound][d]: the first *n_out rows are the output file's rows, in its order.  Returns 0 / -1. */
 int snap_stream_learn_embeddings(int64_t nwalks, int32_t walk_len, int32_t *walks, int64_t id_bound, int32_t d, int32_t window,
-                                 int32_t iters, int32_t seed, int32_t *ids_out, double *emb_out, int64_t *n_out)
+                                 int32_t iters, int32_t seed, int32_t rename, int32_t *ids_out, double *emb_out, int64_t *n_out)
 {
+    /* rename = 1: the binary.  rename = 0 (an experiment, scripts/unigram_layout_effect.py): tokens keep their node ids, i.e. the
+     * vocabulary and with it the unigram alias table are laid out in node-id order -- the layout of oracle/n2v_oracle.c and of the HIP
+     * path.  Under RndUnigramInt's quirk the negative distribution depends on that layout. */
     enum { MAX_EXP = 6, PRECISION = 10000, TABLE = MAX_EXP * PRECISION * 2, NEG = 5 };
     const double start_alpha = 0.025;
     int32_t *rnm = (int32_t *)malloc(sizeof(int32_t) * (size_t)id_bound);
     if (!rnm) return -1;
     for (int64_t i = 0; i < id_bound; ++i) rnm[i] = -1;
     int64_t N = 0;
+    if (!rename) { for (int64_t i = 0; i < id_bound; ++i) { rnm[i] = (int32_t)i; ids_out[i] = (int32_t)i; } N = id_bound; }
     const int64_t all_words = nwalks * walk_len;
     for (int64_t i = 0; i < all_words; ++i) {
         const int32_t v = walks[i];

@@ -285,7 +285,7 @@ def _clib():
         L.snap_stream_walks.restype = C.c_int
         L.snap_stream_walks.argtypes = [C.c_int64, C.c_int64, i32p, i64p, i32p, f64p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, i32p]
         L.snap_stream_learn_embeddings.restype = C.c_int
-        L.snap_stream_learn_embeddings.argtypes = [C.c_int64, C.c_int32, i32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, f64p, i64p]
+        L.snap_stream_learn_embeddings.argtypes = [C.c_int64, C.c_int32, i32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, f64p, i64p]
         L._snap_stream_ready = True
     return L
 
@@ -315,8 +315,9 @@ def fast_walks(order, nbr, w, p, q, num_walks, walk_len, seed):
     return out
 
 
-def fast_learn_embeddings(walks, d, window, iters, seed):
-    """learn_embeddings through the C port (same arguments, same result)."""
+def fast_learn_embeddings(walks, d, window, iters, seed, rename=True):
+    """learn_embeddings through the C port (same arguments, same result).  rename=False: an experiment, not the binary -- tokens keep
+    their node ids, so the unigram alias table is laid out in node-id order (scripts/unigram_layout_effect.py)."""
     import ctypes as C
     wk = np.ascontiguousarray(walks, dtype=np.int32).copy()
     bound = int(wk.max()) + 1
@@ -324,7 +325,7 @@ def fast_learn_embeddings(walks, d, window, iters, seed):
     emb = np.zeros((bound, d), dtype=np.float64)
     n_out = C.c_int64()
     P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
-    rc = _clib().snap_stream_learn_embeddings(wk.shape[0], wk.shape[1], P(wk, C.c_int32), bound, d, window, iters, int(seed), P(ids, C.c_int32),
+    rc = _clib().snap_stream_learn_embeddings(wk.shape[0], wk.shape[1], P(wk, C.c_int32), bound, d, window, iters, int(seed), 1 if rename else 0, P(ids, C.c_int32),
                                               P(emb, C.c_double), C.byref(n_out))
     assert rc == 0
     return ids[:n_out.value].tolist(), emb[:n_out.value].copy()
