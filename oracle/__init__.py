@@ -1,4 +1,5 @@
-"""oracle -- TEST INFRASTRUCTURE.  CPU restatements of the reference algorithms.
+"""oracle -- TEST INFRASTRUCTURE.  CPU restatements of the reference algorithms (gf_oracle.c, hope_oracle.py, n2v_oracle.c; snap_stream.py / .c:
+the node2vec binary restated on its own random stream and pinned to its output).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package.  Nothing under gem_amd/ imports it (tests/test_layout.py checks).
@@ -13,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'liboracle.so')
 REF_GF = os.path.join(_HERE, '_ref', 'gf')
 REF_N2V = os.path.join(_HERE, '_ref', 'node2vec')
+REF_FAKETIME = os.path.join(_HERE, '_ref', 'libfaketime.so')      # shim/faketime.c: LD_PRELOAD it and REF_N2V is deterministic (snap_stream.py)
 _lib = None
 
 
@@ -23,7 +25,7 @@ def build(force=False):
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
         subprocess.check_call(['make', '-s', '-C', _HERE, '_build/liboracle.so'])
-    if os.path.exists('/root/reference/gem/c_src/gf.cpp') and not (os.path.exists(REF_GF) and os.path.exists(REF_N2V)):
+    if os.path.exists('/root/reference/gem/c_src/gf.cpp') and not (os.path.exists(REF_GF) and os.path.exists(REF_N2V) and os.path.exists(REF_FAKETIME)):
         subprocess.check_call(['make', '-s', '-C', _HERE, 'ref'])
     return LIB_PATH
 
