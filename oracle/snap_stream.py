@@ -142,7 +142,7 @@ def alias_draw_int(tab, rnd):
 def simulate_walks(order, nbr, w, p, q, num_walks, walk_len, seed, draws=None):
     """The walk matrix [num_walks * N][walk_len] (int32, zero padded) node2vec() hands to LearnEmbeddings.
     draws=None: the binary's TRnd stream.  Otherwise an object supplying the three random decisions -- round_order(r, ids) -> start
-    nodes of round r, first_hop(walk, deg) -> neighbour index, alias_draw(walk, length, (K, U)) -> neighbour index -- so that the SAME
+    nodes of round r, first_hop(walk, deg) -> neighbour index, alias_draw(walk, length, (K, U), current node) -> neighbour index -- so that the SAME
     body runs on the counter-based draws of oracle/n2v_oracle.c (tests/test_oracle_n2v.py ties that file's walks to this one)."""
     tables = preprocess_transition_probs(order, nbr, w, float(p), float(q))
     rnd = TRnd(seed) if draws is None else None
@@ -164,7 +164,7 @@ def simulate_walks(order, nbr, w, p, q, num_walks, walk_len, seed, draws=None):
                     if not nbr[dst]:
                         break
                     tab = tables[(src, dst)]
-                    wk.append(nbr[dst][alias_draw_int(tab, rnd) if draws is None else draws.alias_draw(wid, len(wk), tab)])
+                    wk.append(nbr[dst][alias_draw_int(tab, rnd) if draws is None else draws.alias_draw(wid, len(wk), tab, dst)])
             out[wid, :len(wk)] = wk
     return out
 

@@ -311,9 +311,49 @@ def test_counter_based_walk_oracle_is_the_pinned_simulate_walk_on_other_draws(na
         def first_hop(self, wid, deg):
             return self._slot(wid, 1, deg)
 
-        def alias_draw(self, wid, length, tab):
+        def alias_draw(self, wid, length, tab, dst):
             assert all(abs(u - 1.0) < 1e-12 for u in tab[1])              # unweighted, p = q = 1: every slot accepts
             return self._slot(wid, length, len(tab[0]))
+    mine = ss.simulate_walks(order, nbr, w, 1.0, 1.0, rounds, L_, seed, draws=Draws())
+    assert np.array_equal(mine, ref)
+
+
+def test_counter_based_weighted_walks_are_the_pinned_body_on_other_draws():
+    """The same tie on a WEIGHTED graph at p = q = 1: uniform first hop (SimulateWalk ignores the weights there), then slot / accept / alias
+    against the first-order table of the current node -- n2v_oracle.c's fp32 per-row tables stand in for the binary's per-pair tables, which
+    at p = q = 1 encode the same row distribution (equal alias targets for generic weights: test above; with small-integer weights some U
+    land exactly on 1 and the two precisions may stack them differently -- another valid table of the same distribution)."""
+    from oracle import snap_stream as ss
+    c = _stream_cases()['karate_weighted_p0.5_q2']
+    order, nbr, w = ss.load_edge_list(c['edge_lines'], directed=True, weighted=True)
+    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
+    wt = np.array([float(ln.split()[2]) for ln in c['edge_lines']], dtype=np.float32)
+    n, seed, rounds, L_ = int(e.max()) + 1, 777, 4, 16
+    row_ptr, col, ww = oracle.sorted_csr(n, e[:, 0], e[:, 1], wt)
+    U, K = oracle.n2v_alias_rows(row_ptr, ww)
+    ref = oracle.n2v_walks(row_ptr, col, U, K, 1.0, 1.0, rounds, L_, seed, SNAP)
+    lib = oracle.lib()
+    start = oracle.start_nodes(row_ptr, col)
+    m = len(start)
+    buf = (C.c_uint32 * 4)()
+
+    class Draws(object):
+        def round_order(self, r, ids):
+            key = seed ^ (((r + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+            return [int(start[lib.oracle_perm(j, m, C.c_uint64(key))]) for j in range(m)]
+
+        def _draw(self, wid, length):
+            lib.oracle_philox(C.c_uint64(seed), C.c_uint32(wid), C.c_uint32(0), C.c_uint32(length), C.c_uint32(1), buf)
+            return buf[0], buf[1]
+
+        def first_hop(self, wid, deg):
+            return (self._draw(wid, 1)[0] * deg) >> 32
+
+        def alias_draw(self, wid, length, tab, dst):
+            a, deg = int(row_ptr[dst]), len(tab[0])
+            x, y = self._draw(wid, length)
+            slot = (x * deg) >> 32
+            return slot if np.float32(y >> 8) * np.float32(1.0 / 16777216.0) < U[a + slot] else int(K[a + slot])
     mine = ss.simulate_walks(order, nbr, w, 1.0, 1.0, rounds, L_, seed, draws=Draws())
     assert np.array_equal(mine, ref)
 
