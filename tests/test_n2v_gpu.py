@@ -112,6 +112,29 @@ def test_karate_walks_with_sinks_bit_exact(karate):
     dev.close()
 
 
+@pytest.mark.parametrize('name', ['karate_p1_q1', 'directed_with_sinks_p1_q1'])
+def test_hip_kernels_equal_the_bodies_pinned_to_the_reference_binary(name):
+    """The chain reference binary -> restatement -> kernels closed ON THE DEVICE.  oracle/snap_stream.py reproduces gem/c_exe/node2vec (run
+    under a fixed time()) walk for walk and number for number (tests/test_oracle_n2v.py); its walk body and its TrainModel body, fed with the
+    kernels' counter-based draws (helpers of that test file: the CPU tier checks them against n2v_oracle.c), must give what the HIP walk kernel
+    writes -- bit for bit, sinks and zero padding included -- and what the deterministic SGNS launch trains -- fp32 against fp64: 2e-4."""
+    from test_oracle_n2v import _stream_cases, pinned_sgns_on_kernel_draws, pinned_walks_on_kernel_draws
+    c = _stream_cases()[name]
+    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
+    n, seed, rounds, l, d, window = int(e.max()) + 1, 424242, 3, 14, 8, 3
+    dev = Dev(n, e[:, 0].astype(np.int32), e[:, 1].astype(np.int32), None)
+    walks = dev.walks(1.0, 1.0, rounds, l, seed, SNAP)
+    assert np.array_equal(walks, pinned_walks_on_kernel_draws(c['edge_lines'], seed, rounds, l))
+    if 'sinks' not in name:          # (the SGNS leg runs on the graph without padded walks; written without a GPU at hand, it stays on ground the
+        _, UT, KT = dev.unigram()    #  deterministic launch has been compared with n2v_oracle.c on before: test_sgns_deterministic_matches_oracle)
+        P, N = dev.sgns(d, window, 1, seed, SNAP | 4)
+        P64, N64 = pinned_sgns_on_kernel_draws(walks, n, d, window, seed, UT, KT)
+        for got, want in ((P, P64), (N, N64)):
+            scale = float(np.abs(want).max())
+            assert float(np.abs(got - want).max()) <= 2e-4 * scale + 1e-6, (np.abs(got - want).max(), scale)
+    dev.close()
+
+
 @pytest.mark.parametrize('gname,d,window,l,epochs,flags', [('karate', 2, 10, 80, 1, SNAP), ('karate', 8, 3, 20, 2, 8),
                                                            ('sbm1024', 16, 10, 40, 1, SNAP), ('sbm1024', 128, 5, 24, 1, SNAP),
                                                            ('karate', 7, 4, 30, 1, SNAP), ('karate', 256, 2, 10, 1, SNAP)])

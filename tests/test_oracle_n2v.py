@@ -248,20 +248,13 @@ def test_snap_stream_restatement_reproduces_the_embedding_file_the_reference_bin
     assert np.abs(R).max() > 0.1                                  # (the run did train: rows moved far from their +-1/16 initial range)
 
 
-def test_counter_based_sgns_oracle_is_the_pinned_train_model_on_other_draws():
-    """oracle_sgns_train (fp32, Philox draws; what the deterministic HIP launch is compared with) against snap_stream.train_model -- the
-    body that reproduces the binary's output -- fed with the SAME Philox draws: same window shrinks, same negative targets (incl.
-    RndUnigramInt's quirk), same update order; what remains is fp32 against fp64 and the exact sigmoid against ... the exact sigmoid."""
+def pinned_sgns_on_kernel_draws(walks, n, d, window, seed, UT, KT):
+    """snap_stream.train_model -- the TrainModel body that reproduces the binary -- in fp64 with the exact sigmoid, fed with the COUNTER-BASED
+    draws of n2v_oracle.c / the HIP kernels (Philox: window shrink from (walk, pos), negatives from (walk, pos, slot, sample), SNAP's
+    RndUnigramInt quirk on the fp32 unigram table given) from the initial tables every implementation draws for `seed`.  Returns (SynPos, SynNeg)."""
     from oracle import snap_stream as ss
-    c = _stream_cases()['karate_p1_q1']
-    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
-    n, d, window, seed = int(e.max()) + 1, 8, 3, 12345
-    row_ptr, col, _ = oracle.sorted_csr(n, e[:, 0], e[:, 1], None)
-    walks = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, 3, 12, seed, SNAP)
-    UT, KT = oracle.unigram_build(oracle.n2v_vocab(n, walks))
-    P, N = oracle.sgns_init(n, d, seed)
-    P64, N64 = P.astype(np.float64), N.astype(np.float64)
-    oracle.sgns_train(walks, window, 0.025, 1, 0, walks.size, 0, 0, UT, KT, seed, SNAP, P, N)
+    P0, N0 = oracle.sgns_init(n, d, seed)
+    P64, N64 = P0.astype(np.float64), N0.astype(np.float64)
     L = oracle.lib()
     buf = (C.c_uint32 * 4)()
 
@@ -276,23 +269,36 @@ def test_counter_based_sgns_oracle_is_the_pinned_train_model_on_other_draws():
         x, y = philox(wi, 0, pos | (a << 16), 3 | (j << 16))          # TAG_NEG, epoch 0
         X = int(KT[(x * n) >> 32])                                    # SNAP's quirk: the alias of the slot
         return X if np.float32(y >> 8) * np.float32(1.0 / 16777216.0) < UT[X] else int(KT[X])
-    ss.train_model(walks.astype(np.int64), P64, N64, window, 1, offset_draw, negative_draw, sigmoid='exact')
+    ss.train_model(np.asarray(walks, dtype=np.int64), P64, N64, window, 1, offset_draw, negative_draw, sigmoid='exact')
+    return P64, N64
+
+
+def test_counter_based_sgns_oracle_is_the_pinned_train_model_on_other_draws():
+    """oracle_sgns_train (fp32, Philox draws; what the deterministic HIP launch is compared with) against snap_stream.train_model -- the
+    body that reproduces the binary's output -- fed with the SAME Philox draws: same window shrinks, same negative targets (incl.
+    RndUnigramInt's quirk), same update order; what remains is fp32 against fp64.  (tests/test_n2v_gpu.py runs the same comparison
+    with the HIP kernels in the oracle's place.)"""
+    c = _stream_cases()['karate_p1_q1']
+    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
+    n, d, window, seed = int(e.max()) + 1, 8, 3, 12345
+    row_ptr, col, _ = oracle.sorted_csr(n, e[:, 0], e[:, 1], None)
+    walks = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, 3, 12, seed, SNAP)
+    UT, KT = oracle.unigram_build(oracle.n2v_vocab(n, walks))
+    P, N = oracle.sgns_init(n, d, seed)
+    oracle.sgns_train(walks, window, 0.025, 1, 0, walks.size, 0, 0, UT, KT, seed, SNAP, P, N)
+    P64, N64 = pinned_sgns_on_kernel_draws(walks, n, d, window, seed, UT, KT)
     assert np.abs(P - P64).max() <= 2e-5 * np.abs(P64).max() and np.abs(N - N64).max() <= 2e-5 * np.abs(N64).max()
     assert np.abs(P64).max() > 0.1
 
 
-@pytest.mark.parametrize('name', ['karate_p1_q1', 'directed_with_sinks_p1_q1'])
-def test_counter_based_walk_oracle_is_the_pinned_simulate_walk_on_other_draws(name):
-    """oracle_n2v_walks (what the HIP walk kernel equals bit for bit) against snap_stream.simulate_walks -- the body that reproduces the
-    binary's walks -- fed with the SAME Philox draws and the same Feistel start permutation, first-order unweighted case (the headline's):
-    identical matrices, sinks and zero padding included."""
+def pinned_walks_on_kernel_draws(edge_lines, seed, rounds, walk_len):
+    """snap_stream.simulate_walks -- the walk body that reproduces the binary -- fed with the COUNTER-BASED draws of n2v_oracle.c / the HIP walk
+    kernel (Feistel start permutation per round, Philox (walk, length) for the neighbour slot), first-order unweighted case.  Returns the matrix."""
     from oracle import snap_stream as ss
-    c = _stream_cases()[name]
-    order, nbr, w = ss.load_edge_list(c['edge_lines'], directed=True, weighted=True)
-    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
-    n, seed, rounds, L_ = int(e.max()) + 1, 424242, 3, 14
+    order, nbr, w = ss.load_edge_list(edge_lines, directed=True, weighted=True)
+    e = np.array([[int(f) for f in ln.split()[:2]] for ln in edge_lines])
+    n = int(e.max()) + 1
     row_ptr, col, _ = oracle.sorted_csr(n, e[:, 0], e[:, 1], None)
-    ref = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, rounds, L_, seed, SNAP)
     lib = oracle.lib()
     start = oracle.start_nodes(row_ptr, col)
     m = len(start)
@@ -314,8 +320,20 @@ def test_counter_based_walk_oracle_is_the_pinned_simulate_walk_on_other_draws(na
         def alias_draw(self, wid, length, tab, dst):
             assert all(abs(u - 1.0) < 1e-12 for u in tab[1])              # unweighted, p = q = 1: every slot accepts
             return self._slot(wid, length, len(tab[0]))
-    mine = ss.simulate_walks(order, nbr, w, 1.0, 1.0, rounds, L_, seed, draws=Draws())
-    assert np.array_equal(mine, ref)
+    return ss.simulate_walks(order, nbr, w, 1.0, 1.0, rounds, walk_len, seed, draws=Draws())
+
+
+@pytest.mark.parametrize('name', ['karate_p1_q1', 'directed_with_sinks_p1_q1'])
+def test_counter_based_walk_oracle_is_the_pinned_simulate_walk_on_other_draws(name):
+    """oracle_n2v_walks (what the HIP walk kernel equals bit for bit) against snap_stream.simulate_walks -- the body that reproduces the
+    binary's walks -- fed with the SAME Philox draws and the same Feistel start permutation, first-order unweighted case (the headline's):
+    identical matrices, sinks and zero padding included.  (tests/test_n2v_gpu.py runs the same comparison with the HIP kernel itself.)"""
+    c = _stream_cases()[name]
+    e = np.array([[int(f) for f in ln.split()[:2]] for ln in c['edge_lines']])
+    n, seed, rounds, L_ = int(e.max()) + 1, 424242, 3, 14
+    row_ptr, col, _ = oracle.sorted_csr(n, e[:, 0], e[:, 1], None)
+    ref = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, rounds, L_, seed, SNAP)
+    assert np.array_equal(pinned_walks_on_kernel_draws(c['edge_lines'], seed, rounds, L_), ref)
 
 
 def test_counter_based_weighted_walks_are_the_pinned_body_on_other_draws():
