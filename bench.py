@@ -111,14 +111,17 @@ class GFWorkload(object):
         Xb = Xa.clone()
         r0, r1 = rank * (n_pad // world), min((rank + 1) * (n_pad // world), n)
         self.b = multi_gpu.HipBackendGF(n, src, dst, None, self.d, r0, r1, Xa, Xb)
-        # N>1: halo exchange after every `--gf-exchange-every`-th sweep (default 8: a 0.6 ms sweep cannot pay a ~1 ms exchange each time;
-        # other ranks' rows are then up to 7 sweeps stale -- block-Jacobi with delay; 1 = bit-identical to one GPU), one gather at the end
+        # N>1: halo exchange after EVERY sweep by default (bit-identical to one GPU: gf.py:93-100's Gauss-Seidel order); `--gf-exchange-every s`
+        # (s > 1) is an opt-in that trades parity for speed -- other ranks' rows are then up to s-1 sweeps stale (block-Jacobi with delay,
+        # SURVEY 8e "or every s sweeps") -- and `quality` then carries the deviation from the single-GPU result; one gather at the end
         self.exchange_every = args.gf_exchange_every if world > 1 else 1
+        self.rank, self.sweeps_done, self.X_init = rank, 0, (Xa[:n].clone() if world > 1 else None)
         self.job = multi_gpu.GFSharded(self.b, comm, rank, world, n, src, dst, exchange_every=self.exchange_every)
         self.kernel_ms, self.launches = 0.0, 0
         log('[rank %d] GF plan: rows %d updates %d levels %d' % (rank, self.b.rows, self.b.updates, self.b.levels))
 
     def step(self):
+        self.sweeps_done += 1
         if self.world > 1:
             self.last = self.job.sweep(self.eta, self.regu)
             return
@@ -147,18 +150,25 @@ class GFWorkload(object):
         avg_s = dev_ms_total * 1e-3 / launches
         algo = self.b.algo_bytes / self.b.levels        # 1548 B x updates
         compulsory = (self.b.rows * 2 * 4 * self.d + self.b.updates * (4 * self.d + 8)) / self.b.levels
-        ach = algo / avg_s / 1e9
+        ach = compulsory / avg_s / 1e9
         per_upd, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_update')
         traffic = None if per_upd is None else per_upd * self.b.updates / self.b.levels
-        return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': traffic, 'traffic_source': tsrc, 'achieved_traffic_GBs': None if traffic is None else traffic / avg_s / 1e9,
-                'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
-                # `frac` follows the contract (SURVEY 8d bytes per update x updates) and exceeds 1 because the kernel keeps X_i in registers for a
-                # whole row; the figure to judge the kernel by is the compulsory one: every touched row read and written once, X_j read per update
-                'compulsory_bytes_per_launch': compulsory, 'achieved_compulsory_GBs': compulsory / avg_s / 1e9,
-                'frac_compulsory': compulsory / avg_s / 1e9 / HBM_PEAK_GBS,
-                'note': 'algorithmic = 1548 B/update (X_i r+w, X_j r per update); the kernel keeps X_i in registers for a whole row, '
-                        'so its compulsory HBM bytes are %.3g per launch = %.0f GB/s (frac_compulsory)' % (compulsory, compulsory / avg_s / 1e9)}
+        n = self.graph[0]
+        table_mb = n * self.d * 4 / 1e6
+        out = {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+               'traffic': traffic, 'traffic_source': tsrc, 'achieved_traffic_GBs': None if traffic is None else traffic / avg_s / 1e9,
+               'achieved_traffic_frac': None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
+               'algorithmic_bytes_per_launch': compulsory, 'avg_launch_us': avg_s * 1e6,
+               # SURVEY 8d's 1548 B per update charges X_i read + write to every edge; the kernel keeps X_i in registers for a whole row, so that figure
+               # is NOT what a launch has to move (it gave "fractions" above 1 in rounds 1-3).  It stays as a rate comparable with the CPU loop's bytes.
+               'comparability_bytes_per_launch': algo, 'comparability_GBs': algo / avg_s / 1e9,
+               'note': '`achieved`/`frac` = compulsory bytes (every touched row read and written once + X_j and (j, w) read per update: rows x 8d + updates x '
+                       '(4d + 8)) / launch time / 8 TB/s; comparability_GBs = SURVEY 8d\'s 1548 B per update x updates (X_i charged per edge: a reuse '
+                       'factor of %.2f over the compulsory bytes, not a bandwidth)' % (algo / compulsory)}
+        if table_mb * 2 <= 32.0:
+            out['regime'] = ('launch-bound, not HBM-bound: both table copies (%.1f MB) stay in the 32 MB of L2 and a sweep is one %.1f us launch; the '
+                             'HBM fraction above only says how far from an HBM-sized problem this configuration is' % (2 * table_mb, avg_s * 1e6))
+        return out
 
     def cpu_baseline(self, budget_s=15.0):
         """(ii) the reference's own native path -- oracle/_ref/gf = g++ -O2 of gem/c_src/gf.cpp, run the way gf.py:55-72
@@ -228,6 +238,38 @@ class GFWorkload(object):
 
     def check(self):
         assert bool(torch.isfinite(self.last).all()), 'non-finite embedding'
+
+    def quality(self):
+        """N>1 (outside the timed region, rank 0): the sharded table against the SAME number of sweeps on one GPU from the same initial table.
+        exchange_every = 1 must reproduce it bit for bit; s > 1 reports what the stale halo cost."""
+        if self.world == 1 or self.rank != 0:
+            return None
+        n, src, dst, w = self.graph
+        Xa = torch.zeros_like(self.b.X[0]); Xa[:n].copy_(self.X_init); Xb = Xa.clone()
+        ref = multi_gpu.HipBackendGF(n, src, dst, None, self.d, 0, n, Xa, Xb)
+        R = ref.sweeps(self.sweeps_done, self.eta, self.regu)[:n]
+        torch.cuda.synchronize()
+        got = self.last[:n]
+        dev = float((got - R).abs().max())
+        moved = float((R - self.X_init).abs().max())
+        ref.close()
+        return {'sweeps': self.sweeps_done, 'exchange_every_sweeps': self.exchange_every, 'bit_identical_to_one_gpu': bool(torch.equal(got, R)),
+                'max_abs_deviation_from_one_gpu': dev, 'largest_change_of_the_run': moved,
+                'deviation_relative_to_largest_change': dev / moved if moved > 0 else 0.0}
+
+    def api_wall(self):
+        """`GraphFactorization.learn_embedding` end to end, numpy in / numpy out (gf.py:81-101 equivalent: edge arrays from the graph
+        object, numpy's 0.01*randn table, H2D, max_iter sweeps, D2H, float64 copy) -- outside the timed region."""
+        from gem_amd.embedding.gf import GraphFactorization
+        n = self.graph[0]
+        iters = 1000 if n <= 100000 else 100
+        m = GraphFactorization(d=self.d, eta=self.eta, regu=self.regu, max_iter=iters, seed=5)
+        m.learn_embedding(graph=make_graph(self.args), is_weighted=True, no_python=True)
+        out = dict(m._api_wall)
+        out.update({'max_iter': iters, 'edges_per_s_api': self.n_edges * iters / out['seconds'],
+                    'what': 'gem_amd.embedding.gf.GraphFactorization(d=%d, max_iter=%d).learn_embedding(graph) wall, numpy in / float64 numpy out; '
+                            'ingest_s includes numpy randn of the %d x %d initial table (gf.py:92)' % (self.d, iters, n, self.d)})
+        return out
 
 
 class N2VWorkload(object):
@@ -300,6 +342,19 @@ class N2VWorkload(object):
                 'note': 'algorithmic = 7168+24 B per (centre,context) pair at d=128 (SynPos r+w, 6 x SynNeg r+w); the kernel keeps the '
                         'positive SynNeg row in registers across a centre\'s contexts (12/14 of that reaches memory)'}
 
+    def api_wall(self):
+        """`node2vec.learn_embedding` end to end, numpy in / numpy out (node2vec.py:27-54 equivalent: graph object -> CSR, H2D,
+        walks + vocabulary + unigram table + SGNS, D2H of SynPos, the float64 array loadEmbedding returns) -- one extra pass outside the timed region."""
+        from gem_amd.embedding.node2vec import node2vec
+        a = self.args
+        m = node2vec(d=a.d, max_iter=1, walk_len=a.walk_len, num_walks=a.num_walks, con_size=a.window, ret_p=a.ret_p, inout_p=a.inout_q, seed=20260923)
+        m.learn_embedding(graph=self.g, is_weighted=True, no_python=True)
+        out = dict(m._api_wall)
+        out.update({'edges_per_s_api': self.n_edges / out['seconds'],
+                    'what': 'gem_amd.embedding.node2vec.node2vec(...).learn_embedding(graph) wall on the benchmark graph, numpy in / float64 numpy out '
+                            '(the timed `value` starts with the CSR in HBM and leaves SynPos there)'})
+        return out
+
     def launch_plan(self):
         """What gemhip_sgns_train chose for this corpus (the rule of DESIGN.md 3.3, recomputed from the token counts by gemhip_sgns_plan_launch;
         environment overrides of the knobs are not reflected)."""
@@ -334,8 +389,10 @@ class N2VWorkload(object):
         if os.path.exists(oracle.REF_N2V):
             tmp = tempfile.mkdtemp()
             gf = os.path.join(tmp, 'g.graph')
-            with open(gf, 'w') as fh:
+            t = time.time()
+            with open(gf, 'w') as fh:            # saveGraphToEdgeListTxtn2v (graph_util.py:137-140): "%d %d %f" per edge
                 fh.writelines('%d %d %f\n' % (i, j, 1.0) for i, j in zip(gs.src.tolist(), gs.dst.tolist()))
+            t_write = time.time() - t
             runs = {}
             for thr in (cores, 1):
                 emb = os.path.join(tmp, 'g%d.emb' % thr)
@@ -344,14 +401,19 @@ class N2VWorkload(object):
                                  '-r:%d' % a.num_walks, '-k:%d' % a.window, '-e:1', '-p:1.000000', '-q:1.000000', '-dr', '-w'],
                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS=str(thr)))
                 el = time.time() - t
+                t = time.time()
                 X = np.zeros((n_s, a.d))
-                with open(emb) as fh:
+                with open(emb) as fh:            # loadEmbedding (graph_util.py:161-169)
                     fh.readline()
                     for line in fh:
                         tok = line.split()
                         X[int(tok[0])] = [float(v) for v in tok[1:]]
+                t_load = time.time() - t
                 runs[thr] = {'edges_per_s': gs.number_of_edges() / el, 'seconds': el, 'threads': thr,
-                             'MAP': gr.evaluateStaticGraphReconstruction(gs, model, X, None)[0]}
+                             'MAP': gr.evaluateStaticGraphReconstruction(gs, model, X, None)[0],
+                             # node2vec.py:27-54 as a whole: edge-list text dump + the binary (its own text IO inside) + loadEmbedding
+                             'api_wall': {'seconds': t_write + el + t_load, 'graph_text_write_s': t_write, 'binary_s': el, 'load_embedding_s': t_load,
+                                          'edges_per_s_api': gs.number_of_edges() / (t_write + el + t_load)}}
             import shutil
             shutil.rmtree(tmp, ignore_errors=True)
             # the HIP path on the very same sample graph (outside every timed region): the MAP the baselines are to be compared with
@@ -543,6 +605,21 @@ class HopeWorkload(object):
                           'the same sample agrees to max |sigma/sigma_cpu - 1| = %.1e'
                           % (a.d // 2, n_s, gs.number_of_edges(), el, self.n, rel)}
 
+    def api_wall(self):
+        """`HOPE.learn_embedding` end to end, numpy in / numpy out (hope.py:23-41 equivalent), outside the timed region."""
+        from gem_amd.embedding.hope import HOPE
+        g = make_graph(self.args)
+        if self.directed:
+            from gem_amd.graph import orient_randomly
+            g = orient_randomly(g, 1)
+        m = HOPE(d=self.args.d, beta=0.01)
+        m.learn_embedding(graph=g, is_weighted=True, no_python=True)
+        out = dict(m._api_wall)
+        out.update({'embeddings_per_s_api': self.n / out['seconds'],
+                    'what': 'gem_amd.embedding.hope.HOPE(d=%d, beta=0.01).learn_embedding(graph) wall, numpy in / float64 numpy out; host_prepare_s = the plan '
+                            '(transpose, symmetry test, uploads, spectral-radius estimate), kernels_s = the solve' % self.args.d})
+        return out
+
     def check(self):
         assert bool(torch.isfinite(self.dU).all()) and np.all(np.diff(self.sig) >= 0) and self.sig[0] > 0
 
@@ -600,9 +677,13 @@ def time_workload(name, args, rank, world, comm, K=None, W=None, with_cpu=True):
         if hasattr(wl, 'phase_split'):
             out['phases'] = wl.phase_split(K)
     if hasattr(wl, 'quality'):
-        out['quality'] = wl.quality()
+        q = wl.quality()
+        if q is not None:
+            out['quality'] = q
     if world == 1:
         out['roofline'] = wl.roofline(dev_ms, K)
+        if hasattr(wl, 'api_wall') and not getattr(args, 'no_api_wall', False):
+            out['api_wall'] = wl.api_wall()
         if with_cpu:
             out['cpu_baseline'] = wl.cpu_baseline()
     return out, wl
@@ -627,10 +708,12 @@ def main():
     ap.add_argument('--inout-q', type=float, default=1.0, help='node2vec in-out parameter q (node2vec.py:41 -q:)')
     ap.add_argument('--gf-eta', type=float, default=1e-2)
     ap.add_argument('--gf-regu', type=float, default=1e-2)
-    ap.add_argument('--gf-exchange-every', type=int, default=8, help='N>1 GF: sweeps between halo exchanges (1 = exchange after every sweep: bit-identical to one GPU)')
+    ap.add_argument('--gf-exchange-every', type=int, default=1, help='N>1 GF: sweeps between halo exchanges (default 1 = after every sweep: bit-identical to one GPU; '
+                    's > 1 is NOT the single-GPU algorithm: rows of other ranks are up to s-1 sweeps stale, `quality` reports the deviation)')
     ap.add_argument('--hope-directed', action='store_true', help='hope: orient every undirected edge in one random direction (A != A^T: the general case of hope.py)')
     ap.add_argument('--episodes', type=int, default=64, help='N>1 node2vec: episodes of the partitioned schedule')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-api-wall', action='store_true', help='skip the extra learn_embedding() pass that fills `api_wall` (outside the timed region)')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():

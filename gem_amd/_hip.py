@@ -34,6 +34,7 @@ _SIGS = {
     'gemhip_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'gemhip_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'gemhip_synchronize': (C.c_int, [C.c_void_p]),
+    'gemhip_last_call_phases': (C.c_int, [f64p]),
     'gemhip_gf_train': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_int32,
                                   f32p, f64p]),
     'gemhip_gf_plan_create': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_int64, C.c_int64,
@@ -192,3 +193,19 @@ def warn_if_unconverged(stats, tol, max_restarts, what):
         warnings.warn('%s: not converged after %d restarts (last relative change of the wanted values %.2e >= tol %.1e, Ritz residual %.2e); '
                       'raise max_restarts or tol' % (what, int(stats['restarts']), stats['last_sigma_change'], tol, stats.get('ritz_residual', float('nan'))),
                       RuntimeWarning, stacklevel=3)
+
+
+def last_call_phases():
+    """{total, host_prepare, h2d, kernels, d2h} seconds of the last one-shot library call on this thread (gemhip_last_call_phases)."""
+    out = (C.c_double * 8)()
+    check(lib().gemhip_last_call_phases(out))
+    return {'library_call_s': out[0], 'host_prepare_s': out[1], 'h2d_s': out[2], 'kernels_s': out[3], 'd2h_s': out[4]}
+
+
+def api_wall(t_begin, t_ingested, t_called, t_end):
+    """SURVEY 8(d) "API wall" of one learn_embedding(): time.perf_counter() stamps at entry, after the graph became arrays (ingest),
+    after the library call, at return (float64 copy done) -> the breakdown bench.py prints as `api_wall`."""
+    ph = last_call_phases()
+    return {'seconds': t_end - t_begin, 'ingest_s': t_ingested - t_begin, 'host_prepare_s': ph['host_prepare_s'], 'h2d_s': ph['h2d_s'],
+            'kernels_s': ph['kernels_s'], 'd2h_s': ph['d2h_s'], 'd2h_float64_s': ph['d2h_s'] + (t_end - t_called),
+            'float64_copy_s': t_end - t_called, 'library_call_s': t_called - t_ingested}

@@ -28,6 +28,18 @@ int fail(int code, const char *fmt, ...);
             return ::gemhip::fail(GEMHIP_E_INVALID, __VA_ARGS__);  \
     } while (0)
 
+// ---------------------------------------------------------------- where a one-shot call's wall time went (gemhip_last_call_phases)
+// Thread-local accumulators the one-shot entry points (gemhip_gf_train, gemhip_n2v_train, gemhip_hope) reset on entry; the staged calls they
+// are made of add host-side preparation (sorting, Vose tables), host->device and device->host copy time to them.  Wall-clock, host side.
+enum { PH_TOTAL = 0, PH_HOST = 1, PH_H2D = 2, PH_KERNELS = 3, PH_D2H = 4, PH_COUNT = 8 };
+double *phase_acc();
+double phase_now();
+struct PhaseScope {
+    int k; double t0;
+    explicit PhaseScope(int kk) : k(kk), t0(phase_now()) {}
+    ~PhaseScope() { phase_acc()[k] += phase_now() - t0; }
+};
+
 constexpr int WAVE = 64;          // CDNA wavefront
 constexpr int NUM_XCD = 8;        // MI355X: 8 XCDs, block b lands on XCD b % 8
 

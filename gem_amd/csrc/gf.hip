@@ -377,6 +377,7 @@ extern "C" int gemhip_gf_plan_create(int64_t n, int64_t m, const int32_t *src, c
     GEMHIP_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n, "gf_plan_create: bad row range");
 
     // 1. rows in the order the reference first visits them; keep only firing edges (dst > src) of owned rows.
+    const double t_host0 = phase_now();
     std::vector<int32_t> pos(n, -1);          // pos[i] = rank of row i among firing source rows (reference order)
     std::vector<int32_t> order;               // row ids by pos
     std::vector<int64_t> deg;
@@ -476,6 +477,8 @@ extern "C" int gemhip_gf_plan_create(int64_t n, int64_t m, const int32_t *src, c
     p->level_off.assign(lvl_cnt.begin(), lvl_cnt.end());
     p->level_hubs = level_hubs;
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail(GEMHIP_E_HIP, "gf_plan_create: no HIP device"); }
+    phase_acc()[PH_HOST] += phase_now() - t_host0;
+    PhaseScope ph_up(PH_H2D);
     auto up = [&](void **dp, const void *hp, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dp, bytes ? bytes : 16);
         if (e != hipSuccess) return e;
@@ -527,6 +530,7 @@ extern "C" int gemhip_gf_plan_set_embedding(gemhip_gf_plan_t p, const float *X_h
     GEMHIP_REQUIRE(p && X_host, "gf_plan_set_embedding: NULL argument");
     if (int rc = ensure_tables(p)) return rc;
     const size_t bytes = (size_t)p->n * p->d * sizeof(float);
+    PhaseScope ph(PH_H2D);
     GEMHIP_CHECK(hipMemcpy(p->X[0], X_host, bytes, hipMemcpyHostToDevice));
     GEMHIP_CHECK(hipMemcpy(p->X[1], p->X[0], bytes, hipMemcpyDeviceToDevice));
     p->cur = 0;
@@ -584,6 +588,7 @@ extern "C" int gemhip_gf_plan_get_embedding(gemhip_gf_plan_t p, float *X_host)
 {
     GEMHIP_REQUIRE(p && X_host && p->X[0], "gf_plan_get_embedding: bad arguments");
     GEMHIP_CHECK(hipDeviceSynchronize());
+    PhaseScope ph(PH_D2H);
     GEMHIP_CHECK(hipMemcpy(X_host, p->X[p->cur], (size_t)p->n * p->d * sizeof(float), hipMemcpyDeviceToHost));
     return GEMHIP_OK;
 }
@@ -610,6 +615,8 @@ extern "C" int gemhip_gf_train(int64_t n, int64_t m, const int32_t *src, const i
 {
     GEMHIP_REQUIRE(X_inout != nullptr, "gf_train: X_inout is NULL");
     GEMHIP_REQUIRE(max_iter >= 0, "gf_train: max_iter=%d", max_iter);
+    for (int k = 0; k < PH_COUNT; ++k) phase_acc()[k] = 0.0;
+    const double t_call = phase_now();
     gemhip_gf_plan_t p = nullptr;
     int rc = gemhip_gf_plan_create(n, m, src, dst, w, d, 0, n, &p);
     if (rc) return rc;
@@ -624,6 +631,7 @@ extern "C" int gemhip_gf_train(int64_t n, int64_t m, const int32_t *src, const i
     }
     if (!rc) rc = gemhip_gf_plan_get_embedding(p, X_inout);
     if (!rc) hipEventElapsedTime(&ms, t0, t1);
+    phase_acc()[PH_KERNELS] = ms * 1e-3;
     if (stats && !rc) {
         stats[0] = ms * 1e-3; stats[1] = (double)p->nupd; stats[2] = (double)p->nrows;
         stats[3] = (double)(p->level_off.size() - 1);
@@ -631,6 +639,7 @@ extern "C" int gemhip_gf_train(int64_t n, int64_t m, const int32_t *src, const i
     if (t0) hipEventDestroy(t0);
     if (t1) hipEventDestroy(t1);
     gemhip_gf_plan_destroy(p);
+    phase_acc()[PH_TOTAL] = phase_now() - t_call;
     return rc;
 }
 

@@ -668,6 +668,7 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     GEMHIP_REQUIRE(row_ptr[0] == 0 && row_ptr[n] == nnz, "n2v_create: row_ptr[0]=%lld row_ptr[n]=%lld nnz=%lld",
                    (long long)row_ptr[0], (long long)row_ptr[n], (long long)nnz);
     // sort columns inside each row (needed by the has_edge test of the 2nd-order walk); weights follow
+    const double t_host0 = phase_now();
     std::vector<int32_t> c(col, col + nnz);
     std::vector<float> ww;
     if (w) ww.assign(w, w + nnz);
@@ -708,6 +709,8 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     if (const char *e = getenv("GEMHIP_SGNS_RELOAD")) h->kn.reload = atoi(e) != 0;
     if (const char *e = getenv("GEMHIP_SGNS_HOT_COUNT")) h->kn.hot_count = std::max(-1, atoi(e));
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
+    phase_acc()[PH_HOST] += phase_now() - t_host0;
+    PhaseScope ph_up(PH_H2D);
     hipError_t e = hipMalloc((void **)&h->d_row_ptr, (n + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMemcpy(h->d_row_ptr, row_ptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_col, std::max<int64_t>(nnz, 4) * sizeof(int32_t));
@@ -919,9 +922,13 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
     const int64_t n = h->n;
     std::vector<int32_t> cnt(n), K;
     std::vector<float> Uf;
-    GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    GEMHIP_REQUIRE(vose_unigram(cnt.data(), n, 1, Uf, K), "n2v_build_unigram: empty vocabulary (no walks?)");
-    h->vs.build(cnt.data(), (int64_t)cnt.size());
+    { PhaseScope ph(PH_D2H); GEMHIP_CHECK(hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost)); }
+    {
+        PhaseScope ph(PH_HOST);
+        GEMHIP_REQUIRE(vose_unigram(cnt.data(), n, 1, Uf, K), "n2v_build_unigram: empty vocabulary (no walks?)");
+        h->vs.build(cnt.data(), (int64_t)cnt.size());
+    }
+    PhaseScope ph_up(PH_H2D);
     if (!h->d_UT) GEMHIP_CHECK(hipMalloc((void **)&h->d_UT, n * sizeof(float)));
     if (!h->d_KT) GEMHIP_CHECK(hipMalloc((void **)&h->d_KT, n * sizeof(int32_t)));
     GEMHIP_CHECK(hipMemcpy(h->d_UT, Uf.data(), n * sizeof(float), hipMemcpyHostToDevice));
@@ -1091,6 +1098,7 @@ extern "C" int gemhip_sgns_get_tables(gemhip_n2v_t h, float *SynPos_host, float 
     GEMHIP_REQUIRE(h && h->SynPos, "sgns_get_tables: no tables");
     GEMHIP_CHECK(hipDeviceSynchronize());
     const size_t bytes = (size_t)h->n * h->d * sizeof(float);
+    PhaseScope ph(PH_D2H);
     if (SynPos_host) GEMHIP_CHECK(hipMemcpy(SynPos_host, h->SynPos, bytes, hipMemcpyDeviceToHost));
     if (SynNeg_host) GEMHIP_CHECK(hipMemcpy(SynNeg_host, h->SynNeg, bytes, hipMemcpyDeviceToHost));
     return GEMHIP_OK;
@@ -1314,6 +1322,8 @@ extern "C" int gemhip_n2v_train(int64_t n, int64_t nnz, const int64_t *row_ptr, 
                                 uint64_t seed, int32_t flags, float *X_out, double *stats)
 {
     GEMHIP_REQUIRE(X_out != nullptr, "n2v_train: X_out is NULL");
+    for (int k = 0; k < PH_COUNT; ++k) phase_acc()[k] = 0.0;
+    const double t_call = phase_now();
     gemhip_n2v_t h = nullptr;
     int rc = gemhip_n2v_create(n, nnz, row_ptr, col, w, &h);
     if (rc) return rc;
@@ -1335,7 +1345,14 @@ extern "C" int gemhip_n2v_train(int64_t n, int64_t nnz, const int64_t *row_ptr, 
         hipEventElapsedTime(&b, ev[2], ev[3]);
         stats[0] = a * 1e-3; stats[1] = b * 1e-3; stats[2] = (double)nwalks * walk_len; stats[3] = h->uniform_rows ? 1.0 : 0.0;
     }
+    if (!rc) {     // kernel seconds of the call (HIP events): walks + vocabulary, then table init + SGNS
+        float a = 0, b = 0;
+        hipEventElapsedTime(&a, ev[0], ev[1]);
+        hipEventElapsedTime(&b, ev[2], ev[3]);
+        phase_acc()[PH_KERNELS] = (a + b) * 1e-3;
+    }
     for (auto &e : ev) if (e) hipEventDestroy(e);
     gemhip_n2v_destroy(h);
+    phase_acc()[PH_TOTAL] = phase_now() - t_call;
     return rc;
 }

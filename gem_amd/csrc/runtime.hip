@@ -1,5 +1,6 @@
 // runtime.hip -- error state and the small device-runtime part of the C ABI.
 #include "common.hpp"
+#include <chrono>
 
 namespace gemhip {
 
@@ -20,9 +21,28 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+double *phase_acc()
+{
+    static thread_local double acc[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return acc;
+}
+
+double phase_now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 }  // namespace gemhip
 
 using namespace gemhip;
+
+// {total_seconds, host_prepare_seconds, h2d_seconds, kernel_seconds, d2h_seconds, 0, 0, 0} of the LAST one-shot call on this thread
+extern "C" int gemhip_last_call_phases(double *out)
+{
+    GEMHIP_REQUIRE(out != nullptr, "last_call_phases: NULL");
+    for (int k = 0; k < PH_COUNT; ++k) out[k] = phase_acc()[k];
+    return GEMHIP_OK;
+}
 
 extern "C" int gemhip_version(void) { return GEMHIP_VERSION; }
 

@@ -28,8 +28,11 @@ using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, 
 sgns_fn pick_sgns(int d);                    // sgns_det.hip: sgns_kernel (no LDS window), nullptr when d is unsupported (even d <= 512, odd d <= 256)
 sgns_fn pick_sgns_win_det(int d);            // sgns_det.hip: sgns_win_kernel, overwrite on leave (bit-compatible with sgns_kernel on one wavefront)
 sgns_fn pick_sgns_win_hogwild(int d);        // sgns_hogwild.hip: sgns_win_kernel, delta write-back
-// floats one cached row occupies in LDS (the wave's footprint of a row, see sgns_win_kernel)
-inline int sgns_win_row_floats(int d) { return d % 2 == 0 ? ((d + 127) / 128) * 128 : ((d + 63) / 64) * 64; }
+// floats one cached row occupies in LDS and in the per-wave scratch row: RW = NV * VEC * 64 of the kernel the pickers INSTANTIATE for d
+// (NV is 1, 2 or 4: three chunks run on the NV = 4 kernel, so d = 129..191 odd and 258..384 even occupy 256 / 512 floats, not 192 / 384;
+// round 3 sized LDS and the scratch rows from the chunk count and the NV = 4 kernels wrote past both -- ADVICE r3)
+inline int sgns_win_nv(int d) { const int nv = d % 2 == 0 ? (d + 127) / 128 : (d + 63) / 64; return nv <= 1 ? 1 : nv <= 2 ? 2 : 4; }
+inline int sgns_win_row_floats(int d) { return sgns_win_nv(d) * (d % 2 == 0 ? 128 : 64); }
 }  // namespace gemhip
 
 using namespace gemhip;

@@ -8,6 +8,8 @@ from gem_amd.graph import edge_arrays, to_csr
 
 
 def learn(model, graph):
+    import time
+    t0 = time.perf_counter()
     n, src, dst, w, order = edge_arrays(graph)
     if order is not None:
         # hope.py:28 builds A with nx.to_numpy_matrix(graph): row/column index = position in graph.nodes,
@@ -16,6 +18,7 @@ def learn(model, graph):
         pos[order] = np.arange(n)
         src, dst = pos[src].astype(np.int32), pos[dst].astype(np.int32)
     row_ptr, col, ww = to_csr(n, src, dst, w)
+    t1 = time.perf_counter()
     d = int(model._d)
     k = d // 2
     if k < 1 or k >= n:
@@ -28,10 +31,13 @@ def learn(model, graph):
                                       int(getattr(model, '_krylov_steps', 3)), int(getattr(model, '_max_restarts', 20)),
                                       float(getattr(model, '_tol', 1e-5)), int(getattr(model, '_seed', 20260923)),
                                       _hip.ptr(U, C.c_float), _hip.ptr(V, C.c_float), _hip.ptr(sig, C.c_float), stats))
+    t2 = time.perf_counter()
     model._sigma = sig.astype(np.float64)
     model._stats = dict(zip(('device_seconds', 'spmm_launches', 'spmm_columns', 'katz_terms', 'basis_columns', 'restarts',
                              'last_sigma_change', 'beta_sigma_max', 'host_eig_seconds', 'host_eig_calls', 'ritz_residual', 'spmm_seconds'), list(stats)))
     model._stats['solver'] = 'symmetric_chebyshev_filter' if model._stats['katz_terms'] == 0 else 'block_krylov'   # hope.hip: A == A^T takes the eigen-path
     _hip.warn_if_unconverged(model._stats, float(getattr(model, '_tol', 1e-5)), int(getattr(model, '_max_restarts', 20)), 'HOPE')
     model._node_num = n
-    return np.concatenate((U, V), axis=1).astype(np.float64)
+    X64 = np.concatenate((U, V), axis=1).astype(np.float64)
+    model._api_wall = _hip.api_wall(t0, t1, t2, time.perf_counter())
+    return X64

@@ -10,8 +10,11 @@ from gem_amd.graph import edge_arrays, to_csr
 def learn(model, graph):
     """Mirrors the argv of gem/embedding/node2vec.py:35-46:
     -d:_d -l:_walk_len -r:_num_walks -k:_con_size -e:_max_iter -p:_ret_p -q:_inout_p -dr -w."""
+    import time
+    t0 = time.perf_counter()
     n, src, dst, w, _ = edge_arrays(graph)
     row_ptr, col, ww = to_csr(n, src, dst, w)
+    t1 = time.perf_counter()
     d = int(model._d)
     seed = getattr(model, '_seed', None)
     if seed is None:
@@ -25,6 +28,9 @@ def learn(model, graph):
                                            _hip.ptr(ww, C.c_float), d, int(model._walk_len), int(model._num_walks),
                                            int(model._con_size), int(model._max_iter), float(model._ret_p),
                                            float(model._inout_p), seed, flags, _hip.ptr(X, C.c_float), stats))
+    t2 = time.perf_counter()
     model._stats = {'walk_seconds': stats[0], 'sgns_seconds': stats[1], 'tokens': stats[2]}
     model._node_num = n
-    return X.astype(np.float64)
+    X64 = X.astype(np.float64)                    # node2vec.py:48 / loadEmbedding return float64
+    model._api_wall = _hip.api_wall(t0, t1, t2, time.perf_counter())
+    return X64

@@ -48,6 +48,11 @@ int gemhip_free(void *dptr);
 int gemhip_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes);
 int gemhip_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes);
 int gemhip_synchronize(void *stream);
+/* Where the wall time of the LAST one-shot call on this thread went (gemhip_gf_train, gemhip_n2v_train, gemhip_hope: the drop-ins
+ * for gf.py:55-72, node2vec.py:35-48 and hope.py:28-36, whose callers time `learn_embedding` as a whole -- SURVEY 8d "API wall"):
+ * out[8] = {total_seconds, host_prepare_seconds (CSR sort, alias / unigram tables, plans), h2d_seconds, kernel_seconds (HIP events),
+ * d2h_seconds, 0, 0, 0}. */
+int gemhip_last_call_phases(double *out);
 
 /* ------------------------------------------------- Graph Factorization (GF)
  * Replaces: gem/embedding/gf.py:81-101 (GraphFactorization.learn_embedding,

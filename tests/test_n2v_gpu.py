@@ -137,7 +137,10 @@ def test_hip_kernels_equal_the_bodies_pinned_to_the_reference_binary(name):
 
 @pytest.mark.parametrize('gname,d,window,l,epochs,flags', [('karate', 2, 10, 80, 1, SNAP), ('karate', 8, 3, 20, 2, 8),
                                                            ('sbm1024', 16, 10, 40, 1, SNAP), ('sbm1024', 128, 5, 24, 1, SNAP),
-                                                           ('karate', 7, 4, 30, 1, SNAP), ('karate', 256, 2, 10, 1, SNAP)])
+                                                           ('karate', 7, 4, 30, 1, SNAP), ('karate', 256, 2, 10, 1, SNAP),
+                                                           # three row chunks run on the NV = 4 instantiation (rows of 256 / 512 floats in LDS and in
+                                                           # the scratch rows): odd d in 129..191 at the default window, even d in 258..384 at window 5
+                                                           ('karate', 129, 10, 30, 1, SNAP), ('karate', 320, 5, 20, 1, SNAP), ('sbm1024', 191, 10, 24, 1, SNAP)])
 def test_sgns_deterministic_matches_oracle(gname, d, window, l, epochs, flags, request):
     """flags|4: one wavefront walks the corpus in order == TrainModel single-threaded.  karate (n=34)
     makes the same row come up as context/negative constantly, exercising the in-wave RAW paths."""
@@ -164,7 +167,8 @@ def test_sgns_deterministic_matches_oracle(gname, d, window, l, epochs, flags, r
 @pytest.mark.parametrize('gname,d,window,l,radius,delta', [('karate', 8, 10, 80, -1, 0), ('karate', 8, 10, 80, 3, 0), ('karate', 7, 4, 30, 2, 0),
                                                            ('sbm1024', 128, 10, 40, -1, 0), ('sbm1024', 128, 10, 40, 4, 0),
                                                            ('sbm1024', 128, 10, 40, -1, 1), ('karate', 256, 5, 20, 5, 1),
-                                                           ('karate', 16, 12, 9, -1, 0), ('karate', 128, 10, 30, 4, 1), ('karate', 128, 10, 30, -1, 9)])
+                                                           ('karate', 16, 12, 9, -1, 0), ('karate', 128, 10, 30, 4, 1), ('karate', 128, 10, 30, -1, 9),
+                                                           ('karate', 129, 10, 30, -1, 1), ('karate', 320, 5, 20, -1, 1), ('karate', 320, 5, 20, -1, 9)])
 @pytest.mark.parametrize('hog', [(2, 1), (1, 1), (2, 0)])
 def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, delta, hog, request):
     """The LDS-window kernel (default) and the round-1 kernel (flag 128) are the same algorithm: one wavefront in walk order gives
