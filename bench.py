@@ -15,7 +15,7 @@ same process -- GF on SBM 10k/100k with examples/run_sbm.py:66's eta/lambda (con
 100k/1M (configs[2]) -- each with its own timed region, roofline and cpu_baseline under "workloads" of the one JSON line.
 For N>1 either launch one rank per GPU with torch.distributed.run (what the driver does) or run plain `python bench.py --gpus N`, which
 spawns the N ranks itself; a mismatch between --gpus and WORLD_SIZE, or fewer GPUs than ranks, is an error (never a silent 1-GPU run).  Both paths shard by SOURCE /
-START NODE (gem_amd/multi_gpu.py; node2vec additionally partitions its tables over the ranks): total work is
+START NODE (gem_amd/multi_gpu.py; node2vec additionally partitions its tables over the ranks and all-gathers the walk shards): total work is
 fixed => "scaling": "strong".
 
 `roofline`: for the dominant kernel, algorithmic bytes per launch (SURVEY 8d per-unit figure x units
@@ -319,8 +319,10 @@ class N2VWorkload(object):
         ph = self.job.phase_seconds() if hasattr(self.job, 'phase_seconds') else None
         if not ph:
             return None
-        return {'last_step_seconds': ph, 'note': 'HIP events of the last pass on this rank: training rounds and SynNeg ring shifts are serial on the '
-                'training stream; pair emission + size exchange + all-to-all of the next episode run on a side stream that does not wait for the training stream'}
+        return {'last_step_seconds': ph, 'pairs_trained_by_this_rank': int(getattr(self.job, 'pairs_trained', 0)),
+                'note': 'HIP events of the last pass on this rank: the bucket launches (TrainModel in walk order restricted to SynPos partition g x the visiting '
+                        'SynNeg partition) and the ring shifts of the SynNeg partitions between them, serial on the training stream; the walk corpus is '
+                        'assembled once per pass (one all-gather of the shards)'}
 
     def roofline(self, dev_ms_total, steps):
         torch.cuda.synchronize()

@@ -86,12 +86,10 @@ _SIGS = {
     'gemhip_n2v_bind_counts': (C.c_int, [C.c_void_p, C.c_void_p]),
     'gemhip_sgns_pairs': (C.c_int, [C.c_void_p, i64p, C.c_int32]),
     'gemhip_n2v_build_unigram_parts': (C.c_int, [C.c_void_p, C.c_int32, f32p, i32p]),
-    'gemhip_sgns_emit_pairs': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int64,
-                                         C.c_void_p, C.c_void_p]),
-    'gemhip_sgns_emit_pairs_bucketed': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p,
-                                                  C.c_int64, i64p, C.c_void_p]),
-    'gemhip_sgns_train_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
-                                          C.c_float, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p]),
+    'gemhip_sgns_train_part': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_float,
+                                         C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p]),
+    'gemhip_n2v_copy_walks': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     'gemhip_n2v_set_max_waves': (C.c_int, [C.c_void_p, C.c_int32]),
     'gemhip_sgns_set_window_cache': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_sgns_set_hogwild': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -11,7 +11,7 @@
 //   InitUnigramTable                      -> host Vose in fp64 (O(n), once)
 //   InitPosEmb/InitNegEmb                 -> sgns_init_kernel
 //   TrainModel (Hogwild over walks)       -> sgns_win_kernel / sgns_kernel (sgns.hpp; one wavefront = one walk), instantiated in
-//        sgns_hogwild.hip and sgns_det.hip; this file holds the C ABI, the launch rule (gemhip_sgns_train) and the partitioned schedule's kernels
+//        sgns_hogwild.hip, sgns_det.hip and sgns_part.hip (one bucket of the partitioned N-GPU schedule); this file holds the C ABI and the launch rule
 //
 // All randomness is a counter-based Philox4x32-10 stream keyed by (seed, walk, position,
 // purpose): results do not depend on scheduling, and the CPU oracle reproduces walks,
@@ -139,12 +139,13 @@ struct gemhip_n2v {
     SgnsKnobs kn;                     // launch knobs (setters below; environment overrides read once in gemhip_n2v_create)
     VocabStats vs;                    // vocabulary statistics (gemhip_n2v_build_unigram*): how concentrated the row traffic is -> plan_sgns_launch
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
-    unsigned long long *d_bcnt = nullptr;               // emit_pairs_bucketed: bucket sizes [64*64] + cursors [64*64]
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
     // per-partition unigram tables (multi-GPU episode schedule): partition p = {v : v % parts == p}, local index v / parts
     int32_t parts = 0;
     float *d_UTp = nullptr; int32_t *d_KTp = nullptr;
+    uint2 *d_UKp = nullptr;                  // {bits of UTp[i], KTp[i]} interleaved (sgns_win_kernel<PART>)
     std::vector<int64_t> part_off;           // table p occupies [part_off[p], part_off[p+1])
+    std::vector<VocabStats> vs_part;         // vocabulary statistics of each partition's rows (launch rule of gemhip_sgns_train_part)
     bool own_counts = true;
 };
 
@@ -284,370 +285,6 @@ __global__ void sgns_init_kernel(float *SynPos, float *SynNeg, int64_t total, in
         }
 }
 
-// ------------------------------------------------------------------ partitioned ("episode") SGNS
-// Multi-GPU schedule (gem_amd/multi_gpu.py): nodes are split into `parts` partitions
-// (v -> v % parts, local row v / parts); the (context, word) pairs TrainModel forms are materialised, bucketed
-// by (part(context), part(word)) and trained bucket by bucket so that no two GPUs ever touch the same row.
-
-// One lane per centre token: emit its (context, word) pairs (same window-shrink draw as sgns_kernel) with a
-// wave-aggregated append (one atomic per wavefront).
-__global__ __launch_bounds__(256) void sgns_emit_pairs_kernel(const int32_t *__restrict__ walks, int64_t walk_lo, int64_t walk_hi, int32_t walk_len,
-                                                              int32_t window, int32_t epoch, int64_t walk_id_offset, uint64_t seed,
-                                                              int2 *__restrict__ out, int64_t cap, unsigned long long *__restrict__ cursor)
-{
-    const int lane = lane_id();
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ntok = (walk_hi - walk_lo) * walk_len;
-    int cnt = 0, b = 0, pos = 0;
-    const int32_t *walk = nullptr;
-    int32_t word = -1;
-    if (t < ntok) {
-        const int64_t wl = walk_lo + t / walk_len;
-        pos = (int)(t % walk_len);
-        walk = walks + wl * walk_len;
-        word = walk[pos];
-        if (word >= 0) {
-            const int64_t wid = walk_id_offset + wl;
-            const u32x4 rw = philox4x32_10(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)epoch << 8));
-            b = (int)(rw.x % (uint32_t)window);
-            for (int a = b; a < 2 * window + 1 - b; ++a) {
-                const int cp = pos - window + a;
-                if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) ++cnt;
-            }
-        }
-    }
-    // exclusive prefix of cnt over the wavefront
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    const int total = __shfl(incl, WAVE - 1);
-    unsigned long long base = 0;
-    if (lane == 0 && total > 0) base = atomicAdd(cursor, (unsigned long long)total);
-    base = ((unsigned long long)__shfl((int)(base >> 32), 0) << 32) | (unsigned int)__shfl((int)(base & 0xffffffffu), 0);
-    int64_t at = (int64_t)base + (incl - cnt);
-    if (cnt > 0) {
-        for (int a = b; a < 2 * window + 1 - b; ++a) {
-            const int cp = pos - window + a;
-            if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) {
-                if (at < cap) out[at] = make_int2(walk[cp], word);
-                ++at;
-            }
-        }
-    }
-}
-
-
-// Bucketed emission for the partitioned schedule: pairs are written grouped by key = (context % parts) * parts + (word % parts)
-// (counting sort: a count pass, an exclusive scan on the host, a fill pass).  Per workgroup an LDS histogram reserves one
-// contiguous range per bucket with ONE global atomic per bucket; lanes then claim slots with LDS atomics.  This replaces two
-// device-wide argsorts per episode in the driver.
-// exclusive prefix of the bucket sizes (<= 64*64 of them): one wavefront, 64 buckets per pass
-__global__ void bucket_prefix_kernel(const unsigned long long *__restrict__ cnt, unsigned long long *__restrict__ cur, int nb)
-{
-    const int lane = threadIdx.x;
-    unsigned long long carry = 0;
-    for (int base = 0; base < nb; base += WAVE) {
-        const unsigned long long v = base + lane < nb ? cnt[base + lane] : 0ull;
-        unsigned long long incl = v;
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const unsigned long long t = __shfl_up(incl, off, WAVE);
-            if (lane >= off) incl += t;
-        }
-        if (base + lane < nb) cur[base + lane] = carry + incl - v;
-        carry += __shfl(incl, WAVE - 1, WAVE);
-    }
-}
-
-template <bool FILL>
-__global__ __launch_bounds__(256) void sgns_bucket_pairs_kernel(const int32_t *__restrict__ walks, int64_t walk_lo, int64_t walk_hi, int32_t walk_len,
-                                                                int32_t window, int32_t epoch, int64_t walk_id_offset, uint64_t seed, int32_t parts,
-                                                                unsigned long long *__restrict__ counts_or_cursor, int2 *__restrict__ out, int64_t cap)
-{
-    __shared__ int hist[4096];                 // parts <= 64
-    __shared__ unsigned long long base[4096];
-    const int nb = parts * parts;
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) hist[k] = 0;
-    __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ntok = (walk_hi - walk_lo) * walk_len;
-    int b = 0, pos = 0;
-    const int32_t *walk = nullptr;
-    int32_t word = -1;
-    if (t < ntok) {
-        const int64_t wl = walk_lo + t / walk_len;
-        pos = (int)(t % walk_len);
-        walk = walks + wl * walk_len;
-        word = walk[pos];
-        if (word >= 0) {
-            const int64_t wid = walk_id_offset + wl;
-            const u32x4 rw = philox4x32_10(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)epoch << 8));
-            b = (int)(rw.x % (uint32_t)window);
-        }
-    }
-    const int wkey = word >= 0 ? word % parts : 0;
-    if (word >= 0)
-        for (int a = b; a < 2 * window + 1 - b; ++a) {
-            const int cp = pos - window + a;
-            if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) atomicAdd(&hist[(walk[cp] % parts) * parts + wkey], 1);
-        }
-    __syncthreads();
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
-        const int c = hist[k];
-        if (FILL) { base[k] = c ? atomicAdd(&counts_or_cursor[k], (unsigned long long)c) : 0ull; hist[k] = 0; }
-        else if (c) atomicAdd(&counts_or_cursor[k], (unsigned long long)c);
-    }
-    if (!FILL) return;
-    __syncthreads();
-    if (word >= 0)
-        for (int a = b; a < 2 * window + 1 - b; ++a) {
-            const int cp = pos - window + a;
-            if (a != window && cp >= 0 && cp < walk_len && walk[cp] >= 0) {
-                const int key = (walk[cp] % parts) * parts + wkey;
-                const int64_t at = (int64_t)base[key] + atomicAdd(&hist[key], 1);
-                if (at < cap) out[at] = make_int2(walk[cp] / parts, word / parts);     // LOCAL row indices inside their partitions
-            }
-        }
-}
-
-struct PairArgs {
-    const int2 *pairs; int64_t npairs; int32_t parts; int32_t neg_part; int64_t n_local_neg;
-    const float *UTp; const int32_t *KTp; float alpha_begin, alpha_end; uint64_t seed; uint32_t stream_id; int32_t flags; int32_t d;
-    float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs_done;
-};
-
-// One wavefront per pair at a time: context row (local), positive row and five negative rows of the visiting
-// SynNeg partition; same arithmetic, clamps and duplicate forwarding as sgns_kernel.
-// SAFE (every Hogwild launch): no update is applied to a stale copy -- what costs Hogwild its quality is a store overwriting what another
-// wavefront stored since the row was read (sgns_win_kernel, RELOAD).  The context row takes its neu1e by atomic add, the centre's positive
-// row an atomic add of what its run of pairs changed, and the five negative rows are fetched a second time after the dot products and leave
-// as `row_now + g * xc`.
-__device__ __forceinline__ void row_atomic_add(float *p, int d, int lane, int c, int vec, const float *v)
-{
-    const int idx = (c * WAVE + lane) * vec;
-    for (int k = 0; k < vec; ++k)
-        if (idx + k < d) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(p + idx + k), v[k]);
-}
-template <int VEC, int NV, bool SAFE>
-__global__ __launch_bounds__(256) void sgns_pairs_kernel(PairArgs A)
-{
-    const int lane = lane_id();
-    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (gw >= A.nwaves) return;
-    const int d = A.d;
-    const bool quirk = (A.flags & 2) != 0;
-    unsigned long long done = 0;
-    // each wavefront takes a CONTIGUOUS chunk of the bucket: neighbouring pairs come from the same centre word /
-    // the same walk, so interleaving them over wavefronts would make concurrent waves fight over the same rows
-    const int64_t chunk = (A.npairs + A.nwaves - 1) / A.nwaves;
-    const int64_t i_end = (gw + 1) * chunk < A.npairs ? (gw + 1) * chunk : A.npairs;
-    // pairs arrive in walk order, so consecutive pairs usually share their centre word: its SynNeg row (the positive
-    // target) stays in registers until the word changes, like in the walk-based kernel
-    const float alpha_slope = (A.alpha_end - A.alpha_begin) / (float)(A.npairs > 1 ? A.npairs : 1);
-    float yp[NV][VEC], yp0[NV][VEC];
-    int32_t held = -1;                                    // local row index currently in yp (yp0: the row as loaded, SAFE)
-    auto release = [&]() {
-        float *po = A.SynNeg + (int64_t)held * d;
-        if constexpr (SAFE) {
-#pragma unroll
-            for (int c = 0; c < NV; ++c) {
-                float dl[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) dl[v] = yp[c][v] - yp0[c][v];
-                row_atomic_add(po, d, lane, c, VEC, dl);
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < NV; ++c) st_row<VEC>(po, d, lane, c, yp[c]);
-        }
-    };
-    // negative targets are drawn for PAIR_BATCH = 12 pairs at a time: lane 5p + (j-1) draws target j of pair i0 + p from the
-    // visiting partition's alias table (two dependent lookups), one batch ahead of its use
-    constexpr int PAIR_BATCH = 12;
-    auto draw = [&](int64_t i0) -> int32_t {
-        int32_t m = -1;
-        const int p = lane / SGNS_NEG, j = lane - p * SGNS_NEG + 1;
-        const int64_t i = i0 + p;
-        if (p < PAIR_BATCH && i < i_end) {
-            const u32x4 rn = philox4x32_10(A.seed, (uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.stream_id,
-                                           (uint32_t)TAG_NEG | ((uint32_t)j << 16) | 0x80000000u);
-            const uint32_t slot = mulhi_range(rn.x, (uint32_t)A.n_local_neg);
-            const int32_t X = quirk ? A.KTp[slot] : (int32_t)slot;
-            m = (u01(rn.y) < A.UTp[X]) ? X : A.KTp[X];
-        }
-        return m;
-    };
-    const int64_t i_begin = gw * chunk;
-    int32_t mine_cur = i_begin < i_end ? draw(i_begin) : -1, mine_next = -1;
-    for (int64_t i = i_begin; i < i_end; ++i) {
-        const int slot_in_batch = (int)((i - i_begin) % PAIR_BATCH);
-        if (slot_in_batch == 0) {
-            if (i != i_begin) mine_cur = mine_next;
-            mine_next = draw(i + PAIR_BATCH);
-        }
-        const int2 pr = A.pairs[i];
-        const int32_t ctx_l = __builtin_amdgcn_readfirstlane(pr.x), word_l = __builtin_amdgcn_readfirstlane(pr.y);   // local rows
-        const float alpha = A.alpha_begin + alpha_slope * (float)i;
-        int32_t tgt[SGNS_NEG];
-#pragma unroll
-        for (int j = 0; j < SGNS_NEG; ++j) tgt[j] = __builtin_amdgcn_readlane(mine_cur, slot_in_batch * SGNS_NEG + j);
-
-        float xc[NV][VEC], neu[NV][VEC], yn[SGNS_NEG][NV][VEC];
-        float *pc = A.SynPos + (int64_t)ctx_l * d;
-        if (word_l != held) {
-            if (held >= 0) release();
-            const float *pp = A.SynNeg + (int64_t)word_l * d;
-#pragma unroll
-            for (int c = 0; c < NV; ++c) ld_row<VEC>(pp, d, lane, c, yp[c]);
-            if constexpr (SAFE) {
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) yp0[c][v] = yp[c][v];
-            }
-            held = word_l;
-        }
-#pragma unroll
-        for (int c = 0; c < NV; ++c) ld_row<VEC>(pc, d, lane, c, xc[c]);
-#pragma unroll
-        for (int j = 0; j < SGNS_NEG; ++j) {
-            const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
-#pragma unroll
-            for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, yn[j][c]);
-        }
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) neu[c][v] = 0.f;
-        // the six targets of a pair are independent unless one repeats or equals the centre word: then one transposed reduction gives the six
-        // dot products and the sigmoid runs once, lane-parallel (wave_sum6, as in sgns_win_kernel); otherwise TrainModel's sequential order
-        bool special = false;
-#pragma unroll
-        for (int j = 0; j < SGNS_NEG; ++j) {
-            special = special || tgt[j] == word_l;
-#pragma unroll
-            for (int jp = 0; jp < j; ++jp) special = special || tgt[jp] == tgt[j];
-        }
-        if (!special && !(A.flags & 256)) {            // (flag 256: A/B switch, sequential order for every pair)
-            float part[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) part[j] = 0.f;
-#pragma unroll
-            for (int c = 0; c < NV; ++c)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    part[0] = fmaf(xc[c][v], yp[c][v], part[0]);
-#pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) part[j + 1] = fmaf(xc[c][v], yn[j][c][v], part[j + 1]);
-                }
-            float rn[SAFE ? SGNS_NEG : 1][NV][VEC];
-            if constexpr (SAFE) {                          // the five rows as they are now; needed after the sigmoid
-#pragma unroll
-                for (int j = 0; j < SGNS_NEG; ++j) {
-                    const float *pn = A.SynNeg + (int64_t)tgt[j] * d;
-#pragma unroll
-                    for (int c = 0; c < NV; ++c) ld_row<VEC>(pn, d, lane, c, rn[j][c]);
-                }
-            }
-            const float f = wave_sum6(part, lane);
-            const float gl = sgns_grad_fast(f, (lane & 7) == 0 ? 1.0f : 0.0f, alpha);
-            float g[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) g[j] = bcast_lane(gl, j);
-#pragma unroll
-            for (int c = 0; c < NV; ++c)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g[0], yp[c][v], neu[c][v]); yp[c][v] = fmaf(g[0], xc[c][v], yp[c][v]); }
-#pragma unroll
-            for (int j = 0; j < SGNS_NEG; ++j) {
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        neu[c][v] = fmaf(g[j + 1], yn[j][c][v], neu[c][v]);
-                        if constexpr (SAFE) rn[j][c][v] = fmaf(g[j + 1], xc[c][v], rn[j][c][v]);
-                        else yn[j][c][v] = fmaf(g[j + 1], xc[c][v], yn[j][c][v]);
-                    }
-                float *pn = A.SynNeg + (int64_t)tgt[j] * d;
-#pragma unroll
-                for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, SAFE ? rn[j][c] : yn[j][c]);
-            }
-        } else {
-            {
-                float part = 0.f;
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yp[c][v], part);
-                const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yp[c][v], neu[c][v]); yp[c][v] = fmaf(g, xc[c][v], yp[c][v]); }
-            }
-#pragma unroll
-            for (int j = 0; j < SGNS_NEG; ++j) {
-                if (tgt[j] == word_l) continue;
-#pragma unroll
-                for (int jp = 0; jp < j; ++jp)
-                    if (tgt[jp] == tgt[j] && tgt[jp] != word_l) {
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) yn[j][c][v] = yn[jp][c][v];
-                    }
-                float part = 0.f;
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) part = fmaf(xc[c][v], yn[j][c][v], part);
-                const float g = sgns_grad(wave_sum(part), 0.0f, alpha);
-#pragma unroll
-                for (int c = 0; c < NV; ++c)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) { neu[c][v] = fmaf(g, yn[j][c][v], neu[c][v]); yn[j][c][v] = fmaf(g, xc[c][v], yn[j][c][v]); }
-                float *pn = A.SynNeg + (int64_t)tgt[j] * d;
-#pragma unroll
-                for (int c = 0; c < NV; ++c) st_row<VEC>(pn, d, lane, c, yn[j][c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            if constexpr (SAFE) row_atomic_add(pc, d, lane, c, VEC, neu[c]);
-            else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) xc[c][v] += neu[c][v];
-                st_row<VEC>(pc, d, lane, c, xc[c]);
-            }
-        }
-        ++done;
-    }
-    if (held >= 0) release();
-    if (lane == 0 && A.pairs_done) atomicAdd(A.pairs_done, done);
-}
-
-using pairs_fn = void (*)(const PairArgs &, int blocks, int threads, hipStream_t);
-template <int VEC, int NV>
-void launch_pairs(const PairArgs &A, int blocks, int threads, hipStream_t s)
-{
-    if (A.nwaves > 1) hipLaunchKernelGGL((sgns_pairs_kernel<VEC, NV, true>), dim3(blocks), dim3(threads), 0, s, A);
-    else hipLaunchKernelGGL((sgns_pairs_kernel<VEC, NV, false>), dim3(blocks), dim3(threads), 0, s, A);
-}
-pairs_fn pick_pairs(int d)
-{
-    if (d % 2 == 0) {
-        const int nv = (d + 127) / 128;
-        if (nv <= 1) return launch_pairs<2, 1>;
-        if (nv <= 2) return launch_pairs<2, 2>;
-        if (nv <= 4) return launch_pairs<2, 4>;
-        return nullptr;
-    }
-    const int nv = (d + 63) / 64;
-    if (nv <= 1) return launch_pairs<1, 1>;
-    if (nv <= 2) return launch_pairs<1, 2>;
-    if (nv <= 4) return launch_pairs<1, 4>;
-    return nullptr;
-}
-
 uint32_t half_bits(uint64_t n)
 {
     uint32_t bits = 1;
@@ -733,9 +370,9 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
 {
     if (!h) return GEMHIP_OK;
     hipFree(h->d_start);
-    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_bcnt);
+    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy);
     if (h->own_counts) hipFree(h->d_counts);
-    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp);
+    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
     delete h;
     return GEMHIP_OK;
@@ -958,6 +595,8 @@ extern "C" int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, flo
     std::vector<float> Uall(n);
     std::vector<int32_t> Kall(n);
     h->part_off.assign(parts + 1, 0);
+    h->vs_part.assign(parts, VocabStats());
+    std::vector<int32_t> cp;
     for (int32_t p = 0; p < parts; ++p) {
         const int64_t np = (n - p + parts - 1) / parts;
         h->part_off[p + 1] = h->part_off[p] + np;
@@ -965,94 +604,24 @@ extern "C" int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, flo
         GEMHIP_REQUIRE(vose_unigram(cnt.data() + p, np, parts, Uf, K), "n2v_build_unigram_parts: partition %d has an empty vocabulary", p);
         std::copy(Uf.begin(), Uf.end(), Uall.begin() + h->part_off[p]);
         std::copy(K.begin(), K.end(), Kall.begin() + h->part_off[p]);
+        cp.resize(np);
+        for (int64_t i = 0; i < np; ++i) cp[i] = cnt[p + i * parts];
+        h->vs_part[p].build(cp.data(), np);
     }
-    hipFree(h->d_UTp); hipFree(h->d_KTp); h->d_UTp = nullptr; h->d_KTp = nullptr;
+    hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp); h->d_UTp = nullptr; h->d_KTp = nullptr; h->d_UKp = nullptr;
     GEMHIP_CHECK(hipMalloc((void **)&h->d_UTp, n * sizeof(float)));
     GEMHIP_CHECK(hipMalloc((void **)&h->d_KTp, n * sizeof(int32_t)));
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_UKp, n * sizeof(uint2)));
     GEMHIP_CHECK(hipMemcpy(h->d_UTp, Uall.data(), n * sizeof(float), hipMemcpyHostToDevice));
     GEMHIP_CHECK(hipMemcpy(h->d_KTp, Kall.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    {
+        std::vector<uint2> UK((size_t)n);
+        for (int64_t i = 0; i < n; ++i) { uint32_t ub; memcpy(&ub, &Uall[i], 4); UK[i] = make_uint2(ub, (uint32_t)Kall[i]); }
+        GEMHIP_CHECK(hipMemcpy(h->d_UKp, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+    }
     h->parts = parts;
     if (UT_out) std::copy(Uall.begin(), Uall.end(), UT_out);
     if (KT_out) std::copy(Kall.begin(), Kall.end(), KT_out);
-    return GEMHIP_OK;
-}
-
-extern "C" int gemhip_sgns_emit_pairs(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi, uint64_t seed,
-                                      void *d_pairs, int64_t cap, void *d_count, void *stream)
-{
-    GEMHIP_REQUIRE(h && d_pairs && d_count && cap >= 0, "sgns_emit_pairs: bad arguments");
-    GEMHIP_REQUIRE(window >= 1 && window < 16384 && epoch >= 0 && epoch < 256, "sgns_emit_pairs: window=%d epoch=%d", window, epoch);
-    GEMHIP_REQUIRE(0 <= walk_lo && walk_lo <= walk_hi && walk_hi <= h->nwalks, "sgns_emit_pairs: bad local walk range");
-    const int64_t ntok = (walk_hi - walk_lo) * h->walk_len;
-    if (ntok == 0) return GEMHIP_OK;
-    hipLaunchKernelGGL(sgns_emit_pairs_kernel, dim3((unsigned)((ntok + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->d_walks, walk_lo, walk_hi,
-                       h->walk_len, window, epoch, h->walk_id_offset, seed, (int2 *)d_pairs, cap, (unsigned long long *)d_count);
-    GEMHIP_CHECK(hipGetLastError());
-    return GEMHIP_OK;
-}
-
-extern "C" int gemhip_sgns_emit_pairs_bucketed(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi, uint64_t seed,
-                                               int32_t parts, void *d_pairs, int64_t cap, int64_t *counts_host, void *stream)
-{
-    GEMHIP_REQUIRE(h && d_pairs && counts_host && cap >= 0, "sgns_emit_pairs_bucketed: bad arguments");
-    GEMHIP_REQUIRE(parts >= 1 && parts <= 64, "sgns_emit_pairs_bucketed: parts=%d (1..64)", parts);
-    GEMHIP_REQUIRE(window >= 1 && window < 16384 && epoch >= 0 && epoch < 256, "sgns_emit_pairs_bucketed: window=%d epoch=%d", window, epoch);
-    GEMHIP_REQUIRE(0 <= walk_lo && walk_lo <= walk_hi && walk_hi <= h->nwalks, "sgns_emit_pairs_bucketed: bad local walk range");
-    const int nb = parts * parts;
-    for (int k = 0; k < nb; ++k) counts_host[k] = 0;
-    const int64_t ntok = (walk_hi - walk_lo) * h->walk_len;
-    if (ntok == 0) return GEMHIP_OK;
-    hipStream_t s = (hipStream_t)stream;
-    // bucket sizes and cursors stay on the device (persistent buffers of the handle; the exclusive prefix is a one-block kernel):
-    // count pass -> prefix -> fill pass queue back to back, the sizes reach the host with ONE synchronisation at the end
-    if (!h->d_bcnt) GEMHIP_CHECK(hipMalloc((void **)&h->d_bcnt, 2 * 64 * 64 * sizeof(unsigned long long)));
-    unsigned long long *d_cnt = h->d_bcnt, *d_cur = h->d_bcnt + 64 * 64;
-    const dim3 grid((unsigned)((ntok + 255) / 256)), blk(256);
-    std::vector<unsigned long long> cnt(nb);
-    GEMHIP_CHECK(hipMemsetAsync(d_cnt, 0, nb * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL((sgns_bucket_pairs_kernel<false>), grid, blk, 0, s, h->d_walks, walk_lo, walk_hi, h->walk_len, window, epoch, h->walk_id_offset,
-                       seed, parts, d_cnt, (int2 *)nullptr, (int64_t)0);
-    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, s, d_cnt, d_cur, nb);
-    hipLaunchKernelGGL((sgns_bucket_pairs_kernel<true>), grid, blk, 0, s, h->d_walks, walk_lo, walk_hi, h->walk_len, window, epoch,
-                       h->walk_id_offset, seed, parts, d_cur, (int2 *)d_pairs, cap);          // writes are bounded by `cap` inside the kernel
-    GEMHIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    GEMHIP_CHECK(hipStreamSynchronize(s));
-    GEMHIP_CHECK(hipGetLastError());
-    unsigned long long acc = 0;
-    for (int k = 0; k < nb; ++k) { acc += cnt[k]; counts_host[k] = (int64_t)cnt[k]; }
-    if ((int64_t)acc > cap) return fail(GEMHIP_E_INVALID, "sgns_emit_pairs_bucketed: %llu pairs exceed the buffer capacity %lld", acc, (long long)cap);
-    return GEMHIP_OK;
-}
-
-extern "C" int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs, int32_t neg_part, void *dSynPos_part,
-                                       void *dSynNeg_part, int32_t d, float alpha_begin, float alpha_end, uint64_t seed, uint32_t stream_id,
-                                       int32_t flags, void *stream)
-{
-    GEMHIP_REQUIRE(h && h->parts >= 1, "sgns_train_pairs: call n2v_build_unigram_parts first");
-    GEMHIP_REQUIRE(npairs >= 0 && (npairs == 0 || d_pairs) && dSynPos_part && dSynNeg_part, "sgns_train_pairs: bad arguments");
-    GEMHIP_REQUIRE(neg_part >= 0 && neg_part < h->parts, "sgns_train_pairs: neg_part=%d of %d", neg_part, h->parts);
-    GEMHIP_REQUIRE(pick_pairs(d) != nullptr, "sgns_train_pairs: d=%d unsupported", d);
-    if (npairs == 0) return GEMHIP_OK;
-    PairArgs A;
-    A.pairs = (const int2 *)d_pairs; A.npairs = npairs; A.parts = h->parts; A.neg_part = neg_part;
-    A.n_local_neg = h->part_off[neg_part + 1] - h->part_off[neg_part];
-    A.UTp = h->d_UTp + h->part_off[neg_part]; A.KTp = h->d_KTp + h->part_off[neg_part];
-    A.alpha_begin = alpha_begin; A.alpha_end = alpha_end; A.seed = seed; A.stream_id = stream_id; A.flags = flags; A.d = d;
-    A.SynPos = (float *)dSynPos_part; A.SynNeg = (float *)dSynNeg_part; A.pairs_done = h->d_pairs;
-    int blocks, threads;
-    if (flags & 4) { blocks = 1; threads = 64; A.nwaves = 1; }
-    else {
-        // Hogwild width: the rows in play are those of ONE partition pair (n/parts each).  Same rule as gemhip_sgns_train: the expected fraction
-        // of stores that overwrite another wavefront's, rho = W x 5 x w / n_partition with w ~ 0.4 pair steps (negative rows are fetched again
-        // right before their update, context and centre rows take atomic adds: sgns_pairs_kernel<SAFE>), stays <= 1.5 %  ->  n_partition / 133
-        // (round 2 ran n_partition / 32 wavefronts on plain read-modify-write rows: rho ~ 20 %)
-        int64_t cap = h->kn.max_waves > 0 ? h->kn.max_waves : std::max<int64_t>(1, A.n_local_neg / 133);
-        cap = std::min<int64_t>(cap, 256 * 16);
-        const int64_t waves = std::min<int64_t>(cap, npairs);
-        threads = 256; blocks = (int)((waves + 3) / 4); A.nwaves = (int32_t)waves;
-    }
-    pick_pairs(d)(A, blocks, threads, (hipStream_t)stream);
-    GEMHIP_CHECK(hipGetLastError());
     return GEMHIP_OK;
 }
 
@@ -1215,6 +784,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.UT = h->d_UT; A.KT = h->d_KT; A.UK = h->d_UK; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->kn.prefetch; A.reload = h->kn.reload; A.counts = nullptr; A.hot_thr = 0;
+    A.parts = 0; A.ctx_part = 0; A.word_part = 0; A.seg = nullptr; A.nseg = 0; A.seg_len = 0;
     const SgnsLaunchPlan P = plan_sgns_launch(h->vs, h->kn, h->n, h->d, window, h->walk_len, walk_hi - walk_lo, flags);
     GEMHIP_REQUIRE(P.lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for LDS staging (%zu bytes)", P.lds);
     A.nwaves = (int32_t)P.waves; A.cache_radius = P.R;
@@ -1265,6 +835,70 @@ extern "C" int gemhip_sgns_plan_launch(const int32_t *counts, int64_t n, int32_t
     if (hot_threshold) *hot_threshold = P.hot_thr;
     if (n_eff) *n_eff = vs.n_eff;
     if (n_eff_cold) *n_eff_cold = P.hot_thr > 0 ? vs.n_eff_cold((double)P.hot_thr) : vs.n_eff;
+    return GEMHIP_OK;
+}
+
+// One bucket of the partitioned (N-GPU) schedule trained in WALK order: TrainModel over a walk corpus restricted to the pairs whose context lies in
+// partition ctx_part (rows of dSynPos_part) and whose centre word lies in partition word_part (rows of dSynNeg_part; negatives drawn from the unigram
+// table restricted to word_part).  The corpus may be assembled from several ranks' shards (d_seg: nseg segments, see SgnsArgs::seg); alpha follows
+// the index of the token in the work-item order (token_offset + index).  Same kernel, same draws per (walk id, position) as gemhip_sgns_train: with
+// parts == 1 it IS gemhip_sgns_train.  Replaces the pair-list pipeline (emit -> bucket -> all-to-all -> sgns_pairs_kernel) of rounds 2-3: what a
+// rank needs from the others is their walks (4 bytes per token, once), not pairs (80 bytes per token, every episode), and the order of the pairs
+// inside a bucket is the reference's.
+extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64_t nwalks, int32_t walk_len, const void *d_seg, int32_t nseg,
+                                      int64_t seg_len, int64_t walk_id_offset, int32_t window, float alpha0, int64_t alpha_tokens_total,
+                                      int64_t token_offset, int32_t epoch, uint64_t seed, int32_t flags, int32_t ctx_part, int32_t word_part,
+                                      void *dSynPos_part, void *dSynNeg_part, int32_t d, void *stream)
+{
+    GEMHIP_REQUIRE(h && h->parts >= 1, "sgns_train_part: call n2v_build_unigram_parts first");
+    GEMHIP_REQUIRE(nwalks >= 0 && (nwalks == 0 || d_walks) && walk_len >= 1 && walk_len < 65536 && dSynPos_part && dSynNeg_part, "sgns_train_part: bad arguments");
+    GEMHIP_REQUIRE(ctx_part >= 0 && ctx_part < h->parts && word_part >= 0 && word_part < h->parts, "sgns_train_part: partitions (%d, %d) of %d", ctx_part, word_part, h->parts);
+    GEMHIP_REQUIRE(window >= 1 && window < 16384 && epoch >= 0 && epoch < 256 && alpha_tokens_total >= 1, "sgns_train_part: window=%d epoch=%d", window, epoch);
+    GEMHIP_REQUIRE(d_seg == nullptr || (nseg >= 1 && seg_len >= 1 && nwalks == (int64_t)nseg * seg_len), "sgns_train_part: nseg=%d seg_len=%lld nwalks=%lld (need nwalks == nseg * seg_len work items)",
+                   nseg, (long long)seg_len, (long long)nwalks);
+    GEMHIP_REQUIRE((h->n + h->parts - 1) / h->parts < (int64_t)(1 << 29), "sgns_train_part: more than 2^29 rows per partition");
+    if (nwalks == 0) return GEMHIP_OK;
+    SgnsArgs A;
+    A.walks = (const int32_t *)d_walks; A.walk_lo = 0; A.walk_hi = nwalks; A.walk_len = walk_len; A.window = window;
+    A.alpha0 = alpha0; A.denom = alpha_tokens_total + 1; A.token_offset = token_offset; A.walk_id_offset = walk_id_offset; A.epoch = epoch;
+    const int64_t off = h->part_off[word_part];
+    A.UT = h->d_UTp + off; A.KT = h->d_KTp + off; A.UK = h->d_UKp + off; A.n = (uint32_t)(h->part_off[word_part + 1] - off);
+    A.seed = seed; A.flags = flags; A.d = d;
+    A.SynPos = (float *)dSynPos_part; A.SynNeg = (float *)dSynNeg_part; A.pairs = h->d_pairs;
+    A.dummy = nullptr; A.prof = nullptr; A.prefetch = 2; A.reload = 1; A.counts = h->d_counts; A.hot_thr = 0;
+    A.parts = h->parts; A.ctx_part = ctx_part; A.word_part = word_part; A.seg = (const int64_t *)d_seg; A.nseg = nseg; A.seg_len = seg_len;
+    // the launch rule of gemhip_sgns_train on the rows in play: the negative rows are those of partition word_part (n_eff of ITS restricted unigram
+    // distribution bounds the Hogwild width: rho = W x 5 x 0.4 / n_eff <= 1.5 %); hot rows are judged on the GLOBAL token counts (a hub sits in
+    // W x (2R+1) x count / tokens windows whatever partition it belongs to)
+    VocabStats vs = h->vs_part[word_part];
+    vs.total = h->vs.total; vs.max = h->vs.max;
+    SgnsKnobs kn = h->kn;
+    kn.prefetch = 2; kn.reload = 1;
+    const SgnsLaunchPlan P = plan_sgns_launch(vs, kn, (int64_t)A.n, d, window, walk_len, nwalks, flags);
+    GEMHIP_REQUIRE(P.window, "sgns_train_part: d=%d window=%d walk_len=%d do not fit the LDS window kernel", d, window, walk_len);
+    A.nwaves = (int32_t)P.waves; A.cache_radius = P.R; A.hot_thr = P.hot_thr;
+    const size_t need = (size_t)P.waves * sgns_win_row_floats(d) * sizeof(float);
+    if (need > h->dummy_bytes) {
+        if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
+        GEMHIP_CHECK(hipMalloc(&h->d_dummy, need));
+        GEMHIP_CHECK(hipMemset(h->d_dummy, 0, need));
+        h->dummy_bytes = need;
+    }
+    A.dummy = h->d_dummy;
+    sgns_fn fn = pick_sgns_win_part(d, P.delta);
+    GEMHIP_REQUIRE(fn != nullptr, "sgns_train_part: d=%d unsupported", d);
+    fn(A, P.blocks, P.threads, P.lds, (hipStream_t)stream);
+    GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+// D2D copy of local walks [walk_lo, walk_hi) into a caller-owned device buffer (e.g. a torch tensor that an all-gather then assembles the corpus from)
+extern "C" int gemhip_n2v_copy_walks(gemhip_n2v_t h, int64_t walk_lo, int64_t walk_hi, void *d_dst, void *stream)
+{
+    GEMHIP_REQUIRE(h && d_dst && 0 <= walk_lo && walk_lo <= walk_hi && walk_hi <= h->nwalks, "n2v_copy_walks: bad arguments");
+    if (walk_hi > walk_lo)
+        GEMHIP_CHECK(hipMemcpyAsync(d_dst, h->d_walks + walk_lo * h->walk_len, (size_t)(walk_hi - walk_lo) * h->walk_len * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                                    (hipStream_t)stream));
     return GEMHIP_OK;
 }
 

@@ -2,7 +2,8 @@
 // Shared by the three translation units that carry it:
 //   sgns_hogwild.hip  sgns_win_kernel<.., DELTA = true, ..>   the shipped Hogwild path (delta write-back, reload-on-update, hot rows)
 //   sgns_det.hip      sgns_win_kernel<.., DELTA = false, ..> + sgns_kernel   deterministic / single-wavefront launches and d >= 384
-//   n2v.hip           the C ABI (gemhip_sgns_train picks a launcher), walks, alias tables, and sgns_pairs_kernel of the partitioned schedule
+//   sgns_part.hip     sgns_win_kernel<.., PART = true>   one bucket (SynPos partition g x SynNeg partition h) of the partitioned N-GPU schedule
+//   n2v.hip           the C ABI (gemhip_sgns_train / gemhip_sgns_train_part pick a launcher), walks, alias tables
 // Every kernel template is instantiated in exactly one of them; the helpers below are inlined wherever they are used.
 #pragma once
 #include "common.hpp"
@@ -22,12 +23,21 @@ struct SgnsArgs {
     int32_t prefetch;           // sgns_win_kernel: pairs whose negative rows are requested ahead (2, or 1)
     int32_t reload;             // sgns_win_kernel<RELOAD>: negative rows updated as they are at store time, centre row by atomic add
     const int32_t *counts; int32_t hot_thr;   // sgns_win_kernel<!ALLC>: nodes with counts[v] >= hot_thr > 0 never enter the LDS window (HOT ROWS below)
+    // sgns_win_kernel<PART> (partitioned tables, N-GPU schedule): node v belongs to partition v % parts, local row v / parts.  SynPos / SynNeg point
+    // at partition ctx_part of SynPos and partition word_part of SynNeg; UT / KT / UK / n describe the unigram table RESTRICTED to word_part (local
+    // indices); `counts` stays global.  Only pairs (context in ctx_part, centre word in word_part) are trained: TrainModel filtered to one bucket.
+    int32_t parts, ctx_part, word_part;
+    // a corpus assembled from several ranks' walk shards: work item wl = r * seg_len + j is walk j of segment r, stored at row seg[r] + j of
+    // `walks`, present when j < seg[nseg + r], with global walk id (the Philox key) seg[2 * nseg + r] + j.  seg == nullptr: one segment, row = wl,
+    // walk id = walk_id_offset + wl
+    const int64_t *seg; int32_t nseg; int64_t seg_len;
 };
 
 using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
 sgns_fn pick_sgns(int d);                    // sgns_det.hip: sgns_kernel (no LDS window), nullptr when d is unsupported (even d <= 512, odd d <= 256)
 sgns_fn pick_sgns_win_det(int d);            // sgns_det.hip: sgns_win_kernel, overwrite on leave (bit-compatible with sgns_kernel on one wavefront)
 sgns_fn pick_sgns_win_hogwild(int d);        // sgns_hogwild.hip: sgns_win_kernel, delta write-back
+sgns_fn pick_sgns_win_part(int d, bool hogwild);   // sgns_part.hip: sgns_win_kernel<PART> (one bucket of the partitioned schedule), Hogwild or single-wavefront
 // floats one cached row occupies in LDS and in the per-wave scratch row: RW = NV * VEC * 64 of the kernel the pickers INSTANTIATE for d
 // (NV is 1, 2 or 4: three chunks run on the NV = 4 kernel, so d = 129..191 odd and 258..384 even occupy 256 / 512 floats, not 192 / 384;
 // round 3 sized LDS and the scratch rows from the chunk count and the NV = 4 kernels wrote past both -- ADVICE r3)
@@ -348,7 +358,12 @@ struct NegSet {
 // algorithm, with or without RELOAD; the SBM graphs have no such node).  Nodes whose expected number of concurrent copies reaches 1
 // (counts[v] >= tokens / (W x (2R+1))) therefore never enter the window: as a context their row is fetched for the pair and takes its
 // neu1e by atomic add (RELOAD) or a plain store, like the contexts beyond the cached radius.
-template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC, int PF = 2, bool RELOAD = false>
+// PART (sgns_part.hip): the same walk-ordered TrainModel restricted to ONE bucket of the partitioned N-GPU schedule -- contexts of partition
+// A.ctx_part, centre words (and negatives) of partition A.word_part, rows addressed by their local index v / parts.  Tokens are tagged once per walk
+// (lane-parallel, in LDS): bits 0..28 local row, bit 29 "a centre of this bucket", bit 30 "a context of this bucket"; a token of any other partition is
+// -1 and costs its centre step the window bookkeeping only.  Every rank scans every walk of an episode once per round and trains its bucket of it:
+// what crosses the fabric is walks (4 bytes per token), not pairs (8 bytes x ~10 per token), and the pair order inside a bucket is TrainModel's.
+template <int VEC, int NV, bool DELTA, bool FULL, bool ALLC, int PF = 2, bool RELOAD = false, bool PART = false>
 __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 {
     static_assert(PF == 1 || PF == 2, "prefetch distance");
@@ -364,6 +379,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     const int nsamp = 2 * win * SGNS_NEG;
     const bool quirk = (A.flags & 2) != 0;
     int32_t *tok = lds;
+    constexpr int32_t PT_ROW = (1 << 29) - 1, PT_WORD = 1 << 29, PT_CTX = 1 << 30;
+    // the token at position k as a centre word / as a context: its (local) row, or -1 when it is none in this launch (padding; PART: another partition)
+    auto tok_w = [&](int k) -> int32_t { const int32_t v = tok[k]; if constexpr (PART) return (v >= 0 && (v & PT_WORD)) ? (v & PT_ROW) : -1; else return v; };
+    auto tok_c = [&](int k) -> int32_t { const int32_t v = tok[k]; if constexpr (PART) return (v >= 0 && (v & PT_CTX)) ? (v & PT_ROW) : -1; else return v; };
     int32_t *negs = tok + len;                       // [2][nsamp]
     float *rowsL = reinterpret_cast<float *>(lds + ((len + 2 * nsamp + 3) & ~3));
     // slot S of rowsL stages a context row that is not cached -- instantiations that cache every context (ALLC) do not carry it: at d = 128, R = 10 that
@@ -393,9 +412,9 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     };
 
     float *dummy = A.dummy + (size_t)gw * RW;        // this wave's private sink / source for predicated-off row traffic
-    auto is_hot = [&](int32_t v) -> bool {           // (wave-uniform v: a scalar load)
+    auto is_hot = [&](int32_t v) -> bool {           // (wave-uniform v: a scalar load; PART: v is a local row of the context partition)
         if constexpr (ALLC) return false;
-        else return A.hot_thr > 0 && A.counts[v] >= A.hot_thr;
+        else return A.hot_thr > 0 && A.counts[PART ? (int64_t)v * A.parts + A.ctx_part : (int64_t)v] >= A.hot_thr;
     };
     auto o_st = [&](int slot, const float (&v)[NV][VEC]) {            // the row as loaded (delta write-back)
         lds_st(rowsO + (size_t)slot * RW, v);
@@ -408,9 +427,28 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     PROF_START();
     for (int64_t wl = A.walk_lo + gw; wl < A.walk_hi; wl += A.nwaves) {
         const int32_t *walk = A.walks + wl * len;
-        for (int k = lane; k < len; k += WAVE) tok[k] = walk[k];
+        int64_t wid = A.walk_id_offset + wl;
+        if constexpr (PART) {
+            if (A.seg) {
+                const int64_t sg = wl / A.seg_len, j = wl - sg * A.seg_len;
+                if (j >= A.seg[A.nseg + sg]) continue;
+                walk = A.walks + (A.seg[sg] + j) * len;
+                wid = A.seg[2 * A.nseg + sg] + j;
+            }
+            for (int k = lane; k < len; k += WAVE) {
+                const int32_t v = walk[k];
+                int32_t t = -1;
+                if (v >= 0) {
+                    const int32_t pv = v % A.parts;
+                    const int32_t tag = (pv == A.word_part ? PT_WORD : 0) | (pv == A.ctx_part ? PT_CTX : 0);
+                    t = tag ? ((v / A.parts) | tag) : -1;
+                }
+                tok[k] = t;
+            }
+        } else {
+            for (int k = lane; k < len; k += WAVE) tok[k] = walk[k];
+        }
         __builtin_amdgcn_wave_barrier();
-        const int64_t wid = A.walk_id_offset + wl;
         const uint32_t w_lo = (uint32_t)wid, w_hi = (uint32_t)((uint64_t)wid >> 32);
 
         // slot directory: lane s < S describes slot s
@@ -424,6 +462,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         bool liveA[NS], liveB[NS];
         auto stage_a = [&](int p) {
             int bp = 0;
+            if constexpr (PART) { if (p < len && __builtin_amdgcn_readfirstlane(tok_w(p)) < 0) p = len; }      // not a centre of this bucket: nothing is drawn
             if (p < len) {
                 const u32x4 rwp = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
                 bp = (int)(rwp.x % (uint32_t)win);
@@ -468,7 +507,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 if (s < nsamp) dst[s] = (uB[k] < UTv[k]) ? XB[k] : KTv[k];
             }
             if (p >= len) return 0u;
-            const int32_t wordn = __builtin_amdgcn_readfirstlane(tok[p]);
+            const int32_t wordn = __builtin_amdgcn_readfirstlane(tok_w(p));
             bool sp = false;
             if (lane < 2 * win) {
                 int32_t t[SGNS_NEG];
@@ -478,12 +517,16 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 for (int j = 0; j < SGNS_NEG; ++j)
 #pragma unroll
                     for (int jp = 0; jp < j; ++jp) sp = sp || t[j] == t[jp];
+                // (PART: the two pairs in flight ahead of a slot are the previous two slots WITH a context of this bucket, known only once the
+                // centre's context mask is -- the centre adds that test itself, see `cross` below)
+                if constexpr (!PART) {
 #pragma unroll
-                for (int k = 0; k < 2 * SGNS_NEG; ++k) {
-                    const int idx = (lane - 2) * SGNS_NEG + k;
-                    const int32_t u = dst[idx >= 0 ? idx : 0];
+                    for (int k = 0; k < 2 * SGNS_NEG; ++k) {
+                        const int idx = (lane - 2) * SGNS_NEG + k;
+                        const int32_t u = dst[idx >= 0 ? idx : 0];
 #pragma unroll
-                    for (int j = 0; j < SGNS_NEG; ++j) sp = sp || (idx >= 0 && t[j] == u);
+                        for (int j = 0; j < SGNS_NEG; ++j) sp = sp || (idx >= 0 && t[j] == u);
+                    }
                 }
             }
             return (uint32_t)__builtin_amdgcn_ballot_w64(sp);
@@ -495,7 +538,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         // --- cache: enter token q (directory now, row through `rowE` -> LDS by the caller), leave token q
         // rows of tokens 0 .. R-1 enter before the first centre
         for (int q = 0; q < R && q < len; ++q) {
-            const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
+            const int32_t v = __builtin_amdgcn_readfirstlane(tok_c(q));
             if (v < 0 || is_hot(v)) continue;
             const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
             if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; continue; }
@@ -527,13 +570,13 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             }
         };
         for (int pos = 0; pos < len; ++pos) {
-            const int32_t word = __builtin_amdgcn_readfirstlane(tok[pos]);
+            const int32_t word = __builtin_amdgcn_readfirstlane(tok_w(pos));
             uint32_t spec_cur = spec_next;
             bool fin_done = false;
             // token pos+R enters
             float rowE[NV][VEC]; int sE = -1;
             if (pos + R < len) {
-                const int32_t v = __builtin_amdgcn_readfirstlane(tok[pos + R]);
+                const int32_t v = __builtin_amdgcn_readfirstlane(tok_c(pos + R));
                 if (v >= 0 && !is_hot(v)) {
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
                     if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; }
@@ -547,7 +590,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             // token pos-R leaves after this centre: when it is the last holder of its slot, fetch the row as it is NOW
             float rowG[NV][VEC], rowO[NV][VEC]; int sX = -1; int32_t vX = -1;
             if (pos - R >= 0) {
-                vX = __builtin_amdgcn_readfirstlane(tok[pos - R]);
+                vX = __builtin_amdgcn_readfirstlane(tok_c(pos - R));
                 const unsigned long long hx = vX >= 0 ? __builtin_amdgcn_ballot_w64(slot_node == vX) : 0ull;     // (no slot: a hot row, never cached)
                 if (hx) {
                     const int s = (int)__builtin_ctzll(hx);
@@ -588,7 +631,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 bool valid = false;
                 {
                     const int a = lane, cp = pos - win + a;
-                    if (a >= b && a < 2 * win + 1 - b && a != win && cp >= 0 && cp < len) valid = tok[cp] >= 0;
+                    if (a >= b && a < 2 * win + 1 - b && a != win && cp >= 0 && cp < len) valid = tok_c(cp) >= 0;
                 }
                 unsigned long long m_proc = __builtin_amdgcn_ballot_w64(valid), m_iss = m_proc;
                 npairs += (unsigned long long)__builtin_popcountll(m_proc);
@@ -596,7 +639,32 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     const unsigned long long lowm = (1ull << win) - 1ull;
                     const unsigned long long mai = (m_proc & lowm) | ((m_proc >> (win + 1)) << win);
                     const unsigned long long sh = mai ? (mai >> __builtin_ctzll(mai)) : 0ull;
-                    if (sh & (sh + 1ull)) spec_cur = 0xFFFFFFFFu;
+                    if constexpr (!PART) { if (sh & (sh + 1ull)) spec_cur = 0xFFFFFFFFu; }
+                    else {
+                        // the contexts of this bucket are scattered over the window: slot ai's rows were requested before the updates of the previous two
+                        // slots THAT HAVE A CONTEXT were stored.  Lane ai compares its five targets with theirs (once per centre, lane-parallel).
+                        bool cross = false;
+                        if (lane < 2 * win && ((mai >> lane) & 1ull)) {
+                            unsigned long long below = mai & ((1ull << lane) - 1ull);
+                            int32_t t[SGNS_NEG];
+#pragma unroll
+                            for (int j = 0; j < SGNS_NEG; ++j) t[j] = ncur[lane * SGNS_NEG + j];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                if (below) {
+                                    const int pa = 63 - __builtin_clzll(below);
+                                    below &= ~(1ull << pa);
+#pragma unroll
+                                    for (int k = 0; k < SGNS_NEG; ++k) {
+                                        const int32_t u = ncur[pa * SGNS_NEG + k];
+#pragma unroll
+                                        for (int j = 0; j < SGNS_NEG; ++j) cross = cross || t[j] == u;
+                                    }
+                                }
+                            }
+                        }
+                        spec_cur |= (uint32_t)__builtin_amdgcn_ballot_w64(cross);
+                    }
                 }
 
                 NegSet<VEC, NV> q0, q1, q2;          // three register sets rotate: processed now / next / the one after
@@ -607,7 +675,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     const int ai = a < win ? a : a - 1;
                     Q.tv = ncur[ai * SGNS_NEG + (lane < SGNS_NEG ? lane : 0)];
                     if (lane >= SGNS_NEG || !live) Q.tv = -1;
-                    if constexpr (!ALLC && RELOAD) Q.cnt = A.counts[Q.tv >= 0 ? Q.tv : 0];      // one 4-byte gather per pair, in flight with the rows
+                    if constexpr (!ALLC && RELOAD) Q.cnt = A.counts[Q.tv >= 0 ? (PART ? (int64_t)Q.tv * A.parts + A.word_part : (int64_t)Q.tv) : 0];      // one 4-byte gather per pair, in flight with the rows
 #pragma unroll
                     for (int j = 0; j < SGNS_NEG; ++j) {
                         Q.tgt[j] = __builtin_amdgcn_readlane(Q.tv, j);
@@ -637,7 +705,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     issue(P2);
                     PROF_LAP(1);                                     // issue of the prefetch
 
-                    const int32_t ctx = __builtin_amdgcn_readfirstlane(tok[pos - win + a]);
+                    const int32_t ctx = __builtin_amdgcn_readfirstlane(tok_c(pos - win + a));
                     const unsigned long long chit = __builtin_amdgcn_ballot_w64(slot_node == ctx);
                     float *lrow = rowsL + (size_t)((ALLC || chit) ? (int)__builtin_ctzll(chit) : S) * RW;
                     float *pc = A.SynPos + (int64_t)ctx * d;
@@ -877,7 +945,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         }
         // the last R tokens are still in the window
         for (int q = (len - R > 0 ? len - R : 0); q < len; ++q) {
-            const int32_t v = __builtin_amdgcn_readfirstlane(tok[q]);
+            const int32_t v = __builtin_amdgcn_readfirstlane(tok_c(q));
             if (v < 0) continue;
             const unsigned long long hq = __builtin_amdgcn_ballot_w64(slot_node == v);
             if (!hq) continue;                                   // a hot row: never cached
@@ -943,5 +1011,17 @@ void launch_sgns_win(const SgnsArgs &A, int blocks, int threads, size_t lds, hip
         else GEMHIP_LAUNCH_WIN(false, false, 2, false);
     }
 #undef GEMHIP_LAUNCH_WIN
+}
+// one bucket of the partitioned schedule: prefetch distance 2; Hogwild launches are reload-on-update (the only Hogwild mode the multi-GPU path uses)
+template <int VEC, int NV, bool DELTA>
+void launch_sgns_win_part(const SgnsArgs &A, int blocks, int threads, size_t lds, hipStream_t s)
+{
+    const bool full = A.d == NV * VEC * WAVE, allc = A.cache_radius >= A.window && A.hot_thr == 0;
+#define GEMHIP_LAUNCH_PART(F, C) hipLaunchKernelGGL((sgns_win_kernel<VEC, NV, DELTA, F, C, 2, DELTA, true>), dim3(blocks), dim3(threads), lds, s, A)
+    if (full && allc) GEMHIP_LAUNCH_PART(true, true);
+    else if (full) GEMHIP_LAUNCH_PART(true, false);
+    else if (allc) GEMHIP_LAUNCH_PART(false, true);
+    else GEMHIP_LAUNCH_PART(false, false);
+#undef GEMHIP_LAUNCH_PART
 }
 }  // namespace

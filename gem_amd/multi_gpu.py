@@ -11,11 +11,11 @@ SURVEY 8(e):
     4n bytes).  SGNS (`Node2VecPartitioned`): replicas that all-reduce the tables do NOT work beyond
     2 ranks -- summed deltas overshoot, averaged deltas under-train (measured) --
     so the tables are PARTITIONED instead (node v -> partition v % N, the scheme of GraphVite-style
-    systems): the (context, word) pairs of an episode of walks are materialised, routed to the owner of
-    the context row (all-to-all) and trained in N rounds in which rank g holds SynPos partition g and
-    SynNeg partition (g+s) % N, the SynNeg partitions rotating around a ring between rounds.  No two
-    GPUs ever touch the same row; with >= 64 episodes the embedding quality equals the sequential
-    algorithm's.  (`Node2VecSharded`, the delta-sum replica scheme, is kept for N <= 2 and for the record.)
+    systems): the walk corpus is assembled on every rank once (all-gather of the shards) and trained episode
+    by episode in N rounds in which rank g holds SynPos partition g and SynNeg partition (g+s) % N and runs
+    TrainModel in walk order restricted to that bucket, the SynNeg partitions rotating around a ring between
+    rounds.  No two GPUs ever touch the same row; with >= 64 episodes the embedding quality equals the
+    sequential algorithm's.  (`Node2VecSharded`, the delta-sum replica scheme, is kept for N <= 2 and for the record.)
 
 The compute backend is injected: `HipBackend*` (below) drives libgem_hip.so through the C ABI with
 torch tensors as device memory; the CPU tests inject a stand-in so the exchange logic runs under gloo.
@@ -55,16 +55,6 @@ class TorchComm(object):
             self.dist.all_gather_into_tensor(full, own)
         else:
             full.copy_(own)
-
-    def side_group(self):
-        """A second process group (its own RCCL communicator and stream) for collectives that run AHEAD of the training stream
-        (Node2VecPartitioned._prepare): torch serialises all collectives of one group on one internal stream in issue order, so on
-        the default group the next episode's all-to-all would queue behind this episode's ring shifts and lose the overlap."""
-        if self.world == 1:
-            return None
-        if getattr(self, '_side', None) is None:
-            self._side = self.dist.new_group(ranks=list(range(self.world)))
-        return self._side
 
     def all_gather_ints(self, values, device, group=None):
         """Every rank's list of ints -> [world][len(values)] nested list (tiny control message)."""
@@ -311,111 +301,118 @@ def assemble_partitions(P_part, comm, world, n):
 
 
 class Node2VecPartitioned(object):
-    """One full node2vec.learn_embedding pass on N ranks with PARTITIONED tables (module docstring)."""
+    """One full node2vec.learn_embedding pass on N ranks with PARTITIONED tables (module docstring).
+
+    Round 4: walks travel, pairs do not.  Every rank generates the walks of its start-node shard (as before), the vocabulary counts are summed
+    (4n-byte all-reduce), and ONE all-gather assembles the walk corpus on every rank (4 bytes per token: 3.2 GB at SBM 1M/10M against the
+    ~67 GB of (context, word) pairs the round-2/3 pipeline routed episode by episode).  An episode = the e-th slice of every rank's shard; in
+    round s of it rank g runs TrainModel in WALK order over those walks restricted to the bucket (contexts of SynPos partition g, centre words of
+    SynNeg partition (g+s) % N) -- `gemhip_sgns_train_part`, the single-GPU window kernel with a partition filter -- then the SynNeg partitions
+    move one step around the ring.  No pair lists, no all-to-all, no host round trip inside the pass; the only per-round traffic is the ring
+    shift of one SynNeg partition (n/N x d x 4 bytes)."""
 
     def __init__(self, backend, comm, rank, world, n, num_walks, walk_len, window, epochs, seed, flags, episodes=64, alpha0=0.025):
         self.b, self.comm, self.rank, self.world = backend, comm, rank, world
         self.n, self.num_walks, self.walk_len, self.window, self.epochs = n, num_walks, walk_len, window, epochs
         self.seed, self.flags, self.episodes, self.alpha0 = seed, flags, max(1, episodes), alpha0
-        self.lo, self.hi = shard_range(backend.num_start_nodes() * num_walks, rank, world)
+        self.total_walks = backend.num_start_nodes() * num_walks
+        self.lo, self.hi = shard_range(self.total_walks, rank, world)
         self.pairs_trained = 0
 
-    def _alpha(self, f):
-        return self.alpha0 * max(1.0 - f, 1e-4)
-
-    def _prepare(self, ep, e):
-        """Everything of episode (ep, e) that does not touch the tables: materialise the (context, word) pairs of this slice of my
-        walks grouped by (context % W, word % W) on the device, exchange the bucket sizes, route the pairs to the owners of
-        their context rows (all-to-all).  Runs one episode AHEAD of the training rounds, on its own stream, so its host round
-        trips (bucket sizes -> split sizes of the all-to-all) never stall the stream that trains."""
-        b, comm, W, g = self.b, self.comm, self.world, self.rank
-        nloc = self.hi - self.lo
-        a, z = shard_range(nloc, e, self.episodes)
-        pairs, counts = b.emit_pairs_bucketed(self.window, ep, a, z, self.seed, W)
-        # The look-ahead collectives go through a SECOND process group (its own RCCL communicator and stream) under nccl: on the default
-        # group torch serialises every collective on one internal stream in issue order, so the size exchange -- whose result the HOST
-        # waits for -- would queue behind all W ring shifts of the episode that was just queued, and the host could not queue the next
-        # episode before this one has drained.  Every rank issues the collectives of each group in the same order, which is what two
-        # communicators need to make progress side by side.  GEM_N2V_SIDE_GROUP=0 falls back to the default group (gloo always does:
-        # its collectives run on the host anyway).
-        import os
-        want = os.environ.get('GEM_N2V_SIDE_GROUP', '1' if getattr(comm, 'backend', lambda: 'gloo')() == 'nccl' else '0') == '1'
-        side = comm.side_group() if (hasattr(comm, 'side_group') and want) else None
-        kw = {'group': side} if side is not None else {}
-        cm = comm.all_gather_ints(counts, pairs.device, **kw)        # cm[src][dest * W + wpart]
-        send_counts = [sum(counts[r * W:(r + 1) * W]) for r in range(W)]
-        recv_counts = [sum(cm[src][g * W:(g + 1) * W]) for src in range(W)]
-        mine = comm.all_to_all_rows(pairs, send_counts, recv_counts, **kw)  # grouped by source rank, then by word % W
-        seg, at = [[None] * W for _ in range(W)], 0
-        for src in range(W):
-            for j in range(W):
-                ln = cm[src][g * W + j]
-                seg[src][j] = (at, at + ln)
-                at += ln
-        return mine, seg
+    def episode_table(self):
+        """int64 [episodes][3][W]: for episode e and shard r -- first row of the slice in the gathered corpus, walks in the slice, global walk id of
+        its first walk -- plus the work items per shard (the longest slice) of every episode."""
+        W = self.world
+        shard = [shard_range(self.total_walks, r, W) for r in range(W)]
+        self.shard_rows = max(hi - lo for lo, hi in shard)             # rows per shard in the gathered corpus (shorter shards are padded)
+        tab = np.zeros((self.episodes, 3, W), dtype=np.int64)
+        seg_len = np.zeros(self.episodes, dtype=np.int64)
+        for e in range(self.episodes):
+            for r, (lo, hi) in enumerate(shard):
+                a, z = shard_range(hi - lo, e, self.episodes)
+                tab[e, 0, r] = r * self.shard_rows + a
+                tab[e, 1, r] = z - a
+                tab[e, 2, r] = lo + a
+            seg_len[e] = max(1, int(tab[e, 1].max()))
+        return tab, seg_len
 
     def run(self, p=1.0, q=1.0):
-        import torch
         b, comm, W, g = self.b, self.comm, self.world, self.rank
         b.walks(p, q, self.num_walks, self.walk_len, self.seed, self.flags, self.lo, self.hi)
         counts = b.vocab()
         comm.all_reduce_sum(counts)
         b.build_unigram_parts(W)
+        tab, seg_len = self.episode_table()
+        corpus = b.gather_corpus(comm, self.shard_rows, W)                  # [W * shard_rows, walk_len] int32, identical on every rank
+        seg_dev = b.upload_table(tab)
         P_part, N_cur, N_tmp = b.init_part_tables(self.seed, g, W)          # partition g of SynPos / SynNeg (+ a receive buffer)
-        total_steps = float(self.epochs * self.episodes)
         self.pairs_trained = 0
-        cuda = bool(getattr(P_part, 'is_cuda', False))
-        main = torch.cuda.current_stream() if cuda else None
-        prep = torch.cuda.Stream() if cuda else None
-        ev = lambda: torch.cuda.Event(enable_timing=True) if cuda else None
-        self._ev = {'train': [], 'shift': [], 'prep': []}
-
-        def prepare(ep, e, first=False):
-            if not cuda:
-                return self._prepare(ep, e), None
-            if first:
-                prep.wait_stream(main)          # walks, vocabulary and tables are produced on `main`; nothing later on `main` feeds _prepare
-            with torch.cuda.stream(prep):
-                e0 = ev(); e0.record()
-                out = self._prepare(ep, e)
-                out[0].record_stream(main)
-                e1 = ev(); e1.record()
-            self._ev['prep'].append((e0, e1))
-            return out, e1
-
-        order = [(ep, e) for ep in range(self.epochs) for e in range(self.episodes)]
-        nxt = prepare(*order[0], first=True)
-        for k, (ep, e) in enumerate(order):
-            (mine, seg), ready = nxt
-            if ready is not None:
-                main.wait_event(ready)
-            step = ep * self.episodes + e
-            for s in range(W):
-                j = (g + s) % W                                          # SynNeg partition visiting me this round
-                parts_j = [mine[x:y] for x, y in (seg[src][j] for src in range(W)) if y > x]
-                bucket = parts_j[0] if len(parts_j) == 1 else (torch.cat(parts_j) if parts_j else mine[:0])
-                f0, f1 = (step + s / W) / total_steps, (step + (s + 1) / W) / total_steps
-                t0, t1, t2 = ev(), ev(), ev()
-                if cuda: t0.record()
-                b.train_pairs(bucket, j, P_part, N_cur, self._alpha(f0), self._alpha(f1), self.seed,
-                              (step * W + g) * W + j, self.flags)
-                if cuda: t1.record()
-                self.pairs_trained += int(bucket.shape[0])
-                N_cur, N_tmp = comm.ring_shift(N_cur, N_tmp)             # after W shifts my own partition is back
-                if cuda:
-                    t2.record()
-                    self._ev['train'].append((t0, t1)); self._ev['shift'].append((t1, t2))
-            # The rounds above are only QUEUED on `main` (kernel launches and P2P shifts are asynchronous).  The next episode's pairs are
-            # emitted and routed now, on `prep`, which does NOT wait for `main` (round 2 made it wait for every round just queued, so the
-            # host -- which synchronises `prep` inside _prepare to read the bucket sizes -- sat out the whole episode and `main` then idled
-            # through the exchange: no overlap at all; ADVICE r2).  The host blocks here only for the emit kernels and the size exchange.
-            nxt = prepare(*order[k + 1]) if k + 1 < len(order) else None
+        self._ev = {'train': [], 'shift': []}
+        timed = hasattr(b, 'event')
+        # alpha: linear in the position of a token in the schedule (episode by episode, work-item order inside one), the same in every round of an
+        # episode -- all ranks are at the same alpha at the same time
+        tok_ep = [int(seg_len[e]) * W * self.walk_len for e in range(self.episodes)]
+        alpha_total = self.epochs * sum(tok_ep)
+        done = 0
+        for ep in range(self.epochs):
+            for e in range(self.episodes):
+                for s in range(W):
+                    j = (g + s) % W                                      # SynNeg partition visiting me this round
+                    t0 = b.event() if timed else None
+                    b.train_part(corpus, seg_dev, e, W, int(seg_len[e]), self.window, self.alpha0, alpha_total, done, ep, self.seed, self.flags,
+                                 g, j, P_part, N_cur)
+                    t1 = b.event() if timed else None
+                    N_cur, N_tmp = comm.ring_shift(N_cur, N_tmp)         # after W shifts my own partition is back
+                    if timed:
+                        t2 = b.event()
+                        self._ev['train'].append((t0, t1)); self._ev['shift'].append((t1, t2))
+                done += tok_ep[e]
+        self.pairs_trained = b.pairs(reset=True)
         return assemble_partitions(P_part, comm, W, self.n)
 
+    def run_virtual(self, parts, p=1.0, q=1.0):
+        """The N-rank schedule with N = `parts` VIRTUAL ranks on ONE GPU (world must be 1): the rounds of an episode run rank after rank instead of side by
+        side -- the buckets of a round touch disjoint rows, so the result is what N GPUs compute (up to Hogwild's order inside a bucket).  Used by the
+        GPU tests (quality of the partitioned schedule at N > 1 on the one-GPU test box) and by scripts/check_partitioned_1m.py for the per-rank cost
+        model: `virtual_rank_seconds[g]` = kernel seconds rank g would spend."""
+        assert self.world == 1, 'run_virtual emulates the ranks on one device'
+        b, W = self.b, int(parts)
+        b.walks(p, q, self.num_walks, self.walk_len, self.seed, self.flags, 0, self.total_walks)
+        b.vocab()
+        b.build_unigram_parts(W)
+        tab, seg_len = self.episode_table()                                 # one shard (this rank's = everything)
+        corpus = b.gather_corpus(self.comm, self.shard_rows, 1)
+        seg_dev = b.upload_table(tab)
+        tabs = [b.init_part_tables(self.seed, g, W) for g in range(W)]
+        Pp, Np = [t[0] for t in tabs], [t[1] for t in tabs]
+        tok_ep = [int(seg_len[e]) * self.walk_len for e in range(self.episodes)]
+        alpha_total = self.epochs * sum(tok_ep)
+        timed = hasattr(b, 'event')
+        evs = [[] for _ in range(W)]
+        done = 0
+        for ep in range(self.epochs):
+            for e in range(self.episodes):
+                for s in range(W):
+                    for g in range(W):
+                        t0 = b.event() if timed else None
+                        b.train_part(corpus, seg_dev, e, 1, int(seg_len[e]), self.window, self.alpha0, alpha_total, done, ep, self.seed, self.flags,
+                                     g, (g + s) % W, Pp[g], Np[(g + s) % W])
+                        if timed:
+                            evs[g].append((t0, b.event()))
+                done += tok_ep[e]
+        self.pairs_trained = b.pairs(reset=True)
+        if timed:
+            import torch
+            torch.cuda.synchronize()
+            self.virtual_rank_seconds = [sum(a.elapsed_time(z) for a, z in ev) * 1e-3 for ev in evs]
+        import torch
+        rows = Pp[0].shape[0]
+        full = torch.stack(Pp, dim=1).reshape(rows * W, -1)[:self.n].contiguous()       # row v = partition[v % W][v // W]
+        return full
+
     def phase_seconds(self):
-        """Device seconds of the last run() by phase (HIP events): training rounds, ring shifts of the SynNeg partitions (both on the
-        training stream), pair emission + size exchange + all-to-all of the NEXT episode (side stream; issued without waiting for the
-        training stream, so it runs next to the rounds -- how much of `prep` is hidden is `train + shift + prep - wall`)."""
+        """Device seconds of the last run() by phase (HIP events on the training stream): the bucket launches and the ring shifts of the SynNeg
+        partitions between them."""
         if not getattr(self, '_ev', None) or not self._ev['train']:
             return None
         import torch
@@ -484,37 +481,33 @@ class HipBackendN2V(object):
         N = torch.zeros_like(P)
         return P, N, torch.zeros_like(P)
 
-    def emit_pairs(self, window, epoch, lo, hi, seed):
+    def gather_corpus(self, comm, shard_rows, world):
+        """My walk shard (padded to shard_rows with -1 tokens) -> the corpus of all ranks, rank-major, on every rank."""
         torch = self.torch
         nw = C.c_int64(); wl = C.c_int32(); p = C.c_void_p()
         _hip.check(self.L.gemhip_n2v_walks_ptr(self.h, C.byref(p), C.byref(nw), C.byref(wl)))
-        cap = max((hi - lo) * wl.value * 2 * window, 1)
-        buf = torch.empty((cap, 2), dtype=torch.int32, device=self.P.device)
-        cnt = torch.zeros(1, dtype=torch.int64, device=self.P.device)
-        _hip.check(self.L.gemhip_sgns_emit_pairs(self.h, window, epoch, lo, hi, seed, C.c_void_p(buf.data_ptr()), cap,
-                                                 C.c_void_p(cnt.data_ptr()), self._stream()))
-        return buf[:int(cnt.item())]
+        mine = torch.full((shard_rows, wl.value), -1, dtype=torch.int32, device=self.P.device)
+        _hip.check(self.L.gemhip_n2v_copy_walks(self.h, 0, nw.value, C.c_void_p(mine.data_ptr()), self._stream()))
+        if world == 1:
+            return mine
+        full = torch.empty((world * shard_rows, wl.value), dtype=torch.int32, device=self.P.device)
+        comm.all_gather_rows(full, mine)
+        return full
 
-    def emit_pairs_bucketed(self, window, epoch, lo, hi, seed, parts):
-        """Pairs grouped by key (context % parts) * parts + (word % parts); returns (int32 [np, 2] tensor, counts list)."""
-        torch = self.torch
-        nw = C.c_int64(); wl = C.c_int32(); p = C.c_void_p()
-        _hip.check(self.L.gemhip_n2v_walks_ptr(self.h, C.byref(p), C.byref(nw), C.byref(wl)))
-        cap = max((hi - lo) * wl.value * 2 * window, 1)
-        buf = torch.empty((cap, 2), dtype=torch.int32, device=self.P.device)
-        counts = (C.c_int64 * (parts * parts))()
-        _hip.check(self.L.gemhip_sgns_emit_pairs_bucketed(self.h, window, epoch, lo, hi, seed, parts, C.c_void_p(buf.data_ptr()), cap, counts,
-                                                          self._stream()))
-        counts = list(counts)
-        return buf[:sum(counts)], counts
+    def upload_table(self, tab):
+        return self.torch.from_numpy(np.ascontiguousarray(tab)).to(self.P.device)
 
-    def train_pairs(self, bucket, neg_part, P_part, N_part, a0, a1, seed, stream_id, flags):
-        if bucket.shape[0] == 0:
-            return
-        bucket = bucket.contiguous()
-        _hip.check(self.L.gemhip_sgns_train_pairs(self.h, C.c_void_p(bucket.data_ptr()), bucket.shape[0], neg_part,
-                                                  C.c_void_p(P_part.data_ptr()), C.c_void_p(N_part.data_ptr()), self.d, a0, a1, seed,
-                                                  stream_id & 0xffffffff, flags, self._stream()))
+    def event(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def train_part(self, corpus, seg_dev, e, nseg, seg_len, window, alpha0, alpha_total, token_offset, epoch, seed, flags, ctx_part, word_part,
+                   P_part, N_part):
+        _hip.check(self.L.gemhip_sgns_train_part(self.h, C.c_void_p(corpus.data_ptr()), nseg * seg_len, corpus.shape[1],
+                                                 C.c_void_p(seg_dev[e].data_ptr()), nseg, seg_len, 0, window, alpha0, alpha_total, token_offset,
+                                                 epoch, seed, flags, ctx_part, word_part, C.c_void_p(P_part.data_ptr()),
+                                                 C.c_void_p(N_part.data_ptr()), self.d, self._stream()))
 
     def pairs(self, reset=True):
         v = C.c_int64()

@@ -234,24 +234,28 @@ int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0,
                       int32_t flags, void *stream);
 
 /* Partitioned ("episode") SGNS for N GPUs -- no reference counterpart (the reference is one process); this is the
- * schedule that lets SGNS shard without two GPUs ever writing the same row:
- * node v belongs to partition v % parts with local row v / parts; the (context, word) pairs TrainModel forms are
- * materialised (emit_pairs: int32 pairs {context, word}, appended at an atomic cursor `d_count` the caller zeroes),
- * bucketed by the caller by (context % parts, word % parts), and each bucket is trained against ONE SynPos
- * partition and ONE SynNeg partition (train_pairs takes LOCAL row indices {context / parts, word / parts}; negatives come from the unigram table restricted to the word's
- * partition, built by build_unigram_parts from the global counts). */
+ * schedule that lets SGNS shard without two GPUs ever writing the same row: node v belongs to
+ * partition v % parts with local row v / parts; rank g keeps SynPos partition g, the SynNeg partitions travel around a
+ * ring, and in every round a rank trains ONE bucket (contexts of its SynPos partition, centre words of the visiting
+ * SynNeg partition) of the walk corpus.  build_unigram_parts: one alias table per partition over local indices
+ * (the unigram^0.75 distribution restricted to the partition), from the global counts of the handle. */
 int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, float *UT_out, int32_t *KT_out);
-int gemhip_sgns_emit_pairs(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi,
-                           uint64_t seed, void *d_pairs, int64_t cap, void *d_count, void *stream);
-/* Same pairs, written GROUPED by key = (context % parts) * parts + (word % parts) (counting sort on the device) and
- * as LOCAL row indices {context / parts, word / parts} -- what train_pairs consumes; counts_host[parts*parts]
- * receives the bucket sizes (bucket k starts at the sum of the sizes before it). */
-int gemhip_sgns_emit_pairs_bucketed(gemhip_n2v_t h, int32_t window, int32_t epoch, int64_t walk_lo, int64_t walk_hi,
-                                    uint64_t seed, int32_t parts, void *d_pairs, int64_t cap, int64_t *counts_host,
-                                    void *stream);
-int gemhip_sgns_train_pairs(gemhip_n2v_t h, const void *d_pairs, int64_t npairs, int32_t neg_part,
-                            void *dSynPos_part, void *dSynNeg_part, int32_t d, float alpha_begin,
-                            float alpha_end, uint64_t seed, uint32_t stream_id, int32_t flags, void *stream);
+/* One bucket of the partitioned schedule trained in WALK order (round 4; no reference counterpart beyond TrainModel itself): TrainModel
+ * (ELF @0x40d6a0) over a walk corpus in device memory, restricted to the pairs whose context is a node of partition ctx_part (rows of
+ * dSynPos_part, local index v / parts) and whose centre word is a node of partition word_part (rows of dSynNeg_part; negatives from the
+ * unigram table restricted to word_part -- gemhip_n2v_build_unigram_parts; the handle's counts must be the GLOBAL ones).
+ * Corpus: nwalks work items.  d_seg == NULL: item i is row i of d_walks, walk id walk_id_offset + i.  Otherwise the corpus is assembled
+ * from nseg shards (d_seg = device int64[3 * nseg] = {first row in d_walks, walks present, global id of the first walk} per shard) and item
+ * i = r * seg_len + j is walk j of shard r (skipped when j >= walks present); nwalks must equal nseg * seg_len.
+ * alpha = alpha0 * max(1 - t / (alpha_tokens_total + 1), 1e-4), t = token_offset + i * walk_len + position, refreshed every 10000 tokens
+ * like the binary.  Same kernel and same draws per (walk id, position) as gemhip_sgns_train; over all parts x parts buckets every pair of
+ * TrainModel is trained exactly once. */
+int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64_t nwalks, int32_t walk_len, const void *d_seg, int32_t nseg,
+                           int64_t seg_len, int64_t walk_id_offset, int32_t window, float alpha0, int64_t alpha_tokens_total,
+                           int64_t token_offset, int32_t epoch, uint64_t seed, int32_t flags, int32_t ctx_part, int32_t word_part,
+                           void *dSynPos_part, void *dSynNeg_part, int32_t d, void *stream);
+/* Local walks [walk_lo, walk_hi) copied (device to device, on `stream`) into a caller-owned device buffer. */
+int gemhip_n2v_copy_walks(gemhip_n2v_t h, int64_t walk_lo, int64_t walk_hi, void *d_dst, void *stream);
 
 /* ---------------------------------------------------------------------- HOPE
  * Replaces: gem/embedding/hope.py:23-41 (HOPE.learn_embedding): S = inv(I - beta A) (beta A)

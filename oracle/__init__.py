@@ -2,7 +2,7 @@
 the node2vec binary restated on its own random stream and pinned to its output).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
-this package.  Nothing under gem_amd/ imports it (tests/test_layout.py checks).
+this package.  Nothing under gem_amd/ imports it (tests/test_capi.py::test_product_never_imports_oracle checks).
 """
 import ctypes as C
 import os
@@ -60,9 +60,9 @@ def lib():
         L.oracle_sgns_init.argtypes = [C.c_int64, C.c_int32, C.c_uint64, f32p, f32p]
         L.oracle_sgns_pairs.restype = C.c_int64
         L.oracle_sgns_pairs.argtypes = [C.c_int64, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, i32p, i32p]
-        L.oracle_sgns_train_pairs.restype = None
-        L.oracle_sgns_train_pairs.argtypes = [C.c_int32, C.c_int64, i32p, i32p, C.c_int32, C.c_int32, C.c_int64, f32p, i32p, C.c_float,
-                                              C.c_float, C.c_uint64, C.c_uint64, C.c_int32, f32p, f32p]
+        L.oracle_sgns_train_part.restype = C.c_int64
+        L.oracle_sgns_train_part.argtypes = [C.c_int32, C.c_int64, C.c_int32, i32p, i64p, C.c_int64, C.c_int32, C.c_float, C.c_int64, C.c_int64, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_int64, f32p, i32p, C.c_uint64, C.c_int32, C.c_int32, f32p, f32p]
         for f in ('oracle_philox', 'oracle_alias_build_f32', 'oracle_n2v_alias_rows', 'oracle_n2v_walks', 'oracle_n2v_vocab',
                   'oracle_unigram_build', 'oracle_sgns_train', 'oracle_sgns_init'):
             getattr(L, f).restype = None
@@ -211,8 +211,14 @@ def unigram_build_parts(counts, parts):
     return np.concatenate(UT), np.concatenate(KT), off
 
 
-def sgns_train_pairs_local(pairs_local, UTp, KTp, a0, a1, seed, stream_id, flags, P_part, N_part):
-    """Train a bucket on PARTITION buffers; pairs_local holds local row indices (context // parts, word // parts)."""
-    ctx = np.ascontiguousarray(pairs_local[:, 0], dtype=np.int32); word = np.ascontiguousarray(pairs_local[:, 1], dtype=np.int32)
-    lib().oracle_sgns_train_pairs(P_part.shape[1], len(ctx), _p(ctx, C.c_int32), _p(word, C.c_int32), 1, 0, len(UTp), _p(UTp, C.c_float),
-                                  _p(KTp, C.c_int32), a0, a1, seed, stream_id, flags, _p(P_part, C.c_float), _p(N_part, C.c_float))
+def sgns_train_part(walks, wids, window, alpha0, alpha_tokens_total, token_offset, epoch, parts, ctx_part, word_part, UTp, KTp, seed, flags,
+                    SynPos, SynNeg, walk_id_offset=0, local_rows=False):
+    """One bucket (contexts of partition ctx_part, centre words of partition word_part) of the partitioned schedule in walk order, in place.
+    UTp / KTp: the unigram table restricted to word_part (local indices); wids: global walk id per walk or None.  SynPos / SynNeg: the FULL
+    tables, or (local_rows) the partition buffers of ctx_part / word_part.  Returns the number of pairs trained."""
+    walks = np.ascontiguousarray(walks, dtype=np.int32)
+    wids = None if wids is None else np.ascontiguousarray(wids, dtype=np.int64)
+    return lib().oracle_sgns_train_part(SynPos.shape[1], walks.shape[0], walks.shape[1], _p(walks, C.c_int32), _p(wids, C.c_int64), walk_id_offset,
+                                        window, alpha0, alpha_tokens_total, token_offset, epoch, parts, ctx_part, word_part, len(UTp),
+                                        _p(UTp, C.c_float), _p(KTp, C.c_int32), seed, flags, 1 if local_rows else 0, _p(SynPos, C.c_float),
+                                        _p(SynNeg, C.c_float))

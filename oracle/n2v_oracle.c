@@ -320,12 +320,10 @@ void oracle_sgns_init(int64_t n, int32_t d, uint64_t seed, float *SynPos, float 
 /* ------------------------------------------------------------------------------------------------
  * Partitioned ("episode") SGNS -- restatement of the multi-GPU schedule of gem_amd/multi_gpu.py, NOT of a
  * reference function (the reference is single-process).  Nodes are split into `parts` partitions
- * (node v -> v % parts).  Positive (context, word) pairs are the ones TrainModel forms (same window
- * shrink draw); they are bucketed by (part(context), part(word)); in round s partition g of SynPos meets
- * partition (g+s)%parts of SynNeg, so no two workers ever touch the same row.  Negatives of a pair are drawn
- * from the unigram table RESTRICTED to the word's partition (UTp/KTp: per-partition alias tables over local
- * indices, global id = local*parts + part).  Used by tests to check that this schedule keeps the quality of
- * the sequential algorithm. */
+ * (node v -> v % parts); the (context, word) pairs TrainModel forms fall into parts x parts buckets by
+ * (part(context), part(word)); in round s partition g of SynPos meets partition (g+s)%parts of SynNeg, so no
+ * two workers ever touch the same row.  oracle_sgns_pairs lists the pairs (tests count them);
+ * oracle_sgns_train_part below trains one bucket in walk order. */
 int64_t oracle_sgns_pairs(int64_t nwalks, int32_t walk_len, const int32_t *walks, int32_t window, int32_t epoch,
                           int64_t walk_id_offset, uint64_t seed, int32_t *ctx_out, int32_t *word_out /* may be NULL: count only */)
 {
@@ -351,39 +349,65 @@ int64_t oracle_sgns_pairs(int64_t nwalks, int32_t walk_len, const int32_t *walks
     return np;
 }
 
-/* one bucket: pairs (ctx, word) all with part(word) == part; negatives from that partition's table */
-void oracle_sgns_train_pairs(int32_t d, int64_t npairs, const int32_t *ctx, const int32_t *word, int32_t parts, int32_t part,
-                             int64_t n_local, const float *UTp, const int32_t *KTp, float alpha_begin, float alpha_end,
-                             uint64_t seed, uint64_t stream_id, int32_t flags, float *SynPos, float *SynNeg)
+/* One bucket of the partitioned schedule in WALK order (round 4, gemhip_sgns_train_part / sgns_win_kernel<PART>): oracle_sgns_train above --
+ * TrainModel, ELF @0x40d6a0 -- restricted to the pairs whose context is a node of partition ctx_part and whose centre word is a node of partition
+ * word_part (node v -> partition v % parts); negatives from the unigram table restricted to word_part (UTp / KTp over local indices, global id =
+ * local * parts + word_part).  Same Philox keys per (walk id, position, slot) as the unrestricted function, so parts = 1 reproduces it exactly.
+ * wids: global walk id of every walk in the buffer (NULL: walk_id_offset + index).  local_rows == 0: SynPos / SynNeg are the FULL tables (global
+ * rows); != 0: they are the partition buffers of ctx_part / word_part (row v / parts).  Returns the number of (centre, context) pairs trained. */
+int64_t oracle_sgns_train_part(int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, const int64_t *wids, int64_t walk_id_offset,
+                            int32_t window, float alpha0, int64_t alpha_tokens_total, int64_t token_offset, int32_t epoch, int32_t parts,
+                            int32_t ctx_part, int32_t word_part, int64_t n_local, const float *UTp, const int32_t *KTp, uint64_t seed,
+                            int32_t flags, int32_t local_rows, float *SynPos, float *SynNeg)
 {
     float *neu1e = (float *)malloc(sizeof(float) * (size_t)d);
-    for (int64_t i = 0; i < npairs; ++i) {
-        const float alpha = alpha_begin + ((alpha_end - alpha_begin) / (float)(npairs > 1 ? npairs : 1)) * (float)i;
-        float *xc = SynPos + (size_t)ctx[i] * d;
-        const int32_t w = word[i];
-        for (int32_t k = 0; k < d; ++k) neu1e[k] = 0.0f;
-        for (int32_t j = 0; j < 6; ++j) {
-            int32_t target; float label;
-            if (j == 0) { target = w; label = 1.0f; }
-            else {
-                const u32x4 rn = philox(seed, (uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, TAG_NEG | ((uint32_t)j << 16) | 0x80000000u);
-                const uint32_t slot = mulhi_range(rn.x, (uint32_t)n_local);
-                const int32_t X = (flags & 2) ? KTp[slot] : (int32_t)slot;      /* RndUnigramInt quirk, per partition */
-                const int32_t loc = (u01(rn.y) < UTp[X]) ? X : KTp[X];
-                target = loc * parts + part;
-                if (target == w) continue;
-                label = 0.0f;
+    const int64_t denom = alpha_tokens_total + 1;
+    int64_t npairs = 0;
+    for (int64_t wl = 0; wl < nwalks; ++wl) {
+        const int32_t *walk = walks + wl * walk_len;
+        const int64_t wid = wids ? wids[wl] : walk_id_offset + wl;
+        for (int32_t pos = 0; pos < walk_len; ++pos) {
+            const int64_t t = token_offset + wl * walk_len + pos;
+            const float alpha = sgns_alpha(alpha0, t, denom);
+            const int32_t word = walk[pos];
+            if (word < 0 || word % parts != word_part) continue;
+            const u32x4 rw = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos, TAG_WIN | ((uint32_t)epoch << 8));
+            const int32_t b = (int32_t)(rw.x % (uint32_t)window);
+            for (int32_t a = b; a < window * 2 + 1 - b; ++a) {
+                if (a == window) continue;
+                const int32_t cp = pos - window + a;
+                if (cp < 0 || cp >= walk_len) continue;
+                const int32_t ctx = walk[cp];
+                if (ctx < 0 || ctx % parts != ctx_part) continue;
+                ++npairs;
+                float *xc = SynPos + (size_t)(local_rows ? ctx / parts : ctx) * d;
+                for (int32_t k = 0; k < d; ++k) neu1e[k] = 0.0f;
+                for (int32_t j = 0; j < 6; ++j) {
+                    int32_t target; float label;
+                    if (j == 0) { target = word; label = 1.0f; }
+                    else {
+                        const u32x4 rn = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32),
+                                                (uint32_t)pos | ((uint32_t)a << 16), TAG_NEG | ((uint32_t)epoch << 8) | ((uint32_t)j << 16));
+                        const uint32_t slot = mulhi_range(rn.x, (uint32_t)n_local);
+                        const int32_t X = (flags & 2) ? KTp[slot] : (int32_t)slot;
+                        const int32_t loc = (u01(rn.y) < UTp[X]) ? X : KTp[X];
+                        target = loc * parts + word_part;
+                        if (target == word) continue;
+                        label = 0.0f;
+                    }
+                    float *yt = SynNeg + (size_t)(local_rows ? target / parts : target) * d;
+                    float f = 0.0f;
+                    for (int32_t k = 0; k < d; ++k) f += xc[k] * yt[k];
+                    float g;
+                    if (f > 6.0f) g = (label - 1.0f) * alpha;
+                    else if (f < -6.0f) g = label * alpha;
+                    else g = (label - 1.0f + 1.0f / (1.0f + expf(f))) * alpha;
+                    for (int32_t k = 0; k < d; ++k) { neu1e[k] += g * yt[k]; yt[k] += g * xc[k]; }
+                }
+                for (int32_t k = 0; k < d; ++k) xc[k] += neu1e[k];
             }
-            float *yt = SynNeg + (size_t)target * d;
-            float f = 0.0f;
-            for (int32_t k = 0; k < d; ++k) f += xc[k] * yt[k];
-            float g;
-            if (f > 6.0f) g = (label - 1.0f) * alpha;
-            else if (f < -6.0f) g = label * alpha;
-            else g = (label - 1.0f + 1.0f / (1.0f + expf(f))) * alpha;
-            for (int32_t k = 0; k < d; ++k) { neu1e[k] += g * yt[k]; yt[k] += g * xc[k]; }
         }
-        for (int32_t k = 0; k < d; ++k) xc[k] += neu1e[k];
     }
     free(neu1e);
+    return npairs;
 }

@@ -176,22 +176,36 @@ class OraclePart(OracleN2V):
         Pp[:len(own)] = own
         return torch.from_numpy(Pp), torch.zeros(rows, self.d), torch.zeros(rows, self.d)
 
-    def emit_pairs(self, window, epoch, lo, hi, seed):
-        return torch.from_numpy(oracle.sgns_pairs(self.w[lo:hi], window, epoch, self.lo + lo, seed))
+    def gather_corpus(self, comm, shard_rows, world):
+        mine = torch.full((shard_rows, self.w.shape[1]), -1, dtype=torch.int32)
+        mine[:self.w.shape[0]] = torch.from_numpy(self.w)
+        if world == 1:
+            return mine
+        full = torch.empty((world * shard_rows, self.w.shape[1]), dtype=torch.int32)
+        comm.all_gather_rows(full, mine)
+        return full
 
-    def emit_pairs_bucketed(self, window, epoch, lo, hi, seed, parts):
-        pr = oracle.sgns_pairs(self.w[lo:hi], window, epoch, self.lo + lo, seed)
-        key = (pr[:, 0] % parts) * parts + (pr[:, 1] % parts)
-        order = np.argsort(key, kind='stable')
-        return torch.from_numpy(np.ascontiguousarray(pr[order] // parts)), np.bincount(key, minlength=parts * parts).tolist()   # local rows
+    def upload_table(self, tab):
+        return torch.from_numpy(tab.copy())
 
-    def train_pairs(self, bucket, neg_part, P_part, N_part, a0, a1, seed, stream_id, flags):
-        if bucket.shape[0] == 0:
-            return
-        local = bucket.numpy()                                   # already local row indices
-        j0, j1 = self.off[neg_part], self.off[neg_part + 1]
-        oracle.sgns_train_pairs_local(local, self.UTp[j0:j1], self.KTp[j0:j1], a0, a1, seed, stream_id & 0xffffffff, flags,
-                                      P_part.numpy(), N_part.numpy())
+    def train_part(self, corpus, seg, e, nseg, seg_len, window, alpha0, alpha_total, token_offset, epoch, seed, flags, ctx_part, word_part, P_part, N_part):
+        """gemhip_sgns_train_part restated with the oracle: shard by shard in work-item order."""
+        base, cnt, wid0 = (seg[e][k].numpy() for k in range(3))
+        j0, j1 = self.off[word_part], self.off[word_part + 1]
+        L = corpus.shape[1]
+        for r in range(nseg):
+            if cnt[r] == 0:
+                continue
+            walks = corpus[base[r]:base[r] + cnt[r]].numpy()
+            self.npairs = getattr(self, 'npairs', 0) + oracle.sgns_train_part(
+                walks, None, window, alpha0, alpha_total, token_offset + r * seg_len * L, epoch, self.parts, ctx_part, word_part,
+                self.UTp[j0:j1], self.KTp[j0:j1], seed, flags, P_part.numpy(), N_part.numpy(), walk_id_offset=int(wid0[r]), local_rows=True)
+
+    def pairs(self, reset=True):
+        v = getattr(self, 'npairs', 0)
+        if reset:
+            self.npairs = 0
+        return v
 
 
 def _worker_part(rank, world, port, out):
