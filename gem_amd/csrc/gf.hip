@@ -45,6 +45,7 @@ struct gemhip_gf_plan {
     float *X[2] = {nullptr, nullptr};
     bool own_X = false;
     int cur = 0;                      // X[cur] holds the latest table
+    int rows_per_wave = 0;            // 0 = auto (gf_rows_per_wave), else forced (gemhip_gf_plan_set_rows_per_wave: tests, A/B)
 };
 
 namespace {
@@ -157,10 +158,101 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_kernel(const int32_t *__res
     }
 }
 
+// The same sweep with K consecutive rows per wavefront (large levels; round 4).  A wave that owns ONE row spends its life in a chain of dependent
+// round trips -- row id and edge offsets, then (col, w) and X_i, then the neighbour rows, then the store -- and only the third moves data: at SBM
+// 1M/10M the kernel reached 3.3 TB/s of real traffic (0.53 of a copy).  Here lane k of a wave fetches the id and the offsets of its k-th row in ONE
+// load, and while row k is trained the (col, w) chunk and X_i of row k+1 are already in flight, so the only exposed latency per row is the gather of
+// its neighbour rows.  Same gf_apply_edge, same edge order inside a row: bit-identical to gf_sweep_kernel (rows of one level are independent).
+template <int VEC, int NV>
+__global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
+                                                                 const uint32_t *__restrict__ col, const float *__restrict__ w,
+                                                                 const float *Xold, float *Xnew, int64_t row0, int64_t nrows, int d,
+                                                                 float eta, float regu, int K)
+{
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int64_t first = (xcd_contiguous_block(blockIdx.x, gridDim.x) * GF_WAVES + wave) * K;
+    if (first >= nrows) return;
+    const int nk = (int)((nrows - first) < (int64_t)K ? (nrows - first) : (int64_t)K);
+    int32_t rv = 0; int64_t pa = 0, pb = 0;
+    if (lane < nk) { rv = rows[row0 + first + lane]; pa = ptr[row0 + first + lane]; pb = ptr[row0 + first + lane + 1]; }
+    auto lane64 = [&](int64_t v, int k) -> int64_t {
+        const uint32_t lo = bcast_lane((uint32_t)v, k), hi = bcast_lane((uint32_t)((uint64_t)v >> 32), k);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    constexpr int DEEP = (GF_PREFETCH_DEEP / NV) >= GF_PREFETCH ? (GF_PREFETCH_DEEP / NV) : GF_PREFETCH;
+    // row 0: first (col, w) chunk and X_i
+    int32_t i_n = bcast_lane(rv, 0);
+    int64_t e0_n = lane64(pa, 0), e1_n = lane64(pb, 0);
+    int cnt_n = (int)((e1_n - e0_n) < (int64_t)WAVE ? (e1_n - e0_n) : (int64_t)WAVE);
+    uint32_t cj_n = lane < cnt_n ? col[e0_n + lane] : 0u;
+    float wj_n = lane < cnt_n ? w[e0_n + lane] : 0.f;
+    float xi_n[NV][VEC];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) load_row<VEC>(Xold + (int64_t)i_n * d, d, lane, c, xi_n[c]);
+    for (int k = 0; k < nk; ++k) {
+        const int32_t i = i_n;
+        const int64_t e0 = e0_n, e1 = e1_n;
+        const int cnt0 = cnt_n;
+        const uint32_t cj0 = cj_n;
+        const float wj0 = wj_n;
+        float xi[NV][VEC];
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xi[c][v] = xi_n[c][v];
+        if (k + 1 < nk) {                                // the next row's inputs travel while this row is trained
+            i_n = bcast_lane(rv, k + 1);
+            e0_n = lane64(pa, k + 1); e1_n = lane64(pb, k + 1);
+            cnt_n = (int)((e1_n - e0_n) < (int64_t)WAVE ? (e1_n - e0_n) : (int64_t)WAVE);
+            cj_n = lane < cnt_n ? col[e0_n + lane] : 0u;
+            wj_n = lane < cnt_n ? w[e0_n + lane] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) load_row<VEC>(Xold + (int64_t)i_n * d, d, lane, c, xi_n[c]);
+        }
+        if (cnt0 == WAVE) gf_chunk<VEC, NV, DEEP>(xi, cj0, wj0, cnt0, Xold, Xnew, d, lane, eta, regu);
+        else if (cnt0 > 0) gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj0, wj0, cnt0, Xold, Xnew, d, lane, eta, regu);
+        for (int64_t e = e0 + WAVE; e < e1; e += WAVE) {
+            const int cnt = (int)((e1 - e) < (int64_t)WAVE ? (e1 - e) : (int64_t)WAVE);
+            const uint32_t cj = lane < cnt ? col[e + lane] : 0u;
+            const float wj = lane < cnt ? w[e + lane] : 0.f;
+            if (cnt == WAVE) gf_chunk<VEC, NV, DEEP>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
+            else gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
+        }
+        float *po = Xnew + (int64_t)i * d;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int idx = (c * WAVE + lane) * VEC;
+            if (idx < d) {
+                if constexpr (VEC == 2) *reinterpret_cast<float2 *>(po + idx) = make_float2(xi[c][0], xi[c][1]);
+                else po[idx] = xi[c][0];
+            }
+        }
+    }
+}
+
+// rows per wavefront of a level with `nrows` rows: 1 (gf_sweep_kernel) until every resident wave slot of the chip (256 CUs x 32 waves) has two rows
+// to work on, then up to GEMHIP_GF_ROWS_PER_WAVE (default 8; read once): a level of 946 188 rows (SBM 1M/10M) runs 8 rows per wave
+int gf_rows_per_wave(int64_t nrows)
+{
+    static const int kmax = getenv("GEMHIP_GF_ROWS_PER_WAVE") ? std::max(1, std::min(64, atoi(getenv("GEMHIP_GF_ROWS_PER_WAVE")))) : 8;
+    const int64_t k = nrows / (2 * 256 * 32);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(k, kmax));
+}
+
 template <int VEC, int NV>
 void launch_sweep(const gemhip_gf_plan *p, int64_t row0, int64_t nrows, const float *Xold, float *Xnew, float eta, float regu,
                   hipStream_t s)
 {
+    const int K = p->rows_per_wave > 0 ? p->rows_per_wave : gf_rows_per_wave(nrows);
+    if (K > 1) {
+        const int64_t waves = (nrows + K - 1) / K;
+        const int64_t blocks = (waves + GF_WAVES - 1) / GF_WAVES;
+        const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
+        hipLaunchKernelGGL((gf_sweep_rows_kernel<VEC, NV>), dim3((unsigned)grid), dim3(GF_BLOCK), 0, s, p->d_rows, p->d_ptr, p->d_col,
+                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K);
+        return;
+    }
     const int64_t blocks = (nrows + GF_WAVES - 1) / GF_WAVES;
     // round the grid up to a multiple of 8 so the XCD-contiguous map covers every slot
     const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
@@ -581,6 +673,13 @@ extern "C" int gemhip_gf_plan_sweeps(gemhip_gf_plan_t p, int32_t nsweeps, float 
         p->cur ^= 1;
     }
     GEMHIP_CHECK(hipGetLastError());
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_gf_plan_set_rows_per_wave(gemhip_gf_plan_t p, int32_t rows_per_wave)
+{
+    GEMHIP_REQUIRE(p && rows_per_wave >= 0 && rows_per_wave <= 64, "gf_plan_set_rows_per_wave: 0 (auto) .. 64");
+    p->rows_per_wave = rows_per_wave;
     return GEMHIP_OK;
 }
 

@@ -105,6 +105,10 @@ int gemhip_gf_plan_init_embedding(gemhip_gf_plan_t plan, uint64_t seed, float sc
 /* Enqueue `nsweeps` sweeps (one sweep = gf.cpp:152-164 over all edges). */
 int gemhip_gf_plan_sweeps(gemhip_gf_plan_t plan, int32_t nsweeps, float eta,
                           float regu, void *stream);
+/* Source rows a wavefront trains back to back inside one sweep launch (1 = one row per wavefront, gf_sweep_kernel; K > 1 =
+ * gf_sweep_rows_kernel, which has the next row's inputs in flight while a row is trained); 0 = auto (by level size).  Every
+ * setting gives bit-identical tables -- rows of a level are independent.  No reference counterpart (gf.cpp is one thread). */
+int gemhip_gf_plan_set_rows_per_wave(gemhip_gf_plan_t plan, int32_t rows_per_wave);
 int gemhip_gf_plan_get_embedding(gemhip_gf_plan_t plan, float *X_host);
 /* Device pointer of the CURRENT table (the one holding the latest sweep). */
 int gemhip_gf_plan_current(gemhip_gf_plan_t plan, void **dX);

@@ -197,3 +197,31 @@ def test_hub_kernel_is_bit_identical_to_the_wave_per_row_kernel(d, sbm1024, kara
                 monkeypatch.setenv(k, v)
             out[tag] = hip_train(n, src, dst, w, d, 0.01, 0.01, sweeps, X0)[0]
         assert np.array_equal(out['hub'], out['plain'])
+
+
+@pytest.mark.parametrize('d', [7, 128, 256])
+@pytest.mark.parametrize('k', [2, 5, 8, 64])
+def test_rows_per_wave_kernel_is_bit_identical(d, k, sbm1024, karate):
+    """gf_sweep_rows_kernel (K consecutive rows per wavefront, the next row's (col, w) chunk and X_i in flight while a row is trained: what large
+    levels run) applies the same gf_apply_edge in the same edge order as gf_sweep_kernel: bit-identical tables for every K, including K that does not
+    divide the level, multi-level schedules (karate) and rows of more than one 64-edge chunk (the dense graph)."""
+    rs = np.random.RandomState(9)
+    dense_src = np.repeat(np.arange(40, dtype=np.int32), 200); dense_dst = rs.randint(0, 400, dense_src.size).astype(np.int32)     # 200 edges per source row
+    for name, (n, src, dst, w) in (('sbm1024', edge_arrays(sbm1024)[:4]), ('karate', edge_arrays(karate)[:4]), ('dense', (400, dense_src, dense_dst, None))):
+        X0 = (0.01 * np.random.RandomState(3).randn(n, d)).astype(np.float32)
+        L = _hip.lib()
+        out = {}
+        for kk in (1, k):
+            plan = C.c_void_p()
+            _hip.check(L.gemhip_gf_plan_create(n, len(src), _hip.ptr(_hip.as_i32(src), C.c_int32), _hip.ptr(_hip.as_i32(dst), C.c_int32),
+                                               _hip.ptr(_hip.as_f32(w), C.c_float), d, 0, n, C.byref(plan)))
+            _hip.check(L.gemhip_gf_plan_set_embedding(plan, _hip.ptr(X0, C.c_float)))
+            _hip.check(L.gemhip_gf_plan_set_rows_per_wave(plan, kk))
+            _hip.check(L.gemhip_gf_plan_sweeps(plan, 4, 0.02, 0.01, None))
+            X = np.empty_like(X0)
+            _hip.check(L.gemhip_gf_plan_get_embedding(plan, _hip.ptr(X, C.c_float)))
+            _hip.check(L.gemhip_gf_plan_destroy(plan))
+            out[kk] = X
+        assert np.array_equal(out[1], out[k]), name
+        if name != 'dense':
+            assert_close(out[k], oracle.gf_train_f32(n, src, dst, w, d, 0.02, 0.01, 4, X0))
