@@ -382,18 +382,20 @@ static const EigOps &eig_ops()
 // back-transformation of the wanted vectors).  GEMHIP_EIG_THREADS (read once) or gemhip_set_host_threads(); default
 // min(4, half the cores this process may run on).  Threads are created per call and joined before it returns: nothing outlives
 // the call, so fork() in the host program (bench.py's CPU baselines are subprocesses) never meets a live pool.
-int g_eig_threads = -1;
+static std::atomic<int> g_eig_threads{-1};       // (atomic: gemhip_set_host_threads may run beside a solve; every phase reads its T once)
 static int eig_threads()
 {
-    if (g_eig_threads < 0) {
+    int cur = g_eig_threads.load(std::memory_order_relaxed);
+    if (cur < 0) {
         int t = 4;
         if (const char *e = getenv("GEMHIP_EIG_THREADS")) t = atoi(e);
         cpu_set_t set;
         CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof(set), &set) == 0) t = std::min(t, std::max(1, CPU_COUNT(&set) / 2));   // spin barriers want idle cores
-        g_eig_threads = std::max(1, std::min(t, 16));
+        cur = std::max(1, std::min(t, 16));
+        g_eig_threads.store(cur, std::memory_order_relaxed);
     }
-    return g_eig_threads;
+    return cur;
 }
 
 // Sense-reversing barrier: a step of the reduction is a few microseconds of work per thread, far below what a futex
@@ -973,6 +975,7 @@ struct Hope {
     struct CoefSlot { float *h = nullptr, *d = nullptr; size_t elems = 0; hipEvent_t done = nullptr; };
     CoefSlot coef[8]; unsigned coef_next = 0;                // pinned staging ring for the small host matrices tsgemm() takes
     float *ws[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t ws_elems[7] = {0, 0, 0, 0, 0, 0, 0};   // eigen-path workspace, kept across solves
+    float *d_cm = nullptr;                                   // 512 floats: column arg-max signs of the output step
     int err = 0;
     ~Hope()
     {
@@ -980,6 +983,7 @@ struct Hope {
         for (hipEvent_t e : sp_pool) hipEventDestroy(e);
         for (CoefSlot &c : coef) { if (c.h) hipHostFree(c.h); hipFree(c.d); if (c.done) hipEventDestroy(c.done); }
         for (float *w : ws) hipFree(w);
+        hipFree(d_cm);
     }
 };
 
@@ -1423,8 +1427,8 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
         // deterministic sign: largest-magnitude entry of each left vector positive (svds signs are arbitrary; the first such row on ties).  The
         // arg-maxima are taken on the device from the compact [n][k] product, the signs go into the coefficients and the product is formed again
         // (one more 36 us GEMM; rounds 1-2 flipped the n x k outputs in two host passes -- ~10 ms at 100k x 64, and impossible for device outputs)
-        float *d_cm = nullptr;
-        HOPE_TRY(H, hipMalloc((void **)&d_cm, 512 * sizeof(float)));
+        if (!H.d_cm) HOPE_TRY(H, hipMalloc((void **)&H.d_cm, 512 * sizeof(float)));       // kept in the plan: no hipMalloc / hipFree (a device sync) per solve
+        float *d_cm = H.d_cm;
         const std::vector<double> &Cref = U_sqrtS ? Cu : Cv;
         if (!H.err) tsgemm(H, U_sqrtS ? Ball : Vall, ldm, mc, Cref, k, 1.0f, nullptr, 0, Tmp, k);           // compact [n][k]
         std::vector<float> cm(k, 0.f);
@@ -1445,7 +1449,6 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
             tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, k);
         } else if (any) tsgemm(H, Vall, ldm, mc, Cv, k, 1.0f, nullptr, 0, Tmp, k);
         HOPE_TRY(H, hipMemcpy(V_sqrtS, Tmp, (size_t)n * k * sizeof(float), hipMemcpyDefault /* host (gemhip_hope_plan_solve) or device (.._solve_device) destination */));
-        if (d_cm) hipFree(d_cm);
     }
     float ms = 0.f;
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
@@ -2098,7 +2101,7 @@ extern "C" int gemhip_set_sym_eig_callback(int (*fn)(int32_t, double *, double *
 extern "C" int gemhip_set_host_threads(int32_t threads, int32_t *in_effect_out)
 {
     GEMHIP_REQUIRE(threads <= 16, "set_host_threads: at most 16 threads (got %d)", threads);
-    g_eig_threads = threads >= 1 ? threads : -1;          // <= 0: back to the default (GEMHIP_EIG_THREADS or min(4, usable cores))
+    g_eig_threads.store(threads >= 1 ? threads : -1, std::memory_order_relaxed);          // <= 0: back to the default (GEMHIP_EIG_THREADS or min(4, usable cores))
     const int t = eig_threads();
     if (in_effect_out) *in_effect_out = t;
     return GEMHIP_OK;

@@ -728,7 +728,14 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
     bool allc = R >= window;
     if (!deterministic) {
         P.delta = mode != 0;
-        const double w_steps = (P.delta && kn.reload) ? 0.4 : (double)(kn.prefetch + 1);
+        // the (reload, prefetch) pair the launcher will actually run: launches WITHOUT reload-on-update and with prefetch distance 1 exist for the
+        // benchmark shape only (d == 128, whole window cached, no hot rows -- launch_sgns_win's AB instantiations); every other Hogwild launch is
+        // reload-on-update with prefetch distance 2 whatever the knobs say, and the width rule has to be computed for THAT kernel
+        auto w_steps_of = [&](bool all_cached) -> double {
+            const bool ab_shape = d == 128 && all_cached;
+            const bool reload_eff = P.delta && (kn.reload || !ab_shape);
+            return reload_eff ? 0.4 : (double)((ab_shape ? kn.prefetch : 2) + 1);
+        };
         const double n_eff = vs.n_eff > 0.0 ? vs.n_eff : (double)n;
         // graphs below 8192 nodes: the window rows themselves (2R+1 per wavefront) are a sizeable part of the table -- SBM-1024 (d=16) loses
         // 3.5 % of MAP at 8 wavefronts and nothing at 2: bound the open fraction of the table at 1/16
@@ -740,10 +747,12 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         auto width = [&](bool all_cached) -> int64_t {
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta, all_cached) + 512)));   // 184 VGPRs: 2 per SIMD
             const int64_t w_dev = std::min<int64_t>(256 * per_cu, nwalks);
+            const double w_steps = w_steps_of(all_cached);
+            const bool reload_eff = w_steps < 1.0;
             int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
             // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
             // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
-            if (P.delta && kn.reload && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(w_dev, w_act) && vs.total > 0.0) {
+            if (reload_eff && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(w_dev, w_act) && vs.total > 0.0) {
                 for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
                     const double thr = std::max(2.0, std::ceil(vs.total / ((double)(wtry - 1) * (2 * R + 1))));
                     if (0.015 * vs.n_eff_cold(thr) / (5.0 * w_steps) >= (double)wtry) { hog_rho = wtry; break; }
