@@ -44,6 +44,8 @@ def lib():
         L.oracle_gf_train_f64.restype = None
         L.oracle_gf_objective.argtypes = [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, f32p, f64p]
         L.oracle_gf_objective.restype = None
+        L.oracle_gf_cpp_init.argtypes = [C.c_uint32, C.c_int64, C.c_int32, f32p]
+        L.oracle_gf_cpp_init.restype = None
         i64p, u32p = C.POINTER(C.c_int64), C.POINTER(C.c_uint32)
         L.oracle_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p]
         L.oracle_perm.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
@@ -94,6 +96,19 @@ def gf_train_f64(n, src, dst, w, d, eta, regu, max_iter, X0):
     lib().oracle_gf_train_f64(n, len(src), _p(src, C.c_int32), _p(dst, C.c_int32), _p(w, C.c_double), d, eta, regu,
                               max_iter, _p(X, C.c_double))
     return X
+
+
+def gf_cpp_init(seed, n, d):
+    """gf.cpp:41-52 init_embedding() for the 32-bit seed the binary derives from its clock: float32 [n, d]."""
+    X = np.empty((n, d), dtype=np.float32)
+    lib().oracle_gf_cpp_init(int(seed) & 0xffffffff, n, d, _p(X, C.c_float))
+    return X
+
+
+def gf_cpp_seed(fake_clock):
+    """The `unsigned seed` of gf.cpp:46 for GEM_FAKE_CLOCK="<sec>[.<nsec>]": nanoseconds since the epoch truncated to 32 bits."""
+    sec, _, nsec = str(fake_clock).partition('.')
+    return (int(sec) * 1000000000 + int(nsec or 0)) & 0xffffffff
 
 
 def gf_objective(n, src, dst, w, d, X):

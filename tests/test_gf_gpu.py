@@ -225,3 +225,18 @@ def test_rows_per_wave_kernel_is_bit_identical(d, k, sbm1024, karate):
         assert np.array_equal(out[1], out[k]), name
         if name != 'dense':
             assert_close(out[k], oracle.gf_train_f32(n, src, dst, w, d, 0.02, 0.01, 4, X0))
+
+
+@pytest.mark.parametrize('case', ['karate', 'sbm1024'])
+def test_hip_equals_the_emb_file_the_gf_cpp_binary_wrote(case, request):
+    """The reference's NATIVE path end to end: gf.cpp's binary, run deterministically (frozen clock, scripts/make_golden_gf_cpp.py), wrote
+    tests/golden/gf_cpp_binary_<case>.emb; from the same initial table (gf.cpp:41-52 restated, pinned to the binary on the CPU tier) the HIP sweeps
+    land on that file within the fp32 dot-product tolerance plus half a unit of its sixth printed digit."""
+    meta = json.load(open(golden_path('gf_cpp_binary.json')))[case]
+    G = request.getfixturevalue(meta['graph'])
+    n, src, dst, w, _ = edge_arrays(G)
+    X0 = oracle.gf_cpp_init(meta['seed32'], n, meta['d'])
+    X, _ = hip_train(n, src, dst, None, meta['d'], meta['eta'], meta['regu'], meta['max_iter'], X0)
+    want = np.loadtxt(golden_path('gf_cpp_binary_%s.emb' % case), skiprows=1)[:, 1:]
+    scale = float(np.abs(want).max())
+    assert float(np.abs(X - want).max()) <= RTOL * scale + 0.5e-5 * scale

@@ -72,3 +72,53 @@ def test_reference_golden_gf_statistics(karate, sbm1024):
     X0 = 0.01 * np.random.RandomState(4).randn(n, 128)
     X = oracle.gf_train_f32(n, src, dst, w, 128, 1e-4, 1.0, 20, X0)
     assert abs(np.mean(tgt - X)) < 1e-3
+
+
+# ---- the reference's NATIVE path, pinned at the vector level (VERDICT r3 missing #4): gf.cpp's own binary, made deterministic by freezing the clock
+# its generator is seeded from (oracle/shim/faketime.c), wrote tests/golden/gf_cpp_binary_*.emb (scripts/make_golden_gf_cpp.py)
+def _emb_lines(path):
+    with open(path) as fh:
+        return fh.read().splitlines()
+
+
+def _as_emb_lines(X):
+    """saveEmbToTxt (gf.cpp:115-129): "n d", then "id v0 v1 ..." with the default ostream precision (6 significant digits)."""
+    n, d = X.shape
+    return ['%d %d' % (n, d)] + ['%d ' % i + ' '.join('%g' % float(v) for v in X[i]) for i in range(n)]
+
+
+@pytest.mark.parametrize('case', ['karate_init', 'karate', 'sbm1024'])
+def test_gf_cpp_binary_output_is_reproduced_to_the_printed_digit(case, request):
+    """oracle_gf_cpp_init (gf.cpp:41-52 restated from libstdc++: minstd_rand0 + polar normal_distribution<float>) followed by oracle_gf_train_f32
+    (gf.cpp:152-164) == the .emb file the reference binary wrote, character for character: the fp32 native path is pinned to the binary, not to a
+    reading of its source."""
+    import json
+    meta = json.load(open(golden_path('gf_cpp_binary.json')))[case]
+    G = request.getfixturevalue(meta['graph'])
+    n, src, dst, w, _ = edge_arrays(G)
+    assert (n, len(src)) == (meta['n'], meta['edges']) and meta['weights_all_one']
+    assert oracle.gf_cpp_seed(meta['clock']) == meta['seed32']
+    X0 = oracle.gf_cpp_init(meta['seed32'], n, meta['d'])
+    X = oracle.gf_train_f32(n, src, dst, None, meta['d'], meta['eta'], meta['regu'], meta['max_iter'], X0)
+    want = _emb_lines(golden_path('gf_cpp_binary_%s.emb' % case))
+    got = _as_emb_lines(X)
+    assert len(got) == len(want)
+    bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+    assert not bad, (bad[:3], got[bad[0]], want[bad[0]])
+
+
+def test_gf_cpp_binary_rerun_equals_its_golden(tmp_path, karate):
+    """Where the reference binary exists (the build container): running it again under the frozen clock rewrites the golden byte for byte."""
+    import json, os, subprocess
+    if not (os.path.exists(oracle.REF_GF) and os.path.exists(oracle.REF_FAKETIME)):
+        pytest.skip('oracle/_ref/gf not built here')
+    meta = json.load(open(golden_path('gf_cpp_binary.json')))['karate']
+    n, src, dst, w, _ = edge_arrays(karate)
+    gfile, efile = str(tmp_path / 'g.txt'), str(tmp_path / 'g.emb')
+    with open(gfile, 'w') as fh:
+        fh.write('%d\n%d\n' % (n, len(src)))
+        for i, j in zip(src.tolist(), dst.tolist()):
+            fh.write('%d %d %f\n' % (i, j, 1.0))
+    subprocess.check_call([oracle.REF_GF, gfile, efile] + meta['argv_after_files'],
+                          env=dict(os.environ, LD_PRELOAD=oracle.REF_FAKETIME, GEM_FAKE_CLOCK=meta['clock']))
+    assert open(efile).read() == open(golden_path('gf_cpp_binary_karate.emb')).read()
