@@ -37,6 +37,10 @@ _SIGS = {
     'gemhip_last_call_phases': (C.c_int, [f64p]),
     'gemhip_gf_train': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_int32,
                                   f32p, f64p]),
+    'gemhip_gf_train_multi': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, i32p, f32p, f64p]),
+    'gemhip_n2v_train_multi': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                         C.c_uint64, C.c_int32, C.c_int32, i32p, C.c_int32, f32p, f64p]),
+    'gemhip_rccl_selftest': (C.c_int, [C.c_int32, i32p, C.c_int64, f64p]),
     'gemhip_gf_plan_create': (C.c_int, [C.c_int64, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_int64, C.c_int64,
                                         C.POINTER(C.c_void_p)]),
     'gemhip_gf_plan_destroy': (C.c_int, [C.c_void_p]),

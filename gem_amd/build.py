@@ -54,7 +54,7 @@ def build(force=False, verbose=True):
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']     # (multi.hip loads RCCL with dlopen)
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -379,15 +379,18 @@ static const EigOps &eig_ops()
 }
 
 // Host threads for the O(n^3) phases of the eigensolver (the reduction's matrix-vector product and rank-2 update, the
-// back-transformation of the wanted vectors).  GEMHIP_EIG_THREADS (read once) or gemhip_set_host_threads(); default
-// min(4, half the cores this process may run on).  Threads are created per call and joined before it returns: nothing outlives
+// back-transformation of the wanted vectors).  GEMHIP_EIG_THREADS (read once) or gemhip_set_host_threads(); default 1 (see below), never more
+// than half the cores this process may run on.  Threads are created per call and joined before it returns: nothing outlives
 // the call, so fork() in the host program (bench.py's CPU baselines are subprocesses) never meets a live pool.
 static std::atomic<int> g_eig_threads{-1};       // (atomic: gemhip_set_host_threads may run beside a solve; every phase reads its T once)
 static int eig_threads()
 {
     int cur = g_eig_threads.load(std::memory_order_relaxed);
     if (cur < 0) {
-        int t = 4;
+        // default ONE thread: on the MI355X host the threaded reduction measured SLOWER than one core (directed SBM 100k/1M solve, 9 projected
+        // 448 x 448 problems: 39.7 ms of host eigensolves at 1 thread, 52.8 ms at 4 -- profiles/r04_hope_directed_eig_threads.json; the spin
+        // barriers of a ~3 us step lose to the host's scheduling noise; the build container measured 1.8x FASTER at 4).  GEMHIP_EIG_THREADS opts in.
+        int t = 1;
         if (const char *e = getenv("GEMHIP_EIG_THREADS")) t = atoi(e);
         cpu_set_t set;
         CPU_ZERO(&set);

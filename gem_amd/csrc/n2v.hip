@@ -95,6 +95,7 @@ struct SgnsKnobs {
     int32_t prefetch = 2;             // pairs whose negative rows are requested ahead: 2 (default) or 1 (d == 64/128/256.., whole window cached)
     int32_t reload = 1;               // Hogwild launches: update negative rows as they are at store time (second fetch) and the centre row by atomic add
     int32_t hot_count = -1;           // nodes with at least this many tokens never enter the LDS window: -1 auto (tokens / ((W-1) x (2R+1))), 0 off
+    double duty = 1.0;                // fraction of a wavefront's time spent in pair steps (negative rows open); < 1 only for the buckets of the partitioned schedule
 };
 // ... and what a launch of TrainModel over `nwalks` walks then looks like (pure host arithmetic: gemhip_sgns_plan_launch exposes it to the CPU tests)
 struct SgnsLaunchPlan {
@@ -749,13 +750,13 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
             const int64_t w_dev = std::min<int64_t>(256 * per_cu, nwalks);
             const double w_steps = w_steps_of(all_cached);
             const bool reload_eff = w_steps < 1.0;
-            int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps)));
+            int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps * kn.duty)));
             // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
             // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
             if (reload_eff && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(w_dev, w_act) && vs.total > 0.0) {
                 for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
                     const double thr = std::max(2.0, std::ceil(vs.total / ((double)(wtry - 1) * (2 * R + 1))));
-                    if (0.015 * vs.n_eff_cold(thr) / (5.0 * w_steps) >= (double)wtry) { hog_rho = wtry; break; }
+                    if (0.015 * vs.n_eff_cold(thr) / (5.0 * w_steps * kn.duty) >= (double)wtry) { hog_rho = wtry; break; }
                 }
             }
             const int64_t hog_win = kn.max_waves > 0 ? kn.max_waves : n >= 8192 ? hog_rho : std::min(hog_rho, hog_tiny);
@@ -883,6 +884,14 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     vs.total = h->vs.total; vs.max = h->vs.max;
     SgnsKnobs kn = h->kn;
     kn.prefetch = 2; kn.reload = 1;
+    // Duty cycle.  The rule bounds the negative rows that are OPEN at any time (W x 5 x w of them).  A wavefront of a bucket launch spends only part of
+    // its time in pair steps: per walk it has walk_len x (window + 1) x 0.95 / parts^2 pairs to train but still 2 x walk_len / parts rows (the contexts and
+    // the centre words of its two partitions) to fetch and return, each an exposed round trip of ~0.7 pair steps.  With that fraction f of the time in
+    // pair steps the same bound on open rows allows W / f wavefronts (f = 0.88 for one partition -- left at 1, the validated rule --, 0.65 at 4, 0.47 at 8).
+    if (h->parts > 1) {
+        const double pairs_pp = (double)walk_len * (window + 1) * 0.95 / ((double)h->parts * h->parts), rows_pp = 2.0 * walk_len / h->parts;
+        kn.duty = pairs_pp / (pairs_pp + 0.7 * rows_pp);
+    }
     const SgnsLaunchPlan P = plan_sgns_launch(vs, kn, (int64_t)A.n, d, window, walk_len, nwalks, flags);
     GEMHIP_REQUIRE(P.window, "sgns_train_part: d=%d window=%d walk_len=%d do not fit the LDS window kernel", d, window, walk_len);
     A.nwaves = (int32_t)P.waves; A.cache_radius = P.R; A.hot_thr = P.hot_thr;

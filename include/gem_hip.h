@@ -261,6 +261,31 @@ int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64_t nwalks, 
 /* Local walks [walk_lo, walk_hi) copied (device to device, on `stream`) into a caller-owned device buffer. */
 int gemhip_n2v_copy_walks(gemhip_n2v_t h, int64_t walk_lo, int64_t walk_hi, void *d_dst, void *stream);
 
+/* ------------------------------------------------------------ N GPUs, one process (RCCL over xGMI)
+ * the one-shot drop-ins above with an `n_gpus` argument.  The reference has no multi-device path; these shard the way
+ * north_star prescribes -- GF by source row, node2vec by start node -- inside ONE host process that drives n_gpus devices, with the
+ * collectives on RCCL (loaded with dlopen on first use: GEMHIP_E_UNSUPPORTED when librccl.so.1 is not there; the single-GPU entry points
+ * never need it).  devices: n_gpus device ordinals, NULL = 0 .. n_gpus-1.  A list that names the SAME device n_gpus times runs the ranks as
+ * VIRTUAL ranks on that device (test mode: RCCL refuses two ranks on one GPU, the collectives become device-to-device copies; sharding,
+ * schedule and kernels are the production ones).  gem_amd/multi_gpu.py is the one-process-per-GPU form of the same schedules.
+ *
+ * gemhip_gf_train_multi: gemhip_gf_train with the source rows in n_gpus contiguous blocks, an in-place all-gather of the owned row blocks
+ * after EVERY sweep -- bit-identical to one GPU (needs the firing sources in ascending id order when n_gpus > 1: GEMHIP_E_UNSUPPORTED
+ * otherwise).  stats (optional, 8 doubles): {sweep + exchange seconds, updates per sweep, rows per sweep, exchange bytes per rank per
+ * sweep, n_gpus, virtual (0/1), 0, 0}.
+ * gemhip_n2v_train_multi: gemhip_n2v_train with walks by start-node shard, an all-reduce of the token counts, one all-gather of the walk
+ * shards and the partitioned-table schedule (`episodes` slices of every shard; rank g trains bucket (g, (g+s) % n_gpus) of each with
+ * gemhip_sgns_train_part and passes its SynNeg partition around a ring).  stats (optional, 8 doubles): {walk + vocabulary + gather
+ * seconds, training seconds, tokens, pairs trained, ring bytes per rank per round, n_gpus, virtual (0/1), bucket launches per rank}.
+ * gemhip_rccl_selftest: communicator create -> all-gather / all-reduce / ring shift of `bytes` per rank on known patterns, every word
+ * checked -> destroy. */
+int gemhip_gf_train_multi(int64_t n, int64_t m, const int32_t *src, const int32_t *dst, const float *w, int32_t d, float eta,
+                          float regu, int32_t max_iter, int32_t n_gpus, const int32_t *devices, float *X_inout, double *stats);
+int gemhip_n2v_train_multi(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, int32_t d,
+                           int32_t walk_len, int32_t num_walks, int32_t window, int32_t epochs, float p, float q, uint64_t seed,
+                           int32_t flags, int32_t n_gpus, const int32_t *devices, int32_t episodes, float *X_out, double *stats);
+int gemhip_rccl_selftest(int32_t n_gpus, const int32_t *devices, int64_t bytes, double *seconds);
+
 /* ---------------------------------------------------------------------- HOPE
  * Replaces: gem/embedding/hope.py:23-41 (HOPE.learn_embedding): S = inv(I - beta A) (beta A)
  * as dense numpy matrices (:28-31) and u, s, vt = scipy.sparse.linalg.svds(S, k=d//2) (:33).

@@ -1,0 +1,134 @@
+"""GPU tier: the N-GPU entry points of the C ABI (gem_amd/csrc/multi.hip: gemhip_gf_train_multi, gemhip_n2v_train_multi, gemhip_rccl_selftest).
+The test box has ONE GPU: n_gpus = 1 runs the real RCCL communicator (1-rank collectives), n_gpus > 1 runs VIRTUAL ranks on device 0 (a device list
+that repeats the device: collectives become copies, sharding / schedule / kernels are the production code)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from gem_amd import _hip
+from gem_amd.embedding.node2vec import node2vec
+from gem_amd.evaluation import reconstruction as gr
+from gem_amd.graph import edge_arrays, sbm_graph, to_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _devs(k):
+    return None if k == 1 else (C.c_int32 * k)(*([0] * k))
+
+
+def test_rccl_selftest_one_rank_and_virtual_ranks():
+    """Communicator create -> all-gather / all-reduce / ring shift -> destroy.  One rank goes through RCCL itself (ncclCommInitAll on one device; a
+    1-rank all-gather is a copy, the ring shift a self send/recv); 2 and 4 virtual ranks check the rank arithmetic of the three collectives."""
+    L = _hip.lib()
+    sec = C.c_double()
+    _hip.check(L.gemhip_rccl_selftest(1, None, 1 << 20, C.byref(sec)))
+    assert sec.value > 0
+    for k in (2, 4):
+        _hip.check(L.gemhip_rccl_selftest(k, _devs(k), 4096, None))
+    assert L.gemhip_rccl_selftest(2, None, 4096, None) != 0            # two REAL ranks need two GPUs: an error, never a silent 1-GPU run
+    assert b'device 1 of 1' in L.gemhip_last_error()
+    assert L.gemhip_rccl_selftest(0, None, 4096, None) != 0
+
+
+@pytest.mark.parametrize('ranks', [1, 2, 4])
+def test_gf_train_multi_is_bit_identical_to_one_gpu(ranks):
+    """Source rows in `ranks` contiguous blocks, all-gather of the owned blocks after every sweep == gemhip_gf_train, bit for bit (n not divisible by
+    the rank count: padded blocks); and == the oracle to the usual tolerance."""
+    g = sbm_graph(1001, 10000, 4, seed=3)
+    n, src, dst, w, _ = edge_arrays(g)
+    X0 = (0.05 * np.random.RandomState(0).randn(n, 32)).astype(np.float32)
+    L = _hip.lib()
+    a = X0.copy(); b = X0.copy()
+    _hip.check(L.gemhip_gf_train(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, 32, 0.05, 0.01, 6, _hip.ptr(a, C.c_float), None))
+    st = (C.c_double * 8)()
+    _hip.check(L.gemhip_gf_train_multi(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, 32, 0.05, 0.01, 6, ranks, _devs(ranks),
+                                       _hip.ptr(b, C.c_float), st))
+    assert np.array_equal(a, b)
+    assert st[4] == ranks and st[5] == (1.0 if ranks > 1 else 0.0) and st[1] > 0
+    ref = oracle.gf_train_f32(n, src, dst, None, 32, 0.05, 0.01, 6, X0)
+    assert np.abs(b - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_gf_train_multi_refuses_an_order_it_cannot_shard(karate):
+    """karate's insertion order 0, 31, 21, ... visits sources out of id order: sharded ranks would read rows 'already updated' in the same sweep.
+    One GPU handles it (levels); n_gpus > 1 says so instead of training something else."""
+    n, src, dst, w, _ = edge_arrays(karate)
+    X = (0.1 * np.random.RandomState(1).randn(n, 8)).astype(np.float32)
+    L = _hip.lib()
+    rc = L.gemhip_gf_train_multi(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, 8, 0.05, 0.01, 3, 2, _devs(2), _hip.ptr(X.copy(), C.c_float), None)
+    assert rc == -3 and b'ascending id order' in L.gemhip_last_error()
+    Y = X.copy()
+    _hip.check(L.gemhip_gf_train_multi(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, 8, 0.05, 0.01, 3, 1, None, _hip.ptr(Y, C.c_float), None))
+    assert np.abs(Y - oracle.gf_train_f32(n, src, dst, None, 8, 0.05, 0.01, 3, X)).max() <= 2e-5 * np.abs(Y).max()
+
+
+def _oracle_multi_schedule(n, src, dst, d, L, r, win, seed, flags, N, episodes):
+    """gemhip_n2v_train_multi restated with the oracle: the same shards, episode slices, bucket order (episode, round s, rank g -> bucket (g, (g+s) % N)),
+    alpha offsets and partition tables, every bucket through oracle_sgns_train_part."""
+    rp, cs, _ = oracle.sorted_csr(n, src, dst, None)
+    total = len(oracle.start_nodes(rp, cs)) * r
+    shard = [(total * k // N, total * (k + 1) // N) for k in range(N)]
+    walks = [oracle.n2v_walks(rp, cs, None, None, 1.0, 1.0, r, L, seed, flags, lo, hi) for lo, hi in shard]
+    cnt = sum(oracle.n2v_vocab(n, w_) for w_ in walks)
+    UTp, KTp, off = oracle.unigram_build_parts(cnt.astype(np.int32), N)
+    P, Nn = oracle.sgns_init(n, d, seed)
+    Pl = [np.ascontiguousarray(P[k::N]) for k in range(N)]
+    Nl = [np.zeros_like(Pl[k]) for k in range(N)]
+    seg_len = [max(1, max((hi - lo) * (e + 1) // episodes - (hi - lo) * e // episodes for lo, hi in shard)) for e in range(episodes)]
+    alpha_total = sum(s_ * N * L for s_ in seg_len)
+    done, pairs = 0, 0
+    for e in range(episodes):
+        for s in range(N):
+            for g in range(N):
+                h = (g + s) % N
+                for k, (lo, hi) in enumerate(shard):          # work items: shard after shard
+                    a, z = (hi - lo) * e // episodes, (hi - lo) * (e + 1) // episodes
+                    if z > a:
+                        pairs += oracle.sgns_train_part(walks[k][a:z], None, win, 0.025, alpha_total, done + k * seg_len[e] * L, 0, N, g, h,
+                                                        UTp[off[h]:off[h + 1]], KTp[off[h]:off[h + 1]], seed, flags, Pl[g], Nl[h], walk_id_offset=lo + a,
+                                                        local_rows=True)
+        done += seg_len[e] * N * L
+    X = np.zeros((n, d), np.float32)
+    for k in range(N):
+        X[k::N] = Pl[k]
+    return X, pairs
+
+
+@pytest.mark.parametrize('ranks,episodes', [(1, 3), (3, 4)])
+def test_n2v_train_multi_deterministic_equals_the_oracle_schedule(sbm1024, ranks, episodes):
+    """flags | 4 (every bucket on ONE wavefront in walk order): the C-ABI driver -- shards, count all-reduce, corpus all-gather, episode table, bucket
+    order, ring of SynNeg partitions, assembly -- lands on the oracle's restatement of the same schedule to 2e-4, and trains every pair of TrainModel
+    exactly once."""
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    row_ptr, col, _ = to_csr(n, src, dst, None)
+    d, L, r, win, seed, flags = 16, 30, 1, 5, 7, 11
+    X = np.empty((n, d), np.float32)
+    st = (C.c_double * 8)()
+    _hip.check(_hip.lib().gemhip_n2v_train_multi(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, d, L, r, win, 1, 1.0, 1.0, seed,
+                                                 flags | 4, ranks, _devs(ranks), episodes, _hip.ptr(X, C.c_float), st))
+    want, pairs = _oracle_multi_schedule(n, src, dst, d, L, r, win, seed, flags, ranks, episodes)
+    assert st[3] == pairs and st[5] == ranks
+    rp, cs, _ = oracle.sorted_csr(n, src, dst, None)
+    assert pairs == len(oracle.sgns_pairs(oracle.n2v_walks(rp, cs, None, None, 1.0, 1.0, r, L, seed, flags), win, 0, 0, seed))
+    assert np.abs(X - want).max() <= 2e-4 * np.abs(want).max() + 1e-6
+
+
+@pytest.mark.parametrize('ranks', [1, 4])
+def test_n2v_train_multi_quality(sbm1024, ranks):
+    """Hogwild buckets: graph-reconstruction MAP of the N-rank run against the sequential algorithm (same bar as the partitioned driver of
+    gem_amd/multi_gpu.py on this 1024-node graph: 8 % over 3 seeds)."""
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    row_ptr, col, _ = to_csr(n, src, dst, None)
+    m = node2vec(d=16, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
+    maps = []
+    for seed in (1, 2, 3):
+        X = np.empty((n, 16), np.float32)
+        _hip.check(_hip.lib().gemhip_n2v_train_multi(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, 16, 80, 10, 10, 1, 1.0, 1.0, seed, 9,
+                                                     ranks, _devs(ranks), 16, _hip.ptr(X, C.c_float), None))
+        maps.append(gr.evaluateStaticGraphReconstruction(sbm1024, m, X.astype(np.float64), None)[0])
+    Xs, _ = oracle.n2v_train(n, src, dst, None, 16, 80, 10, 10, 1, 1.0, 1.0, 1, 9)
+    MAPs = gr.evaluateStaticGraphReconstruction(sbm1024, m, Xs.astype(np.float64), None)[0]
+    assert abs(np.mean(maps) - MAPs) <= 0.08 * MAPs, (maps, MAPs)
