@@ -95,6 +95,7 @@ struct SgnsKnobs {
     int32_t prefetch = 2;             // pairs whose negative rows are requested ahead: 2 (default) or 1 (d == 64/128/256.., whole window cached)
     int32_t reload = 1;               // Hogwild launches: update negative rows as they are at store time (second fetch) and the centre row by atomic add
     int32_t hot_count = -1;           // nodes with at least this many tokens never enter the LDS window: -1 auto (tokens / ((W-1) x (2R+1))), 0 off
+    int32_t window_span = 0;          // positions of a walk whose context rows a wavefront holds at once: 0 = 2R+1 (the sliding window); the whole walk in the bucket kernel's whole-walk mode
     double duty = 1.0;                // fraction of a wavefront's time spent in pair steps (negative rows open); < 1 only for the buckets of the partitioned schedule
 };
 // ... and what a launch of TrainModel over `nwalks` walks then looks like (pure host arithmetic: gemhip_sgns_plan_launch exposes it to the CPU tests)
@@ -718,10 +719,11 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
     const int mode = kn.cache_delta;                 // -1 auto: delta write-back whenever other wavefronts train concurrently
     P.delta = deterministic && mode == 1;            // (cache_delta 1 on a deterministic launch: the Hogwild code path on ONE wavefront, for the parity tests)
     // a node expected to sit in another wavefront's window at any time -- (W - 1) x (2R + 1) x count / tokens >= 1 -- is hot
+    const double span = kn.window_span > 0 ? (double)kn.window_span : (double)(2 * R + 1);
     auto hot_threshold = [&](int64_t waves) -> int32_t {
         if (kn.hot_count > 0) return kn.hot_count;
         if (kn.hot_count < 0 && waves > 1 && vs.total > 0.0) {
-            const double thr = vs.total / ((double)(waves - 1) * (2 * R + 1));
+            const double thr = vs.total / ((double)(waves - 1) * span);
             if (vs.max >= thr) return (int32_t)std::max(2.0, std::ceil(thr));
         }
         return 0;
@@ -755,7 +757,7 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
             // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
             if (reload_eff && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(w_dev, w_act) && vs.total > 0.0) {
                 for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
-                    const double thr = std::max(2.0, std::ceil(vs.total / ((double)(wtry - 1) * (2 * R + 1))));
+                    const double thr = std::max(2.0, std::ceil(vs.total / ((double)(wtry - 1) * span)));
                     if (0.015 * vs.n_eff_cold(thr) / (5.0 * w_steps * kn.duty) >= (double)wtry) { hog_rho = wtry; break; }
                 }
             }
@@ -891,6 +893,9 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     if (h->parts > 1) {
         const double pairs_pp = (double)walk_len * (window + 1) * 0.95 / ((double)h->parts * h->parts), rows_pp = 2.0 * walk_len / h->parts;
         kn.duty = pairs_pp / (pairs_pp + 0.7 * rows_pp);
+        // from ~4 partitions on a walk's contexts of one partition fit the window's slots and stay cached for the WHOLE walk (sgns_win_kernel<PART>,
+        // whole-walk mode): a node then sits in W x walk_len x count / tokens windows, which is what decides whether it is hot
+        if (walk_len / h->parts <= 2 * std::min(window, 10) + 1) kn.window_span = walk_len;
     }
     const SgnsLaunchPlan P = plan_sgns_launch(vs, kn, (int64_t)A.n, d, window, walk_len, nwalks, flags);
     GEMHIP_REQUIRE(P.window, "sgns_train_part: d=%d window=%d walk_len=%d do not fit the LDS window kernel", d, window, walk_len);

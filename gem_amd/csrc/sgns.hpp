@@ -536,18 +536,51 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         stage_a(1);
 
         // --- cache: enter token q (directory now, row through `rowE` -> LDS by the caller), leave token q
-        // rows of tokens 0 .. R-1 enter before the first centre
-        for (int q = 0; q < R && q < len; ++q) {
+        // PART, WHOLE-WALK mode: a bucket's contexts are the 1 / parts of the tokens that belong to its SynPos partition.  When all of them fit the
+        // window's slots (always from ~4 partitions on) they enter TOGETHER before the first centre -- four rows in flight at a time instead of one
+        // exposed round trip per token, which is what a bucket launch otherwise spends its time on -- and leave together after the last centre; the
+        // centre loop then does no window bookkeeping at all.  One wavefront: the window is transparent, so the tables are the same either way.
+        bool whole = false;
+        if constexpr (PART) {
+            int nctx = 0;
+            for (int base = 0; base < len; base += WAVE)
+                nctx += (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(base + lane < len && tok_c(base + lane < len ? base + lane : 0) >= 0));
+            whole = nctx <= S;
+        }
+        // rows of tokens 0 .. R-1 (whole-walk mode: of every token) enter before the first centre
+        for (int q = 0; (PART && whole) ? q < len : (q < R && q < len); ++q) {
             const int32_t v = __builtin_amdgcn_readfirstlane(tok_c(q));
             if (v < 0 || is_hot(v)) continue;
             const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
             if (hit) { if (lane == (int)__builtin_ctzll(hit)) ++slot_ref; continue; }
             const int s = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(slot_node < 0 && lane < S));
-            float r[NV][VEC];
-            g_ld(A.SynPos + (int64_t)v * d, r);
-            lds_st(rowsL + (size_t)s * RW, r);
-            if constexpr (DELTA) o_st(s, r);
+            if (!(PART && whole)) {
+                float r[NV][VEC];
+                g_ld(A.SynPos + (int64_t)v * d, r);
+                lds_st(rowsL + (size_t)s * RW, r);
+                if constexpr (DELTA) o_st(s, r);
+            }
             if (lane == s) { slot_node = v; slot_ref = 1; }
+        }
+        if constexpr (PART) {
+            if (whole) {
+                unsigned long long occ = __builtin_amdgcn_ballot_w64(slot_node >= 0 && lane < S);
+                while (occ) {
+                    int sl[4]; float r4[4][NV][VEC];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        sl[u] = occ ? (int)__builtin_ctzll(occ) : -1;
+                        if (occ) occ &= occ - 1;
+                        if (sl[u] >= 0) g_ld(A.SynPos + (int64_t)__builtin_amdgcn_readlane(slot_node, sl[u]) * d, r4[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (sl[u] >= 0) {
+                            lds_st(rowsL + (size_t)sl[u] * RW, r4[u]);
+                            if constexpr (DELTA) o_st(sl[u], r4[u]);
+                        }
+                }
+            }
         }
 
         // data and address registers of the stores a centre ends with.  They are kept alive (empty asm "uses" inside the next centre's pair steps) so
@@ -575,7 +608,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             bool fin_done = false;
             // token pos+R enters
             float rowE[NV][VEC]; int sE = -1;
-            if (pos + R < len) {
+            if (pos + R < len && !(PART && whole)) {
                 const int32_t v = __builtin_amdgcn_readfirstlane(tok_c(pos + R));
                 if (v >= 0 && !is_hot(v)) {
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64(slot_node == v);
@@ -589,7 +622,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             }
             // token pos-R leaves after this centre: when it is the last holder of its slot, fetch the row as it is NOW
             float rowG[NV][VEC], rowO[NV][VEC]; int sX = -1; int32_t vX = -1;
-            if (pos - R >= 0) {
+            if (pos - R >= 0 && !(PART && whole)) {
                 vX = __builtin_amdgcn_readfirstlane(tok_c(pos - R));
                 const unsigned long long hx = vX >= 0 ? __builtin_amdgcn_ballot_w64(slot_node == vX) : 0ull;     // (no slot: a hot row, never cached)
                 if (hx) {
@@ -943,8 +976,31 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             PROF_LAP(7);                                             // end of the centre: consume, then the centre's stores
             __builtin_amdgcn_wave_barrier();
         }
+        if constexpr (PART) {
+            if (whole) {        // every cached row leaves now: what this wavefront changed, as an atomic add (Hogwild) or the row itself (one wavefront)
+                unsigned long long occ = __builtin_amdgcn_ballot_w64(slot_node >= 0 && lane < S);
+                while (occ) {
+                    const int s = (int)__builtin_ctzll(occ);
+                    occ &= occ - 1;
+                    float *prow = A.SynPos + (int64_t)__builtin_amdgcn_readlane(slot_node, s) * d;
+                    float l[NV][VEC];
+                    lds_ld(rowsL + (size_t)s * RW, l);
+                    if constexpr (DELTA) {
+                        float o[NV][VEC];
+                        o_ld(s, o);
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k)
+                                if ((c * WAVE + lane) * VEC + k < dg)
+                                    __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(prow + (c * WAVE + lane) * VEC + k), l[c][k] - o[c][k]);
+                    } else g_st(prow, l);
+                }
+                slot_node = -1; slot_ref = 0;
+            }
+        }
         // the last R tokens are still in the window
-        for (int q = (len - R > 0 ? len - R : 0); q < len; ++q) {
+        for (int q = ((PART && whole) ? len : (len - R > 0 ? len - R : 0)); q < len; ++q) {
             const int32_t v = __builtin_amdgcn_readfirstlane(tok_c(q));
             if (v < 0) continue;
             const unsigned long long hq = __builtin_amdgcn_ballot_w64(slot_node == v);
