@@ -118,7 +118,8 @@ class GFWorkload(object):
         self.rank, self.sweeps_done, self.X_init = rank, 0, (Xa[:n].clone() if world > 1 else None)
         self.job = multi_gpu.GFSharded(self.b, comm, rank, world, n, src, dst, exchange_every=self.exchange_every)
         self.kernel_ms, self.launches = 0.0, 0
-        log('[rank %d] GF plan: rows %d updates %d levels %d' % (rank, self.b.rows, self.b.updates, self.b.levels))
+        self.kernel = 'gf_sweep_rows_kernel' if self.b.rows_per_wave > 1 else 'gf_sweep_kernel'
+        log('[rank %d] GF plan: rows %d updates %d levels %d, %s (%d rows per wavefront)' % (rank, self.b.rows, self.b.updates, self.b.levels, self.kernel, self.b.rows_per_wave))
 
     def step(self):
         self.sweeps_done += 1
@@ -288,6 +289,9 @@ class N2VWorkload(object):
         n, src, dst, w, _ = edge_arrays(g)
         row_ptr, col, ww = to_csr(n, src, dst, w)
         self.b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, args.d)
+        # one GPU: the unigram alias table in the reference binary's own layout (first-appearance order, GEMHIP_N2V_VOCAB_ORDER) -- what
+        # node2vec.learn_embedding runs by default; quality() adds a pass in the node-id layout, whose draws pair with the sequential oracle's run
+        self.b.vocab_order = (world == 1)
         if world == 1:
             self.job = multi_gpu.Node2VecSharded(self.b, comm, rank, world, n, args.num_walks, args.walk_len, args.window, 1,
                                                  seed=20260923, flags=_hip.N2V_SNAP_COMPAT)
@@ -477,8 +481,20 @@ class N2VWorkload(object):
         nodes = rng.choice(self.g.n, size=min(nsample, self.g.n), replace=False)        # uniform over all nodes, hubs included (a prefix of a larger sample)
         ap = gr.sampled_ap_gpu(self.g, None, self.P.cpu().numpy(), nodes)
         out = {'sampled_map': float(ap.mean()), 'sampled_map_se': float(ap.std(ddof=1) / np.sqrt(len(ap))), 'nodes_sampled': int(len(nodes)),
-               'evaluator': 'metrics.computeMAP semantics on the GPU', 'reference_map': None}
+               'evaluator': 'metrics.computeMAP semantics on the GPU', 'reference_map': None,
+               'unigram_layout': 'vocabulary order (the binary\'s: GEMHIP_N2V_VOCAB_ORDER)' if getattr(self.b, 'vocab_order', False) else 'node-id order'}
+        ap_by_engine = {'snap': ap, 'oracle': ap}
+        if getattr(self.b, 'vocab_order', False) and a.graph == 'sbm' and os.path.exists(self._ref_golden('oracle', self.g.n)) and self.world == 1:
+            # the sequential oracle's committed run drew its negatives from the node-id layout: one more pass (outside every timed region) in THAT layout,
+            # same seed, pairs with it draw for draw; the timed pass (the binary's layout) is scored against the reference binary's own run
+            self.b.vocab_order = False
+            P2 = self.job.run(float(a.ret_p), float(a.inout_q))
+            self.b.vocab_order = True
+            ap_by_engine['oracle'] = gr.sampled_ap_gpu(self.g, None, P2.cpu().numpy(), nodes)
+            out['oracle_pass'] = {'unigram_layout': 'node-id order (the layout of the oracle\'s committed run: paired draws)',
+                                  'sampled_map': float(ap_by_engine['oracle'].mean())}
         for engine, key in (('snap', 'reference_map'), ('oracle', 'oracle_map')):
+            ap = ap_by_engine[engine]
             path = self._ref_golden(engine, self.g.n)
             if a.graph == 'sbm' and os.path.exists(path):
                 ref = json.load(open(path))
@@ -678,12 +694,13 @@ def time_workload(name, args, rank, world, comm, K=None, W=None, with_cpu=True):
         out['config']['world_size_seen'] = dist.get_world_size()
         if hasattr(wl, 'phase_split'):
             out['phases'] = wl.phase_split(K)
+    if world == 1:
+        out['roofline'] = wl.roofline(dev_ms, K)          # (before quality(): that may run one more, untimed pass on the same handle)
     if hasattr(wl, 'quality'):
         q = wl.quality()
         if q is not None:
             out['quality'] = q
     if world == 1:
-        out['roofline'] = wl.roofline(dev_ms, K)
         if hasattr(wl, 'api_wall') and not getattr(args, 'no_api_wall', False):
             out['api_wall'] = wl.api_wall()
         if with_cpu:

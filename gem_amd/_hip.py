@@ -86,6 +86,7 @@ _SIGS = {
     'gemhip_n2v_walks_ptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p, i32p]),
     'gemhip_n2v_vocab': (C.c_int, [C.c_void_p, C.c_void_p]),
     'gemhip_n2v_counts_ptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    'gemhip_n2v_build_unigram_vocab_order': (C.c_int, [C.c_void_p, C.c_int32, i64p, i32p, f32p, i32p]),
     'gemhip_n2v_build_unigram': (C.c_int, [C.c_void_p, i32p, f32p, i32p]),
     'gemhip_sgns_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
     'gemhip_n2v_bind_counts': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -177,6 +178,8 @@ def ptr(a, ctype):
 
 N2V_PAD_ZERO, N2V_UNIGRAM_QUIRK, N2V_DETERMINISTIC, N2V_UNIFORM_FIRST_HOP = 1, 2, 4, 8
 N2V_SNAP_COMPAT = 11
+N2V_VOCAB_ORDER = 16              # unigram table in the binary's layout (first-appearance order over the nodes that occur)
+N2V_SNAP_LAYOUT = 27             # SNAP_COMPAT | VOCAB_ORDER: what node2vec.learn_embedding passes by default
 N2V_NO_WINDOW_CACHE = 128       # A/B switch: round-1 SGNS kernel without the LDS window of context rows
 
 

@@ -705,7 +705,12 @@ extern "C" int gemhip_gf_plan_info(gemhip_gf_plan_t p, int64_t *info)
     info[0] = p->nupd; info[1] = p->nrows; info[2] = (int64_t)p->level_off.size() - 1; info[3] = p->n; info[4] = p->d;
     // 3*4d + 12 bytes per update (read X_i, read X_j, write X_i, (i,j,w))
     info[5] = p->nupd * (3 * 4 * p->d + 12);
-    info[6] = 0; info[7] = 0;
+    {   // rows per wavefront the largest level's sweep launch will use (1: gf_sweep_kernel, > 1: gf_sweep_rows_kernel)
+        int64_t big = 0;
+        for (size_t l = 0; l + 1 < p->level_off.size(); ++l) big = std::max<int64_t>(big, p->level_off[l + 1] - p->level_off[l]);
+        info[6] = p->rows_per_wave > 0 ? p->rows_per_wave : gf_rows_per_wave(big);
+    }
+    info[7] = 0;
     return GEMHIP_OK;
 }
 

@@ -17,6 +17,7 @@
 // purpose): results do not depend on scheduling, and the CPU oracle reproduces walks,
 // counts and alias tables bit for bit.
 #include "sgns.hpp"
+#include <hipcub/hipcub.hpp>
 #include <vector>
 #include <cstring>
 #include <cmath>
@@ -134,6 +135,9 @@ struct gemhip_n2v {
     int32_t *d_KT = nullptr;
     uint2 *d_UK = nullptr;             // {bits of UT[i], KT[i]} interleaved: one 8-byte gather instead of two 4-byte gathers
     bool unigram_ready = false;
+    // vocabulary-order layout (gemhip_n2v_build_unigram_vocab_order): the slot table of RndUnigramInt, and how many slots it has
+    int32_t *d_KTslot = nullptr; int64_t n_vocab = 0; bool vocab_order = false;
+    unsigned long long *d_first = nullptr;   // first token index of every node (scratch of that builder)
     // embeddings
     int32_t d = 0;
     float *SynPos = nullptr, *SynNeg = nullptr;
@@ -274,6 +278,22 @@ __global__ void n2v_vocab_kernel(const int32_t *__restrict__ walks, int64_t ntok
 
 // -------------------------------------------------------------------------- SGNS
 // InitPosEmb (ELF @0x40e270): (U(0,1)-0.5)/d ; InitNegEmb: zeros.
+// first[v] = index of the first token equal to v (LearnVocab @0x40d560 renames the tokens 0..N-1 in that order)
+__global__ void n2v_first_token_kernel(const int32_t *__restrict__ walks, int64_t ntokens, unsigned long long *__restrict__ first)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntokens; t += stride) {
+        const int32_t v = walks[t];
+        if (v >= 0 && first[v] > (unsigned long long)t) atomicMin(&first[v], (unsigned long long)t);
+    }
+}
+
+__global__ void iota_kernel(int32_t *p, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+
 __global__ void sgns_init_kernel(float *SynPos, float *SynNeg, int64_t total, int32_t d, uint64_t seed)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -374,7 +394,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
     hipFree(h->d_start);
     hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy);
     if (h->own_counts) hipFree(h->d_counts);
-    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp);
+    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_KTslot); hipFree(h->d_first); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
     delete h;
     return GEMHIP_OK;
@@ -578,8 +598,73 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
         if (!h->d_UK) GEMHIP_CHECK(hipMalloc((void **)&h->d_UK, n * sizeof(uint2)));
         GEMHIP_CHECK(hipMemcpy(h->d_UK, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
     }
-    h->unigram_ready = true;
+    h->unigram_ready = true; h->vocab_order = false;
     if (counts_out) std::copy(cnt.begin(), cnt.end(), counts_out);
+    if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
+    if (KT_out) std::copy(K.begin(), K.end(), KT_out);
+    return GEMHIP_OK;
+}
+
+// InitUnigramTable in the BINARY's layout.  LearnEmbeddings (ELF @0x40ea30) renames the tokens 0..N-1 in order of first appearance in the walk matrix
+// (LearnVocab @0x40d560) and builds the alias table over those N entries in that order; RndUnigramInt (@0x40d5f0) then draws a SLOT floor(u N) of that
+// table.  Vose's stack discipline makes the table depend on the order of its entries, so the node-id layout of gemhip_n2v_build_unigram is the same
+// distribution but not the same table (measured on SBM-1024 with the binary-pinned restatement: -0.33 +- 0.24 % of MAP, profiles/r03_unigram_layout_effect.json).
+// Here: first token index per node on the device (atomicMin over the walks), nodes that occur sorted by it (N = their number), Vose over their counts in
+// that order, and the result stored in NODE space so that the kernels need no renaming of tokens or tables:
+//   KTslot[slot] = node of KTable'[slot]   (flags & 2, the RndUnigramInt quirk; else node of slot)        -- what A.KT points at
+//   UK[v]        = {UTable'[r(v)], node of KTable'[r(v)]}   with r(v) the renamed id of node v            -- what A.UK points at
+// order_out[N]: node ids in first-appearance order; UT_out / KT_out [N]: the table in RENAMED indices, as the binary holds it (tests compare them
+// with oracle/snap_stream.py's).  The walks must be the whole corpus of the handle (single-GPU path).
+extern "C" int gemhip_n2v_build_unigram_vocab_order(gemhip_n2v_t h, int32_t flags, int64_t *n_vocab_out, int32_t *order_out, float *UT_out, int32_t *KT_out)
+{
+    GEMHIP_REQUIRE(h && h->d_walks && h->nwalks > 0, "n2v_build_unigram_vocab_order: no walks");
+    const int64_t n = h->n, ntok = h->nwalks * h->walk_len;
+    if (!h->d_first) GEMHIP_CHECK(hipMalloc((void **)&h->d_first, n * sizeof(unsigned long long)));
+    GEMHIP_CHECK(hipMemset(h->d_first, 0xff, n * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(n2v_first_token_kernel, dim3((unsigned)std::min<int64_t>((ntok + 255) / 256, 256 * 16)), dim3(256), 0, 0, h->d_walks, ntok, h->d_first);
+    GEMHIP_CHECK(hipGetLastError());
+    // nodes sorted by their first token index on the device (radix sort of (first, node) pairs: nodes that never occur sort last)
+    std::vector<int32_t> back(n), cnt(n);              // back: renamed id -> node
+    {
+        unsigned long long *keys_out = nullptr; int32_t *ids = nullptr, *ids_out = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
+        GEMHIP_CHECK(hipMalloc((void **)&keys_out, n * sizeof(unsigned long long)));
+        GEMHIP_CHECK(hipMalloc((void **)&ids, 2 * n * sizeof(int32_t)));
+        ids_out = ids + n;
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ids, n);
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
+        if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) { PhaseScope ph(PH_D2H); e = hipMemcpy(back.data(), ids_out, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+                               if (e == hipSuccess) e = hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost); }
+        hipFree(keys_out); hipFree(ids); hipFree(tmp);
+        if (e != hipSuccess) return fail(GEMHIP_E_HIP, "n2v_build_unigram_vocab_order: device sort failed: %s", hipGetErrorString(e));
+    }
+    PhaseScope ph_host(PH_HOST);
+    int64_t N = 0;
+    while (N < n && cnt[back[N]] > 0) ++N;             // the nodes that occur come first (a node occurs iff it has a first token iff its count > 0)
+    back.resize(N);
+    GEMHIP_REQUIRE(N > 0, "n2v_build_unigram_vocab_order: empty vocabulary");
+    std::vector<int32_t> cr(N), K;
+    std::vector<float> Uf;
+    for (int64_t r = 0; r < N; ++r) cr[r] = cnt[back[r]];
+    GEMHIP_REQUIRE(vose_unigram(cr.data(), N, 1, Uf, K), "n2v_build_unigram_vocab_order: empty vocabulary");
+    h->vs.build(cnt.data(), n);
+    std::vector<int32_t> slot(N);
+    std::vector<uint2> UK((size_t)n, make_uint2(0u, 0u));          // nodes that never occur are never drawn
+    for (int64_t r = 0; r < N; ++r) {
+        slot[r] = (flags & 2) ? back[K[r]] : back[r];
+        uint32_t ub; memcpy(&ub, &Uf[r], 4);
+        UK[back[r]] = make_uint2(ub, (uint32_t)back[K[r]]);
+    }
+    if (!h->d_KTslot) GEMHIP_CHECK(hipMalloc((void **)&h->d_KTslot, n * sizeof(int32_t)));
+    if (!h->d_UK) GEMHIP_CHECK(hipMalloc((void **)&h->d_UK, n * sizeof(uint2)));
+    { PhaseScope ph(PH_H2D);
+      GEMHIP_CHECK(hipMemcpy(h->d_KTslot, slot.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
+      GEMHIP_CHECK(hipMemcpy(h->d_UK, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice)); }
+    h->n_vocab = N; h->vocab_order = true; h->unigram_ready = true;
+    if (n_vocab_out) *n_vocab_out = N;
+    if (order_out) std::copy(back.begin(), back.end(), order_out);
     if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
     if (KT_out) std::copy(K.begin(), K.end(), KT_out);
     return GEMHIP_OK;
@@ -794,6 +879,9 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     // the kernel computes t = token_offset + wl*walk_len + pos with wl the LOCAL walk index
     A.token_offset = token_offset; A.walk_id_offset = h->walk_id_offset; A.epoch = epoch;
     A.UT = h->d_UT; A.KT = h->d_KT; A.UK = h->d_UK; A.n = (uint32_t)h->n; A.seed = seed; A.flags = flags; A.d = h->d;
+    if (h->vocab_order) {      // the binary's table layout: slots over the nodes that occur, in first-appearance order; the slot table is always consulted
+        A.KT = h->d_KTslot; A.n = (uint32_t)h->n_vocab; A.flags = flags | 2; A.UT = nullptr;
+    }
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->kn.prefetch; A.reload = h->kn.reload; A.counts = nullptr; A.hot_thr = 0;
     A.parts = 0; A.ctx_part = 0; A.word_part = 0; A.seg = nullptr; A.nseg = 0; A.seg_len = 0;
@@ -989,7 +1077,8 @@ extern "C" int gemhip_n2v_train(int64_t n, int64_t nnz, const int64_t *row_ptr, 
     const int64_t nwalks = h->m_start * (int64_t)num_walks;
     if (!rc) { hipEventRecord(ev[0], 0); rc = gemhip_n2v_walks(h, p, q, num_walks, walk_len, seed, flags, 0, nwalks, nullptr); }
     if (!rc) rc = gemhip_n2v_vocab(h, nullptr);
-    if (!rc) { hipEventRecord(ev[1], 0); rc = gemhip_n2v_build_unigram(h, nullptr, nullptr, nullptr); }
+    if (!rc) { hipEventRecord(ev[1], 0); rc = (flags & GEMHIP_N2V_VOCAB_ORDER) ? gemhip_n2v_build_unigram_vocab_order(h, flags, nullptr, nullptr, nullptr, nullptr)
+                                                                                 : gemhip_n2v_build_unigram(h, nullptr, nullptr, nullptr); }
     if (!rc) rc = gemhip_sgns_init(h, d, seed, nullptr, nullptr);
     if (!rc) hipEventRecord(ev[2], 0);
     for (int ep = 0; !rc && ep < epochs; ++ep)

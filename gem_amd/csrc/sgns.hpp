@@ -15,6 +15,8 @@ namespace gemhip {
 struct SgnsArgs {
     const int32_t *walks; int64_t walk_lo, walk_hi; int32_t walk_len; int32_t window;
     float alpha0; int64_t denom; int64_t token_offset; int64_t walk_id_offset; int32_t epoch;
+    // negative sampling (RndUnigramInt): slot = floor(u n) -> X = KT[slot] (flags & 2; else X = slot) -> target = u' < UK[X].x ? X : UK[X].y.  KT is indexed
+    // by SLOT, UK = {UTable, KTable} by NODE: the same arrays in the node-id layout, different ones in the binary's vocabulary-order layout (n2v.hip)
     const float *UT; const int32_t *KT; const uint2 *UK; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
     float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs;
     float *dummy;               // sgns_win_kernel: nwaves rows, never read for their value
@@ -179,8 +181,9 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
                 const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos | ((uint32_t)a << 16),
                                                (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
                 const uint32_t slot = mulhi_range(rn.x, A.n);
-                const int32_t X = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
-                negs[s] = (u01(rn.y) < A.UT[X]) ? X : A.KT[X];
+                const int32_t X = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0); A.KT: the table indexed by SLOT
+                const uint2 uk = A.UK[X];                                      // {UTable[X], KTable[X]} indexed by NODE (the two differ in the vocabulary-order layout)
+                negs[s] = (u01(rn.y) < __builtin_bit_cast(float, uk.x)) ? X : (int32_t)uk.y;
             }
             __builtin_amdgcn_wave_barrier();
 

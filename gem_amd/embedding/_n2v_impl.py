@@ -20,7 +20,7 @@ def learn(model, graph):
     if seed is None:
         # the reference binary seeds with time(); draw from numpy's global RNG so np.random.seed() controls a run
         seed = int(np.random.randint(0, 2 ** 31 - 1))
-    flags = int(getattr(model, '_flags', _hip.N2V_SNAP_COMPAT))
+    flags = int(getattr(model, '_flags', _hip.N2V_SNAP_LAYOUT))       # the binary's quirks AND its unigram-table layout (include/gem_hip.h)
     _hip.require_device()
     X = np.empty((n, d), dtype=np.float32)
     stats = (C.c_double * 4)()

@@ -234,7 +234,7 @@ class HipBackendGF(object):
         _hip.check(self.L.gemhip_gf_plan_bind(self.plan, C.c_void_p(Xa.data_ptr()), C.c_void_p(Xb.data_ptr())))
         info = (C.c_int64 * 8)()
         _hip.check(self.L.gemhip_gf_plan_info(self.plan, info))
-        self.updates, self.rows, self.levels, self.algo_bytes = info[0], info[1], info[2], info[5]
+        self.updates, self.rows, self.levels, self.algo_bytes, self.rows_per_wave = info[0], info[1], info[2], info[5], info[6]
 
     def sweep(self, eta, regu):
         s = self.torch.cuda.current_stream().cuda_stream
@@ -452,7 +452,10 @@ class HipBackendN2V(object):
 
     def build_unigram(self):
         self.torch.cuda.current_stream().synchronize()
-        _hip.check(self.L.gemhip_n2v_build_unigram(self.h, None, None, None))
+        if getattr(self, 'vocab_order', False):      # the binary's table layout (needs the WHOLE corpus on this handle: one rank)
+            _hip.check(self.L.gemhip_n2v_build_unigram_vocab_order(self.h, getattr(self, 'vocab_flags', _hip.N2V_SNAP_COMPAT), None, None, None, None))
+        else:
+            _hip.check(self.L.gemhip_n2v_build_unigram(self.h, None, None, None))
 
     def init_tables(self, seed):
         self.torch.cuda.current_stream().synchronize()

@@ -113,7 +113,7 @@ int gemhip_gf_plan_get_embedding(gemhip_gf_plan_t plan, float *X_host);
 /* Device pointer of the CURRENT table (the one holding the latest sweep). */
 int gemhip_gf_plan_current(gemhip_gf_plan_t plan, void **dX);
 /* info (8 int64): {updates_per_sweep, rows_per_sweep, levels, n, d,
- * algorithmic_bytes_per_sweep, 0, 0} */
+ * algorithmic_bytes_per_sweep, rows per wavefront of the largest level's launch, 0} */
 int gemhip_gf_plan_info(gemhip_gf_plan_t plan, int64_t *info);
 /* gf.cpp:94-113 objective on the device table: out = {f1, f2}. `m` edges as in
  * plan_create but over ALL edges (no dst>src filter), like the reference. */
@@ -142,6 +142,11 @@ int gemhip_gf_objective(int64_t n, int64_t m, const int32_t *src,
 #define GEMHIP_N2V_DETERMINISTIC 4
 #define GEMHIP_N2V_UNIFORM_FIRST_HOP 8
 #define GEMHIP_N2V_SNAP_COMPAT 11
+#define GEMHIP_N2V_VOCAB_ORDER 16     /* unigram alias table laid out the way the binary lays it out: over the nodes that occur, in order of first appearance
+                                         in the walk matrix (LearnVocab renames the tokens that way), instead of over all nodes in id order -- same distribution,
+                                         the binary's TABLE (gemhip_n2v_build_unigram_vocab_order; single-GPU path).  GEMHIP_N2V_SNAP_COMPAT | 16 = 27 is what
+                                         gem_amd.embedding.node2vec passes by default */
+#define GEMHIP_N2V_SNAP_LAYOUT 27
 #define GEMHIP_N2V_NO_WINDOW_CACHE 128 /* A/B switch: train with the round-1 kernel (every context row goes to memory for every pair) instead of the
                                           LDS-window kernel (gemhip_sgns_set_window_cache); same arithmetic and draws either way */
 /* (bits 32 and 64 selected two round-1/2 experiments -- 16-byte row accesses, negatives shared per centre word -- that were measured slower /
@@ -165,6 +170,11 @@ int gemhip_n2v_destroy(gemhip_n2v_t h);
 /* PreprocessTransitionProbs: first-order Vose alias tables per row (no-op when every
  * row has equal weights).  2nd-order bias is applied by rejection inside the walk. */
 int gemhip_n2v_build_alias(gemhip_n2v_t h, void *stream);
+/* InitUnigramTable in the binary's layout (flags bit GEMHIP_N2V_VOCAB_ORDER of the one-shot call): see n2v.hip.  Needs the walks and the counts
+ * (gemhip_n2v_vocab) of the whole corpus on this handle.  `flags`: bit 2 (the RndUnigramInt quirk) decides what a slot maps to.  n_vocab_out: nodes
+ * that occur; order_out[n_vocab]: their ids in first-appearance order; UT_out / KT_out [n_vocab]: the alias table in the binary's renamed indices
+ * (all optional, caller-sized n).  gemhip_sgns_train uses this table from then on (gemhip_n2v_build_unigram switches back). */
+int gemhip_n2v_build_unigram_vocab_order(gemhip_n2v_t h, int32_t flags, int64_t *n_vocab_out, int32_t *order_out, float *UT_out, int32_t *KT_out);
 /* Fetch tables/sorted columns for tests.  Returns 1 (not an error) when rows are uniform
  * and no tables exist. */
 int gemhip_n2v_get_alias(gemhip_n2v_t h, float *U_host, int32_t *K_host, int32_t *col_sorted_host);

@@ -76,13 +76,18 @@ def test_eigen_path_agrees_with_block_krylov_and_scipy(monkeypatch):
     g = sbm_graph(20000, 200000, 8, seed=21)
     n, src, dst, w = symmetric_arrays(g)
     out = {}
-    for sym in ('0', '1'):
-        monkeypatch.setenv('GEMHIP_HOPE_SYM', sym)
-        m = LaplacianEigenmaps(d=16)
-        Y = m.learn_embedding(graph=g)
-        out[sym] = (Y, m._eigvals.copy(), m._stats['solver'])
-    monkeypatch.delenv('GEMHIP_HOPE_SYM')
-    m = LaplacianEigenmaps(d=16); m.learn_embedding(graph=g)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', RuntimeWarning)          # a parity test must not trip the solver's own non-convergence warning
+        for sym in ('0', '1'):
+            monkeypatch.setenv('GEMHIP_HOPE_SYM', sym)
+            # the forced block-Krylov leg (not what runs at this size by default): the 8 eigenvalues at the bottom of this spectrum are clustered within
+            # 2e-3 and the fp32 Ritz values stop moving at ~1.5e-6 relative -- its tolerance is stated at that floor instead of the 1e-6 default
+            m = LaplacianEigenmaps(d=16) if sym == '1' else LaplacianEigenmaps(d=16, tol=3e-6, max_restarts=40)
+            Y = m.learn_embedding(graph=g)
+            out[sym] = (Y, m._eigvals.copy(), m._stats['solver'])
+        monkeypatch.delenv('GEMHIP_HOPE_SYM')
+        m = LaplacianEigenmaps(d=16); m.learn_embedding(graph=g)
     assert out['0'][2] == 'block_krylov' and out['1'][2] == 'symmetric_chebyshev_filter' and m._stats['solver'] == 'symmetric_chebyshev_filter'
     A = sp.csr_matrix((np.ones(len(src)) if w is None else w.astype(np.float64), (src, dst)), shape=(n, n))
     deg = np.asarray(A.sum(axis=1)).ravel(); dinv = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1e-300)), 0.0)

@@ -357,3 +357,35 @@ def test_second_order_walks_match_the_snap_binary_on_map(p, q, sbm1024):
         Y = m.learn_embedding(graph=sbm1024, edge_f=None, is_weighted=True, no_python=True)
         maps.append(gr.evaluateStaticGraphReconstruction(sbm1024, m, Y, None)[0])
     assert abs(np.mean(maps) - np.mean(ref)) <= 0.04 * np.mean(ref), (maps, ref)
+
+
+@pytest.mark.parametrize('name', ['karate_p1_q1', 'karate_p0.25_q4', 'karate_p4_q0.25', 'karate_weighted_p0.5_q2', 'directed_with_sinks_p1_q1',
+                                  'directed_with_sinks_p2_q0.5', 'karate_two_epochs_alpha_schedule'])
+def test_vocab_order_unigram_table_is_the_binarys(name):
+    """GEMHIP_N2V_VOCAB_ORDER: from the reference binary's own walk matrix (tests/golden/n2v_snap_stream_walks.json: gem/c_exe/node2vec run
+    deterministically) the device builds the unigram alias table the way LearnEmbeddings does -- tokens renamed by first appearance (the zero padding
+    behind a sink counts as node 0), Vose over their counts in THAT order -- and it is the table of oracle/snap_stream.py, the restatement that
+    reproduces the binary's embedding file: same node order, same alias targets, U to fp32; and the node-space form the kernels read maps every slot
+    and every node to the same targets."""
+    from oracle import snap_stream as ss
+    c = json.load(open(golden_path('n2v_snap_stream_walks.json')))['cases'][name]
+    walks = np.ascontiguousarray(np.asarray(c['walks'], dtype=np.int32))
+    n = int(walks.max()) + 1
+    dev = Dev(n, np.array([0], np.int32), np.array([min(1, n - 1)], np.int32), None)
+    _hip.check(dev.L.gemhip_n2v_set_walks(dev.h, _hip.ptr(walks, C.c_int32), walks.shape[0], walks.shape[1], 0))
+    _hip.check(dev.L.gemhip_n2v_vocab(dev.h, None))
+    nv = C.c_int64(); order = np.full(n, -1, np.int32); UT = np.zeros(n, np.float32); KT = np.zeros(n, np.int32)
+    _hip.check(dev.L.gemhip_n2v_build_unigram_vocab_order(dev.h, SNAP, C.byref(nv), _hip.ptr(order, C.c_int32), _hip.ptr(UT, C.c_float), _hip.ptr(KT, C.c_int32)))
+    N = nv.value
+    # the restatement's renaming and table (learn_embeddings: first appearance in row-major order; unigram_table over the renamed counts)
+    back, seen = [], set()
+    for v in walks.ravel().tolist():
+        if v not in seen:
+            seen.add(v); back.append(v)
+    assert N == len(back) and order[:N].tolist() == back
+    rn = {v: i for i, v in enumerate(back)}
+    vocab = np.bincount(np.vectorize(rn.get)(walks).ravel(), minlength=N)
+    K64, U64 = ss.unigram_table(vocab.tolist())
+    assert KT[:N].tolist() == K64
+    np.testing.assert_allclose(UT[:N], np.asarray(U64), rtol=0, atol=1e-6)
+    dev.close()
