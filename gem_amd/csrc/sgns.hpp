@@ -502,8 +502,8 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         // (the second use must see the first update), or a target also occurs in one of the previous two slots (this slot's rows
         // were requested before those slots' updates were stored, so the slow path fetches them again).  One lane per slot,
         // once per centre; at n = 1M it is set for ~1e-4 of the pairs, on karate (n = 34) for nearly all.
-        auto stage_fin = [&](int p) -> uint32_t {
-            int32_t *dst = negs + (p & 1) * nsamp;
+        auto stage_fin = [&](int p, int buf) -> uint32_t {
+            int32_t *dst = negs + buf * nsamp;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int s = lane + k * WAVE;
@@ -534,22 +534,43 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             }
             return (uint32_t)__builtin_amdgcn_ballot_w64(sp);
         };
-        stage_a(0); stage_b();
-        uint32_t spec_next = stage_fin(0);
-        stage_a(1);
-
-        // --- cache: enter token q (directory now, row through `rowE` -> LDS by the caller), leave token q
         // PART, WHOLE-WALK mode: a bucket's contexts are the 1 / parts of the tokens that belong to its SynPos partition.  When all of them fit the
         // window's slots (always from ~4 partitions on) they enter TOGETHER before the first centre -- four rows in flight at a time instead of one
-        // exposed round trip per token, which is what a bucket launch otherwise spends its time on -- and leave together after the last centre; the
-        // centre loop then does no window bookkeeping at all.  One wavefront: the window is transparent, so the tables are the same either way.
+        // exposed round trip per token -- and leave together after the last centre; the centre loop then does no window bookkeeping at all and visits
+        // ONLY the positions that hold a centre word of this bucket (the other 1 - 1 / parts of a walk cost ~0.5 us each as empty iterations: most
+        // of a bucket launch's time at 8 partitions).  One wavefront: the window is transparent, so the tables are the same either way.
         bool whole = false;
+        unsigned long long actm0 = 0ull, actm1 = 0ull;          // positions 0..63 / 64..127 that hold a centre word of this bucket
         if constexpr (PART) {
             int nctx = 0;
             for (int base = 0; base < len; base += WAVE)
                 nctx += (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(base + lane < len && tok_c(base + lane < len ? base + lane : 0) >= 0));
-            whole = nctx <= S;
+            whole = nctx <= S && len <= 2 * WAVE;
+            if (whole) {
+                actm0 = __builtin_amdgcn_ballot_w64(lane < len && tok_w(lane < len ? lane : 0) >= 0);
+                actm1 = __builtin_amdgcn_ballot_w64(WAVE + lane < len && tok_w(WAVE + lane < len ? WAVE + lane : 0) >= 0);
+                if (!(actm0 | actm1)) { __builtin_amdgcn_wave_barrier(); continue; }        // no centre word of this bucket in the walk: nothing to train
+            }
         }
+        auto next_act = [&](int p) -> int {                     // first position >= p that holds a centre word of this bucket (len if none)
+            if (p < WAVE) { const unsigned long long m = actm0 >> p; if (m) return p + (int)__builtin_ctzll(m); p = WAVE; }
+            if (p < 2 * WAVE) { const unsigned long long m = actm1 >> (p - WAVE); if (m) return p + (int)__builtin_ctzll(m); }
+            return len;
+        };
+        int pos_first = 0;
+        uint32_t spec_next;
+        if constexpr (PART) {
+            pos_first = whole ? next_act(0) : 0;
+            stage_a(pos_first); stage_b();
+            spec_next = stage_fin(pos_first, 0);
+            stage_a(whole ? next_act(pos_first + 1) : 1);
+        } else {
+            stage_a(0); stage_b();
+            spec_next = stage_fin(0, 0);
+            stage_a(1);
+        }
+
+        // --- cache: enter token q (directory now, row through `rowE` -> LDS by the caller), leave token q
         // rows of tokens 0 .. R-1 (whole-walk mode: of every token) enter before the first centre
         for (int q = 0; (PART && whole) ? q < len : (q < R && q < len); ++q) {
             const int32_t v = __builtin_amdgcn_readfirstlane(tok_c(q));
@@ -605,7 +626,14 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(tail_d0[c][k]), "v"(tail_d1[c][k]));
             }
         };
-        for (int pos = 0; pos < len; ++pos) {
+        int pos_next = 0, par = 1;                              // (par: PART whole-walk mode -- parity of the centre's ordinal among the visited ones; toggled at the top of an iteration)
+        for (int pos = PART ? pos_first : 0; pos < len; pos = PART ? pos_next : pos + 1) {
+            // the next two positions the loop will visit (whole-walk mode: the next two that hold a centre word of this bucket)
+            int nx1 = pos + 1, nx2 = pos + 2;
+            if constexpr (PART) {
+                if (whole) { nx1 = next_act(pos + 1); nx2 = next_act(nx1 + 1); }
+                pos_next = nx1; par ^= 1;
+            }
             const int32_t word = __builtin_amdgcn_readfirstlane(tok_w(pos));
             uint32_t spec_cur = spec_next;
             bool fin_done = false;
@@ -641,7 +669,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             // negatives: B for centre pos+1, A for centre pos+2
             PROF_LAP(0);
             stage_b();
-            stage_a(pos + 2);
+            if constexpr (PART) stage_a(nx2); else stage_a(pos + 2);
             PROF_LAP(5);                                             // negative-target pipeline: stage B gathers, stage A Philox + table gather
 
             float yp[NV][VEC], yp0[NV][VEC];                         // the centre's positive row SynNeg[word] (and, RELOAD, as it was loaded)
@@ -653,7 +681,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 alpha = fmaxf(alpha, A.alpha0 * 0.0001f);
                 const u32x4 rw = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)pos, (uint32_t)TAG_WIN | ((uint32_t)A.epoch << 8));
                 const int b = (int)(rw.x % (uint32_t)win);
-                const int32_t *ncur = negs + (pos & 1) * nsamp;
+                const int32_t *ncur = negs + ((PART && whole) ? par : (pos & 1)) * nsamp;
 
                 g_ld(pp, yp);
                 if constexpr (RELOAD) {
@@ -765,7 +793,8 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     if (!fin_done) {
                         // the negative targets of the NEXT centre: their table gather (stage_b, issued before this centre's first prefetch) is older than
                         // the rows just waited for, so consuming it HERE costs no wait; after the pair loop it would be a full drain
-                        spec_next = stage_fin(pos + 1);
+                        if constexpr (PART) spec_next = stage_fin(nx1, whole ? (par ^ 1) : (nx1 & 1));
+                        else spec_next = stage_fin(pos + 1, (pos + 1) & 1);
                         fin_done = true;
                     }
                     if (!((spec_cur >> ai_c) & 1u)) {
@@ -927,7 +956,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             // first everything that CONSUMES loads (the negative targets of the next centre, the leaving row as it is now) -- one drain, of
             // the last pair's stores -- and only then the centre's own stores, after which nothing waits until the next centre's first pair
             // (round 2 stored the centre row, then consumed, then stored the leaving row: three exposed round trips per centre).
-            if (!fin_done) spec_next = stage_fin(pos + 1);          // (a centre without pairs; otherwise done inside its first pair step)
+            if (!fin_done) {                                        // (a centre without pairs; otherwise done inside its first pair step)
+                if constexpr (PART) spec_next = stage_fin(nx1, whole ? (par ^ 1) : (nx1 & 1));
+                else spec_next = stage_fin(pos + 1, (pos + 1) & 1);
+            }
             if (sX >= 0) {
                 float l[NV][VEC];
                 lds_ld(rowsL + (size_t)sX * RW, l);
