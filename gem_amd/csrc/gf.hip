@@ -46,6 +46,7 @@ struct gemhip_gf_plan {
     bool own_X = false;
     int cur = 0;                      // X[cur] holds the latest table
     int rows_per_wave = 0;            // 0 = auto (gf_rows_per_wave), else forced (gemhip_gf_plan_set_rows_per_wave: tests, A/B)
+    int row_stripe = -1;              // -1 = GEMHIP_GF_ROW_STRIPE (default 0: consecutive rows), else the stripe of gf_sweep_rows_kernel
 };
 
 namespace {
@@ -167,15 +168,21 @@ template <int VEC, int NV>
 __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
                                                                  const uint32_t *__restrict__ col, const float *__restrict__ w,
                                                                  const float *Xold, float *Xnew, int64_t row0, int64_t nrows, int d,
-                                                                 float eta, float regu, int K)
+                                                                 float eta, float regu, int K, int stripe)
 {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
-    const int64_t first = (xcd_contiguous_block(blockIdx.x, gridDim.x) * GF_WAVES + wave) * K;
+    // which rows: K consecutive ones (stripe == 0), or -- striped -- rows j, j + stripe, j + 2 stripe, ... of a super-block of stripe x K rows, so that
+    // the `stripe` wavefronts resident on an XCD at any time all work inside one band of ~stripe consecutive rows (whose neighbour rows then meet
+    // in that XCD's L2) instead of K x stripe of them
+    const int64_t wv = xcd_contiguous_block(blockIdx.x, gridDim.x) * GF_WAVES + wave;
+    const int64_t first = stripe > 0 ? (wv / stripe) * ((int64_t)stripe * K) + (wv % stripe) : wv * K;
+    const int64_t step = stripe > 0 ? stripe : 1;
     if (first >= nrows) return;
-    const int nk = (int)((nrows - first) < (int64_t)K ? (nrows - first) : (int64_t)K);
+    const int64_t avail = (nrows - first + step - 1) / step;
+    const int nk = (int)(avail < (int64_t)K ? avail : (int64_t)K);
     int32_t rv = 0; int64_t pa = 0, pb = 0;
-    if (lane < nk) { rv = rows[row0 + first + lane]; pa = ptr[row0 + first + lane]; pb = ptr[row0 + first + lane + 1]; }
+    if (lane < nk) { const int64_t r = row0 + first + (int64_t)lane * step; rv = rows[r]; pa = ptr[r]; pb = ptr[r + 1]; }
     auto lane64 = [&](int64_t v, int k) -> int64_t {
         const uint32_t lo = bcast_lane((uint32_t)v, k), hi = bcast_lane((uint32_t)((uint64_t)v >> 32), k);
         return (int64_t)(((uint64_t)hi << 32) | lo);
@@ -233,6 +240,12 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
 
 // rows per wavefront of a level with `nrows` rows: 1 (gf_sweep_kernel) until every resident wave slot of the chip (256 CUs x 32 waves) has two rows
 // to work on, then up to GEMHIP_GF_ROWS_PER_WAVE (default 8; read once): a level of 946 188 rows (SBM 1M/10M) runs 8 rows per wave
+int gf_row_stripe()
+{
+    static const int st = getenv("GEMHIP_GF_ROW_STRIPE") ? std::max(0, atoi(getenv("GEMHIP_GF_ROW_STRIPE"))) : 0;
+    return st;
+}
+
 int gf_rows_per_wave(int64_t nrows)
 {
     static const int kmax = getenv("GEMHIP_GF_ROWS_PER_WAVE") ? std::max(1, std::min(64, atoi(getenv("GEMHIP_GF_ROWS_PER_WAVE")))) : 8;
@@ -246,11 +259,12 @@ void launch_sweep(const gemhip_gf_plan *p, int64_t row0, int64_t nrows, const fl
 {
     const int K = p->rows_per_wave > 0 ? p->rows_per_wave : gf_rows_per_wave(nrows);
     if (K > 1) {
-        const int64_t waves = (nrows + K - 1) / K;
+        const int stripe = p->row_stripe >= 0 ? p->row_stripe : gf_row_stripe();
+        const int64_t waves = stripe > 0 ? ((nrows + (int64_t)stripe * K - 1) / ((int64_t)stripe * K)) * stripe : (nrows + K - 1) / K;
         const int64_t blocks = (waves + GF_WAVES - 1) / GF_WAVES;
         const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
         hipLaunchKernelGGL((gf_sweep_rows_kernel<VEC, NV>), dim3((unsigned)grid), dim3(GF_BLOCK), 0, s, p->d_rows, p->d_ptr, p->d_col,
-                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K);
+                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K, stripe);
         return;
     }
     const int64_t blocks = (nrows + GF_WAVES - 1) / GF_WAVES;
@@ -678,7 +692,9 @@ extern "C" int gemhip_gf_plan_sweeps(gemhip_gf_plan_t p, int32_t nsweeps, float 
 
 extern "C" int gemhip_gf_plan_set_rows_per_wave(gemhip_gf_plan_t p, int32_t rows_per_wave)
 {
-    GEMHIP_REQUIRE(p && rows_per_wave >= 0 && rows_per_wave <= 64, "gf_plan_set_rows_per_wave: 0 (auto) .. 64");
+    GEMHIP_REQUIRE(p && rows_per_wave >= 0 && (rows_per_wave & 0xffff) <= 64, "gf_plan_set_rows_per_wave: 0 (auto) .. 64");
+    p->row_stripe = rows_per_wave >> 16 ? (rows_per_wave >> 16) - 1 : -1;          // (A/B: bits 16.. = 1 + stripe of the striped row assignment)
+    rows_per_wave &= 0xffff;
     p->rows_per_wave = rows_per_wave;
     return GEMHIP_OK;
 }

@@ -59,6 +59,10 @@ def lib():
         L.oracle_sgns_train.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_float,
                                         C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, f32p, i32p, C.c_uint64,
                                         C.c_int32, f32p, f32p]
+        L.oracle_sgns_train_vocab_order.argtypes = [C.c_int64, i32p, C.c_int32, C.c_int64, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_float,
+                                                    C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, f32p, i32p, C.c_uint64,
+                                                    C.c_int32, f32p, f32p]
+        L.oracle_sgns_train_vocab_order.restype = None
         L.oracle_sgns_init.argtypes = [C.c_int64, C.c_int32, C.c_uint64, f32p, f32p]
         L.oracle_sgns_pairs.restype = C.c_int64
         L.oracle_sgns_pairs.argtypes = [C.c_int64, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, i32p, i32p]
@@ -191,17 +195,51 @@ def sgns_train(walks, window, alpha0, epochs, epoch, tokens_total, token_offset,
                             _p(SynPos, C.c_float), _p(SynNeg, C.c_float))
 
 
+def unigram_build_vocab_order(counts, walks, flags):
+    """InitUnigramTable in the binary's layout (LearnVocab renames the tokens by first appearance in the walk matrix; flag 16 of the library): returns
+    (slot_tab int32[N], UTn float32[n], KTn int32[n], back int32[N], U' float32[N], K' int32[N]) -- N = nodes that occur, slot_tab[slot] = the node a slot
+    names (under flags & 2: the node of KTable'[slot]), UTn / KTn the table indexed by NODE (alias as a node), back = renamed id -> node."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n = len(counts)
+    flat = np.asarray(walks).ravel()
+    ok = flat >= 0
+    first = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first, flat[ok], np.nonzero(ok)[0])
+    back = np.argsort(first, kind='stable')[:int((first < np.iinfo(np.int64).max).sum())].astype(np.int32)
+    U, K = unigram_build(np.ascontiguousarray(counts[back]))
+    slot_tab = np.ascontiguousarray(back[K] if (flags & 2) else back, dtype=np.int32)
+    UTn = np.zeros(n, np.float32); KTn = np.zeros(n, np.int32)
+    UTn[back] = U; KTn[back] = back[K]
+    return slot_tab, UTn, KTn, back, U, K
+
+
+def sgns_train_vocab_order(walks, window, alpha0, epochs, epoch, tokens_total, token_offset, walk_id_offset, slot_tab, UTn, KTn, seed, flags, SynPos,
+                           SynNeg, neg=5):
+    """oracle_sgns_train with the unigram table in the binary's layout (unigram_build_vocab_order).  In place on SynPos / SynNeg."""
+    walks = np.ascontiguousarray(walks, dtype=np.int32)
+    n, d = SynPos.shape
+    lib().oracle_sgns_train_vocab_order(len(slot_tab), _p(slot_tab, C.c_int32), d, walks.shape[0], walks.shape[1], _p(walks, C.c_int32), window, neg,
+                                        alpha0, epochs, epoch, tokens_total, token_offset, walk_id_offset, _p(UTn, C.c_float), _p(KTn, C.c_int32), seed,
+                                        flags, _p(SynPos, C.c_float), _p(SynNeg, C.c_float))
+
+
 def n2v_train(n, src, dst, w, d, walk_len, num_walks, window, epochs, p, q, seed, flags):
-    """Whole pipeline on the CPU, sequential: the meaning of the reference binary for one seed."""
+    """Whole pipeline on the CPU, sequential: the meaning of the reference binary for one seed.  flags & 16: the unigram table in the binary's
+    own layout (first-appearance order), else in node-id order."""
     row_ptr, col, ww = sorted_csr(n, src, dst, w)
     uniform = ww is None or all(np.all(ww[row_ptr[v]:row_ptr[v + 1]] == ww[row_ptr[v]]) for v in range(n) if row_ptr[v + 1] > row_ptr[v])
     U = K = None
     if not uniform:
         U, K = n2v_alias_rows(row_ptr, ww)
     walks = n2v_walks(row_ptr, col, U, K, p, q, num_walks, walk_len, seed, flags)
-    UT, KT = unigram_build(n2v_vocab(n, walks))
     P, N = sgns_init(n, d, seed)
     tot = walks.size
+    if flags & 16:
+        slot_tab, UTn, KTn = unigram_build_vocab_order(n2v_vocab(n, walks), walks, flags)[:3]
+        for ep in range(epochs):
+            sgns_train_vocab_order(walks, window, 0.025, epochs, ep, tot, ep * tot, 0, slot_tab, UTn, KTn, seed, flags, P, N)
+        return P, walks
+    UT, KT = unigram_build(n2v_vocab(n, walks))
     for ep in range(epochs):
         sgns_train(walks, window, 0.025, epochs, ep, tot, ep * tot, 0, UT, KT, seed, flags, P, N)
     return P, walks

@@ -248,11 +248,15 @@ static float sgns_alpha(float alpha0, int64_t t, int64_t denom)
     return a;
 }
 
-void oracle_sgns_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, int32_t window,
-                       int32_t neg, float alpha0, int32_t epochs, int32_t epoch, int64_t tokens_total,
-                       int64_t token_offset, int64_t walk_id_offset, const float *UT, const int32_t *KT, uint64_t seed,
-                       int32_t flags, float *SynPos, float *SynNeg)
+/* The two lookups of RndUnigramInt are kept apart -- slot_tab[floor(u * n_slots)] names the entry X, (UT[X], KT[X]) decide the target -- because the
+ * binary's own table layout (LearnVocab @0x40d560 renames the tokens by first appearance; gemhip_n2v_build_unigram_vocab_order, flag 16) stores the
+ * first in slot space and the second in node space.  Node-id layout: slot_tab == KT, n_slots == n. */
+static void sgns_train_core(int64_t n_slots, const int32_t *slot_tab, int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, int32_t window,
+                            int32_t neg, float alpha0, int32_t epochs, int32_t epoch, int64_t tokens_total,
+                            int64_t token_offset, int64_t walk_id_offset, const float *UT, const int32_t *KT, uint64_t seed,
+                            int32_t flags, float *SynPos, float *SynNeg)
 {
+    (void)flags;
     float *neu1e = (float *)malloc(sizeof(float) * (size_t)d);
     const int64_t denom = (int64_t)epochs * tokens_total + 1;
     for (int64_t wl = 0; wl < nwalks; ++wl) {
@@ -279,8 +283,8 @@ void oracle_sgns_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, c
                     else {
                         const u32x4 rn = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32),
                                                 (uint32_t)pos | ((uint32_t)a << 16), TAG_NEG | ((uint32_t)epoch << 8) | ((uint32_t)j << 16));
-                        const uint32_t slot = mulhi_range(rn.x, (uint32_t)n);
-                        const int32_t X = (flags & 2) ? KT[slot] : (int32_t)slot;
+                        const uint32_t slot = mulhi_range(rn.x, (uint32_t)n_slots);
+                        const int32_t X = slot_tab ? slot_tab[slot] : (int32_t)slot;
                         target = (u01(rn.y) < UT[X]) ? X : KT[X];
                         if (target == word) continue;
                         label = 0.0f;
@@ -304,7 +308,26 @@ void oracle_sgns_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, c
     free(neu1e);
 }
 
-/* InitPosEmb: (U(0,1) - 0.5) / d from the counter stream; InitNegEmb: zeros */
+void oracle_sgns_train(int64_t n, int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, int32_t window,
+                       int32_t neg, float alpha0, int32_t epochs, int32_t epoch, int64_t tokens_total,
+                       int64_t token_offset, int64_t walk_id_offset, const float *UT, const int32_t *KT, uint64_t seed,
+                       int32_t flags, float *SynPos, float *SynNeg)
+{
+    sgns_train_core(n, (flags & 2) ? KT : NULL, d, nwalks, walk_len, walks, window, neg, alpha0, epochs, epoch, tokens_total, token_offset, walk_id_offset,
+                    UT, KT, seed, flags, SynPos, SynNeg);
+}
+
+/* TrainModel with the unigram table in the binary's layout: n_slots = nodes that occur, slot_tab[slot] = the node the slot names (the node of
+ * KTable'[slot] under the RndUnigramInt quirk, else the slot's own node), UT / KT indexed by node (KT: the alias as a NODE). */
+void oracle_sgns_train_vocab_order(int64_t n_slots, const int32_t *slot_tab, int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks,
+                                   int32_t window, int32_t neg, float alpha0, int32_t epochs, int32_t epoch, int64_t tokens_total,
+                                   int64_t token_offset, int64_t walk_id_offset, const float *UT, const int32_t *KT, uint64_t seed,
+                                   int32_t flags, float *SynPos, float *SynNeg)
+{
+    sgns_train_core(n_slots, slot_tab, d, nwalks, walk_len, walks, window, neg, alpha0, epochs, epoch, tokens_total, token_offset, walk_id_offset,
+                    UT, KT, seed, flags, SynPos, SynNeg);
+}
+
 void oracle_sgns_init(int64_t n, int32_t d, uint64_t seed, float *SynPos, float *SynNeg)
 {
     const int64_t total = n * (int64_t)d;

@@ -34,6 +34,7 @@ ap.add_argument('--workdir', default=None)
 ap.add_argument('--rmat-scale', type=int, default=0, help='R-MAT graph (gem_amd.graph.rmat_graph(scale, edges, seed)) instead of the SBM')
 ap.add_argument('--save-emb', default=None, help='write the trained embedding (float32 .npy) here so a later run can re-score a bigger sample')
 ap.add_argument('--load-emb', default=None, help='skip training, score this saved embedding')
+ap.add_argument('--flags', type=int, default=11, help='oracle engine: 11 = SNAP quirks, unigram table in node-id layout (rounds 2-3); 27 = + the binary\'s table layout (first-appearance order)')
 a = ap.parse_args()
 PARAMS = dict(n=a.nodes, edges=a.edges, blocks=a.blocks, seed=a.seed, d=128, walk_len=80, num_walks=10, window=10, p=a.p, q=a.q)
 
@@ -73,12 +74,13 @@ elif a.engine == 'snap':
 else:
     import oracle
     _, src, dst, w, _ = edge_arrays(g)
-    X = oracle.n2v_train(n, src, dst, None, PARAMS['d'], PARAMS['walk_len'], PARAMS['num_walks'], PARAMS['window'], 1, a.p, a.q, 20260923, 11)    # flags 11 = SNAP_COMPAT
+    X = oracle.n2v_train(n, src, dst, None, PARAMS['d'], PARAMS['walk_len'], PARAMS['num_walks'], PARAMS['window'], 1, a.p, a.q, 20260923, a.flags)
+    PARAMS['flags'] = a.flags
     if isinstance(X, tuple):
         X = X[0]
     X = np.asarray(X, dtype=np.float32)
     el = time.time() - t
-    engine = 'oracle/n2v_oracle.c (sequential restatement of SNAP)'
+    engine = 'oracle/n2v_oracle.c (sequential restatement of SNAP)' + (', unigram table in the binary\'s vocabulary-order layout' if a.flags & 16 else '')
 print('trained in %.0fs' % el, flush=True)
 if a.save_emb and not a.load_emb:
     np.save(a.save_emb, X)

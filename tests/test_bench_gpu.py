@@ -89,12 +89,18 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
         ~0.5 % (s.d.; HIP 0.498-0.508 over four seeds), so three HIP seeds are averaged against the binary's single run (measured +0.59, +1.05, +1.62 %: mean +1.1 %, s.d. of the mean ~0.3 %); the expected s.d. of
         that gap is ~0.7 % even for identical algorithms, hence this leg asserts 2 % (a 1 % bar would flake in ~15 % of the runs) and bench.py
         prints the measured gap (`quality.map_minus_reference_map`) for the record."""
-    refs = {e: golden_path(f) for e, f in (('snap', 'n2v_ref_snap_1000k.json'), ('oracle', 'n2v_ref_oracle_1000k_s4096.json'), ('oracle1k', 'n2v_ref_oracle_1000k.json'))}
+    # oracle goldens, best first: the run in the binary's unigram-table layout (flags 27, the plugin default since round 4; scripts/make_golden_n2v_scale.py
+    # --flags 27, 8.4 h of CPU), else the node-id-layout runs of round 3 (flags 11) -- the HIP leg is run with the golden's own flags, so the draws pair
+    refs = {e: golden_path(f) for e, f in (('snap', 'n2v_ref_snap_1000k.json'), ('oracle27', 'n2v_ref_oracle_1000k_vocab_order_s4096.json'),
+                                           ('oracle', 'n2v_ref_oracle_1000k_s4096.json'), ('oracle1k', 'n2v_ref_oracle_1000k.json'))}
     refs = {e: json.load(open(f)) for e, f in refs.items() if os.path.exists(f)}
-    if 'oracle' in refs:
-        refs.pop('oracle1k', None)
-    elif 'oracle1k' in refs:
-        refs['oracle'] = refs.pop('oracle1k')
+    for e in ('oracle27', 'oracle', 'oracle1k'):
+        if e in refs:
+            best = refs[e]
+            for q in ('oracle27', 'oracle', 'oracle1k'):
+                refs.pop(q, None)
+            refs['oracle'] = best
+            break
     if not refs:
         pytest.skip('no 1M/10M reference run committed yet')
     pr = next(iter(refs.values()))['params']
@@ -102,14 +108,15 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
     nmax = max(len(r['ap']) for r in refs.values())
     nodes = np.random.RandomState(0).choice(g.n, size=nmax, replace=False)            # (a smaller golden sample is a prefix of it)
 
-    def run(seed, k):
-        m = node2vec(d=pr['d'], max_iter=1, walk_len=pr['walk_len'], num_walks=pr['num_walks'], con_size=pr['window'], ret_p=1, inout_p=1, seed=seed)
+    def run(seed, k, flags=None):
+        kw = {} if flags is None else {'flags': flags}
+        m = node2vec(d=pr['d'], max_iter=1, walk_len=pr['walk_len'], num_walks=pr['num_walks'], con_size=pr['window'], ret_p=1, inout_p=1, seed=seed, **kw)
         return gr.sampled_ap_gpu(g, None, m.learn_embedding(graph=g, is_weighted=True, no_python=True), nodes[:k])
     if 'oracle' in refs:
         ref = refs['oracle']
         k = len(ref['ap'])
         apo = np.asarray(ref['ap'])[:k]
-        gaps = [float((run(20260923, k) - apo).mean() / apo.mean()) for _ in range(3)]
+        gaps = [float((run(20260923, k, ref['params'].get('flags', 11)) - apo).mean() / apo.mean()) for _ in range(3)]
         print('1M parity, oracle leg (paired): gaps %s over %d nodes' % (np.round(gaps, 4).tolist(), k))
         assert abs(np.mean(gaps)) <= 0.01, (gaps, ref['MAP'])
     if 'snap' in refs:

@@ -82,8 +82,9 @@ def test_eigen_path_agrees_with_block_krylov_and_scipy(monkeypatch):
         for sym in ('0', '1'):
             monkeypatch.setenv('GEMHIP_HOPE_SYM', sym)
             # the forced block-Krylov leg (not what runs at this size by default): the 8 eigenvalues at the bottom of this spectrum are clustered within
-            # 2e-3 and the fp32 Ritz values stop moving at ~1.5e-6 relative -- its tolerance is stated at that floor instead of the 1e-6 default
-            m = LaplacianEigenmaps(d=16) if sym == '1' else LaplacianEigenmaps(d=16, tol=3e-6, max_restarts=40)
+            # 2e-3 and the fp32 Ritz values stop moving at ~1.5e-6 relative (measured: 1.47e-6 after 30 restarts) -- its tolerance is stated just above
+            # that floor instead of the 1e-6 default, with restarts to spare
+            m = LaplacianEigenmaps(d=16) if sym == '1' else LaplacianEigenmaps(d=16, tol=2e-6, max_restarts=60)
             Y = m.learn_embedding(graph=g)
             out[sym] = (Y, m._eigvals.copy(), m._stats['solver'])
         monkeypatch.delenv('GEMHIP_HOPE_SYM')
