@@ -37,6 +37,7 @@ struct gemhip_gf_plan {
     int device = 0;
     std::vector<int64_t> level_off;   // rows of level L are [level_off[L], level_off[L+1])
     std::vector<int64_t> level_hubs;  // ... of which the first level_hubs[L] are hub rows (gf_hub_kernel)
+    std::vector<int64_t> level_maxlen;  // longest non-hub row of the level, in firing edges (the rows-per-wavefront rule looks at it)
     hipStream_t hub_stream = nullptr; hipEvent_t hub_fork = nullptr, hub_join = nullptr;
     int32_t *d_rows = nullptr;        // row ids in processing order (sorted by level, then reference order)
     int64_t *d_ptr = nullptr;         // CSR offsets over d_rows
@@ -46,7 +47,6 @@ struct gemhip_gf_plan {
     bool own_X = false;
     int cur = 0;                      // X[cur] holds the latest table
     int rows_per_wave = 0;            // 0 = auto (gf_rows_per_wave), else forced (gemhip_gf_plan_set_rows_per_wave: tests, A/B)
-    int row_stripe = -1;              // -1 = GEMHIP_GF_ROW_STRIPE (default 0: consecutive rows), else the stripe of gf_sweep_rows_kernel
 };
 
 namespace {
@@ -168,21 +168,18 @@ template <int VEC, int NV>
 __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
                                                                  const uint32_t *__restrict__ col, const float *__restrict__ w,
                                                                  const float *Xold, float *Xnew, int64_t row0, int64_t nrows, int d,
-                                                                 float eta, float regu, int K, int stripe)
+                                                                 float eta, float regu, int K)
 {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
-    // which rows: K consecutive ones (stripe == 0), or -- striped -- rows j, j + stripe, j + 2 stripe, ... of a super-block of stripe x K rows, so that
-    // the `stripe` wavefronts resident on an XCD at any time all work inside one band of ~stripe consecutive rows (whose neighbour rows then meet
-    // in that XCD's L2) instead of K x stripe of them
-    const int64_t wv = xcd_contiguous_block(blockIdx.x, gridDim.x) * GF_WAVES + wave;
-    const int64_t first = stripe > 0 ? (wv / stripe) * ((int64_t)stripe * K) + (wv % stripe) : wv * K;
-    const int64_t step = stripe > 0 ? stripe : 1;
+    // K CONSECUTIVE rows.  (Measured and dropped, round 4: striping a wavefront's rows 512 / 1024 / 2048 apart inside super-blocks, so that the
+    // wavefronts resident on an XCD work in one band of rows at a time -- 560 / 567 / 567 us against 564: the L2 misses of the neighbour gathers are
+    // capacity misses of a 5 MB block in 4 MB of L2, not a matter of which rows run together.)
+    const int64_t first = (xcd_contiguous_block(blockIdx.x, gridDim.x) * GF_WAVES + wave) * K;
     if (first >= nrows) return;
-    const int64_t avail = (nrows - first + step - 1) / step;
-    const int nk = (int)(avail < (int64_t)K ? avail : (int64_t)K);
+    const int nk = (int)((nrows - first) < (int64_t)K ? (nrows - first) : (int64_t)K);
     int32_t rv = 0; int64_t pa = 0, pb = 0;
-    if (lane < nk) { const int64_t r = row0 + first + (int64_t)lane * step; rv = rows[r]; pa = ptr[r]; pb = ptr[r + 1]; }
+    if (lane < nk) { rv = rows[row0 + first + lane]; pa = ptr[row0 + first + lane]; pb = ptr[row0 + first + lane + 1]; }
     auto lane64 = [&](int64_t v, int k) -> int64_t {
         const uint32_t lo = bcast_lane((uint32_t)v, k), hi = bcast_lane((uint32_t)((uint64_t)v >> 32), k);
         return (int64_t)(((uint64_t)hi << 32) | lo);
@@ -240,12 +237,6 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
 
 // rows per wavefront of a level with `nrows` rows: 1 (gf_sweep_kernel) until every resident wave slot of the chip (256 CUs x 32 waves) has two rows
 // to work on, then up to GEMHIP_GF_ROWS_PER_WAVE (default 8; read once): a level of 946 188 rows (SBM 1M/10M) runs 8 rows per wave
-int gf_row_stripe()
-{
-    static const int st = getenv("GEMHIP_GF_ROW_STRIPE") ? std::max(0, atoi(getenv("GEMHIP_GF_ROW_STRIPE"))) : 0;
-    return st;
-}
-
 int gf_rows_per_wave(int64_t nrows)
 {
     static const int kmax = getenv("GEMHIP_GF_ROWS_PER_WAVE") ? std::max(1, std::min(64, atoi(getenv("GEMHIP_GF_ROWS_PER_WAVE")))) : 8;
@@ -257,14 +248,19 @@ template <int VEC, int NV>
 void launch_sweep(const gemhip_gf_plan *p, int64_t row0, int64_t nrows, const float *Xold, float *Xnew, float eta, float regu,
                   hipStream_t s)
 {
-    const int K = p->rows_per_wave > 0 ? p->rows_per_wave : gf_rows_per_wave(nrows);
+    // K rows per wavefront pays where rows are short and alike (SBM: 548 against 579 us per sweep at 1M/10M); on a power-law level a wavefront that
+    // draws a few long rows among its K holds the launch up (R-MAT scale 22: 6.99 against 6.52 ms) -- levels with rows of more than two 64-edge
+    // chunks keep one row per wavefront
+    int64_t maxlen = 0;
+    for (size_t l = 0; l + 1 < p->level_off.size(); ++l)
+        if (row0 >= p->level_off[l] && row0 < p->level_off[l + 1]) maxlen = p->level_maxlen.size() > l ? p->level_maxlen[l] : 0;
+    const int K = p->rows_per_wave > 0 ? p->rows_per_wave : (maxlen > 2 * WAVE ? 1 : gf_rows_per_wave(nrows));
     if (K > 1) {
-        const int stripe = p->row_stripe >= 0 ? p->row_stripe : gf_row_stripe();
-        const int64_t waves = stripe > 0 ? ((nrows + (int64_t)stripe * K - 1) / ((int64_t)stripe * K)) * stripe : (nrows + K - 1) / K;
+        const int64_t waves = (nrows + K - 1) / K;
         const int64_t blocks = (waves + GF_WAVES - 1) / GF_WAVES;
         const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
         hipLaunchKernelGGL((gf_sweep_rows_kernel<VEC, NV>), dim3((unsigned)grid), dim3(GF_BLOCK), 0, s, p->d_rows, p->d_ptr, p->d_col,
-                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K, stripe);
+                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K);
         return;
     }
     const int64_t blocks = (nrows + GF_WAVES - 1) / GF_WAVES;
@@ -582,6 +578,9 @@ extern "C" int gemhip_gf_plan_create(int64_t n, int64_t m, const int32_t *src, c
     p->n = n; p->d = d; p->nrows = nrows; p->nupd = nupd;
     p->level_off.assign(lvl_cnt.begin(), lvl_cnt.end());
     p->level_hubs = level_hubs;
+    p->level_maxlen.assign(nlevels, 0);
+    for (int32_t l = 0; l < nlevels; ++l)
+        for (int64_t q = lvl_cnt[l] + level_hubs[l]; q < lvl_cnt[l + 1]; ++q) p->level_maxlen[l] = std::max(p->level_maxlen[l], ptr_sorted[q + 1] - ptr_sorted[q]);
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail(GEMHIP_E_HIP, "gf_plan_create: no HIP device"); }
     phase_acc()[PH_HOST] += phase_now() - t_host0;
     PhaseScope ph_up(PH_H2D);
@@ -692,9 +691,7 @@ extern "C" int gemhip_gf_plan_sweeps(gemhip_gf_plan_t p, int32_t nsweeps, float 
 
 extern "C" int gemhip_gf_plan_set_rows_per_wave(gemhip_gf_plan_t p, int32_t rows_per_wave)
 {
-    GEMHIP_REQUIRE(p && rows_per_wave >= 0 && (rows_per_wave & 0xffff) <= 64, "gf_plan_set_rows_per_wave: 0 (auto) .. 64");
-    p->row_stripe = rows_per_wave >> 16 ? (rows_per_wave >> 16) - 1 : -1;          // (A/B: bits 16.. = 1 + stripe of the striped row assignment)
-    rows_per_wave &= 0xffff;
+    GEMHIP_REQUIRE(p && rows_per_wave >= 0 && rows_per_wave <= 64, "gf_plan_set_rows_per_wave: 0 (auto) .. 64");
     p->rows_per_wave = rows_per_wave;
     return GEMHIP_OK;
 }
@@ -724,7 +721,10 @@ extern "C" int gemhip_gf_plan_info(gemhip_gf_plan_t p, int64_t *info)
     {   // rows per wavefront the largest level's sweep launch will use (1: gf_sweep_kernel, > 1: gf_sweep_rows_kernel)
         int64_t big = 0;
         for (size_t l = 0; l + 1 < p->level_off.size(); ++l) big = std::max<int64_t>(big, p->level_off[l + 1] - p->level_off[l]);
-        info[6] = p->rows_per_wave > 0 ? p->rows_per_wave : gf_rows_per_wave(big);
+        int64_t bigmax = 0;
+        for (size_t l = 0; l + 1 < p->level_off.size(); ++l)
+            if (p->level_off[l + 1] - p->level_off[l] == big) bigmax = p->level_maxlen.size() > l ? p->level_maxlen[l] : 0;
+        info[6] = p->rows_per_wave > 0 ? p->rows_per_wave : (bigmax > 2 * WAVE ? 1 : gf_rows_per_wave(big));
     }
     info[7] = 0;
     return GEMHIP_OK;

@@ -97,6 +97,7 @@ struct SgnsKnobs {
     int32_t reload = 1;               // Hogwild launches: update negative rows as they are at store time (second fetch) and the centre row by atomic add
     int32_t hot_count = -1;           // nodes with at least this many tokens never enter the LDS window: -1 auto (tokens / ((W-1) x (2R+1))), 0 off
     int32_t window_span = 0;          // positions of a walk whose context rows a wavefront holds at once: 0 = 2R+1 (the sliding window); the whole walk in the bucket kernel's whole-walk mode
+    bool part = false;                // a bucket launch of the partitioned schedule (sgns_win_kernel<PART>: as-loaded window copies in global scratch, 3 wavefronts per SIMD)
     double duty = 1.0;                // fraction of a wavefront's time spent in pair steps (negative rows open); < 1 only for the buckets of the partitioned schedule
 };
 // ... and what a launch of TrainModel over `nwalks` walks then looks like (pure host arithmetic: gemhip_sgns_plan_launch exposes it to the CPU tests)
@@ -145,6 +146,7 @@ struct gemhip_n2v {
     SgnsKnobs kn;                     // launch knobs (setters below; environment overrides read once in gemhip_n2v_create)
     VocabStats vs;                    // vocabulary statistics (gemhip_n2v_build_unigram*): how concentrated the row traffic is -> plan_sgns_launch
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
+    float *d_scratch = nullptr; size_t scratch_bytes = 0;   // sgns_win_kernel<PART>: the window rows as loaded, 2R+1 rows per wavefront
     unsigned long long *d_pairs = nullptr;   // (centre,context) pairs trained so far
     // per-partition unigram tables (multi-GPU episode schedule): partition p = {v : v % parts == p}, local index v / parts
     int32_t parts = 0;
@@ -392,7 +394,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
 {
     if (!h) return GEMHIP_OK;
     hipFree(h->d_start);
-    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy);
+    hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_scratch);
     if (h->own_counts) hipFree(h->d_counts);
     hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_KTslot); hipFree(h->d_first); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
@@ -784,7 +786,8 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
     const size_t ints = (size_t)((walk_len + 4 * window * SGNS_NEG + 3) & ~3);
     // tokens + negative targets of two centres, the window rows (twice with the delta write-back: as trained / as loaded) and -- unless every context
     // row is cached (`allc`: R >= window and no hot rows, the launcher's ALLC instantiations) -- one staging row for an uncached context
-    auto lds_bytes = [&](bool delta, bool allc) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * (delta ? 2 : 1) + (allc ? 0 : 1)) * rw * sizeof(float); };
+    // (kn.part: the bucket kernels keep the as-loaded copies in a global scratch instead of LDS)
+    auto lds_bytes = [&](bool delta, bool allc) { return ints * sizeof(int32_t) + (size_t)((2 * R + 1) * ((delta && !kn.part) ? 2 : 1) + (allc ? 0 : 1)) * rw * sizeof(float); };
     // the window has to fit a block's LDS: wide rows / long walks fall back to sgns_kernel
     P.window = R > 0 && !(flags & GEMHIP_N2V_NO_WINDOW_CACHE) && 2 * window * SGNS_NEG <= 2 * WAVE && walk_len >= 2 && lds_bytes(true, false) <= 64 * 1024 &&
                (d % 2 == 0 ? d <= 512 : d <= 256);
@@ -833,7 +836,8 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         // 26 % of its 5 936 active rows open ended 21 % ABOVE the sequential algorithm's MAP: its hubs under-trained)
         const int64_t w_act = std::max<int64_t>(1, (int64_t)((vs.active > 0.0 ? vs.active : (double)n) / 50.0));
         auto width = [&](bool all_cached) -> int64_t {
-            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta, all_cached) + 512)));   // 184 VGPRs: 2 per SIMD
+            // registers: the single-GPU kernels allocate 176-184 VGPRs (2 wavefronts per SIMD = 8 per CU), the bucket kernels 136-145 (3 per SIMD = 12 per CU)
+            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(kn.part ? 12 : 8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta, all_cached) + 512)));
             const int64_t w_dev = std::min<int64_t>(256 * per_cu, nwalks);
             const double w_steps = w_steps_of(all_cached);
             const bool reload_eff = w_steps < 1.0;
@@ -884,7 +888,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     }
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->kn.prefetch; A.reload = h->kn.reload; A.counts = nullptr; A.hot_thr = 0;
-    A.parts = 0; A.ctx_part = 0; A.word_part = 0; A.seg = nullptr; A.nseg = 0; A.seg_len = 0;
+    A.parts = 0; A.ctx_part = 0; A.word_part = 0; A.seg = nullptr; A.nseg = 0; A.seg_len = 0; A.scratch = nullptr;
     const SgnsLaunchPlan P = plan_sgns_launch(h->vs, h->kn, h->n, h->d, window, h->walk_len, walk_hi - walk_lo, flags);
     GEMHIP_REQUIRE(P.lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for LDS staging (%zu bytes)", P.lds);
     A.nwaves = (int32_t)P.waves; A.cache_radius = P.R;
@@ -973,7 +977,7 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     VocabStats vs = h->vs_part[word_part];
     vs.total = h->vs.total; vs.max = h->vs.max;
     SgnsKnobs kn = h->kn;
-    kn.prefetch = 2; kn.reload = 1;
+    kn.prefetch = 2; kn.reload = 1; kn.part = true;
     // Duty cycle.  The rule bounds the negative rows that are OPEN at any time (W x 5 x w of them).  A wavefront of a bucket launch spends only part of
     // its time in pair steps: per walk it has walk_len x (window + 1) x 0.95 / parts^2 pairs to train but still 2 x walk_len / parts rows (the contexts and
     // the centre words of its two partitions) to fetch and return, each an exposed round trip of ~0.7 pair steps.  With that fraction f of the time in
@@ -996,6 +1000,16 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
         h->dummy_bytes = need;
     }
     A.dummy = h->d_dummy;
+    A.scratch = nullptr;
+    if (P.delta) {
+        const size_t sneed = (size_t)P.waves * (size_t)(2 * P.R + 1) * sgns_win_row_floats(d) * sizeof(float);
+        if (sneed > h->scratch_bytes) {
+            if (h->d_scratch) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_scratch); h->d_scratch = nullptr; h->scratch_bytes = 0; }
+            GEMHIP_CHECK(hipMalloc(&h->d_scratch, sneed));
+            h->scratch_bytes = sneed;
+        }
+        A.scratch = h->d_scratch;
+    }
     sgns_fn fn = pick_sgns_win_part(d, P.delta);
     GEMHIP_REQUIRE(fn != nullptr, "sgns_train_part: d=%d unsupported", d);
     fn(A, P.blocks, P.threads, P.lds, (hipStream_t)stream);

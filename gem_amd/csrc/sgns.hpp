@@ -33,6 +33,7 @@ struct SgnsArgs {
     // `walks`, present when j < seg[nseg + r], with global walk id (the Philox key) seg[2 * nseg + r] + j.  seg == nullptr: one segment, row = wl,
     // walk id = walk_id_offset + wl
     const int64_t *seg; int32_t nseg; int64_t seg_len;
+    float *scratch;             // sgns_win_kernel<PART, DELTA>: nwaves x (2R+1) rows -- the window rows as loaded (delta write-back), kept out of LDS
 };
 
 using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
@@ -390,7 +391,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     float *rowsL = reinterpret_cast<float *>(lds + ((len + 2 * nsamp + 3) & ~3));
     // slot S of rowsL stages a context row that is not cached -- instantiations that cache every context (ALLC) do not carry it: at d = 128, R = 10 that
     // brings a wavefront's LDS from 23 136 to 22 624 bytes, i.e. from six to SEVEN wavefronts per CU (plan_sgns_launch sizes the launch the same way)
-    float *rowsO = rowsL + (size_t)(S + (ALLC ? 0 : 1)) * RW;     // DELTA only: the rows as loaded
+    // DELTA only: the rows as loaded.  In LDS next to the working copies -- except in the bucket kernels (PART), which keep them in a per-wavefront
+    // global scratch (written once when a row enters, read once when it leaves; it stays in L2): half the LDS per wavefront lets 12 instead of 7 share a CU,
+    // and a bucket launch, whose wavefronts wait on row fetches most of the time (section 6 of DESIGN.md), needs the wavefronts more than the LDS
+    float *rowsO = PART ? A.scratch + (size_t)gw * (size_t)(2 * R + 1) * RW : rowsL + (size_t)(S + (ALLC ? 0 : 1)) * RW;
 
     auto lds_ld = [&](const float *row, float (&v)[NV][VEC]) {
 #pragma unroll
@@ -420,10 +424,16 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         else return A.hot_thr > 0 && A.counts[PART ? (int64_t)v * A.parts + A.ctx_part : (int64_t)v] >= A.hot_thr;
     };
     auto o_st = [&](int slot, const float (&v)[NV][VEC]) {            // the row as loaded (delta write-back)
-        lds_st(rowsO + (size_t)slot * RW, v);
+        if constexpr (PART) {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) st_row<VEC>(rowsO + (size_t)slot * RW, NV * VEC * WAVE, lane, c, v[c]);
+        } else lds_st(rowsO + (size_t)slot * RW, v);
     };
     auto o_ld = [&](int slot, float (&v)[NV][VEC]) {
-        lds_ld(rowsO + (size_t)slot * RW, v);
+        if constexpr (PART) {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) ld_row<VEC>(rowsO + (size_t)slot * RW, NV * VEC * WAVE, lane, c, v[c]);
+        } else lds_ld(rowsO + (size_t)slot * RW, v);
     };
     unsigned long long npairs = 0;
     PROF_DECL;

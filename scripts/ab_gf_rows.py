@@ -6,7 +6,6 @@ import numpy as np, torch
 from gem_amd import _hip
 from gem_amd.graph import sbm_graph, edge_arrays
 
-# an argument K or K:stripe (stripe: rows j, j + stripe, ... of super-blocks of stripe x K rows per wavefront instead of K consecutive rows)
 ks = [a for a in sys.argv[1:]] or ['1', '2', '4', '8', '16', '32']
 nodes, edges, blocks = (int(os.environ.get(k, v)) for k, v in (('NODES', 1000000), ('EDGES', 10000000), ('BLOCKS', 100)))
 g = sbm_graph(nodes, edges, blocks, seed=20260923 + 4)
@@ -16,13 +15,12 @@ dev = torch.device('cuda', 0)
 X0 = (0.01 * torch.randn(n, d, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))).contiguous()
 ref = None
 for spec in ks:
-    k, _, st = spec.partition(':')
-    k = int(k); st = int(st) if st else 0
+    k, st = int(spec), 0
     Xa, Xb = X0.clone(), X0.clone()
     plan = C.c_void_p()
     _hip.check(L.gemhip_gf_plan_create(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, d, 0, n, C.byref(plan)))
     _hip.check(L.gemhip_gf_plan_bind(plan, C.c_void_p(Xa.data_ptr()), C.c_void_p(Xb.data_ptr())))
-    _hip.check(L.gemhip_gf_plan_set_rows_per_wave(plan, k | ((st + 1) << 16)))
+    _hip.check(L.gemhip_gf_plan_set_rows_per_wave(plan, k))
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _hip.check(L.gemhip_gf_plan_sweeps(plan, 10, 1e-2, 1e-2, s))                 # warm-up (even count: result lands in Xa)
     torch.cuda.synchronize()
@@ -34,6 +32,6 @@ for spec in ks:
     comp = info[1] * 2 * 4 * d + info[0] * (4 * d + 8)
     if ref is None:
         ref = Xa.clone()
-    print(json.dumps(dict(rows_per_wave=k, stripe=st, us_per_sweep=us, compulsory_GBs=comp / us / 1e3, frac_of_8TBs=comp / us / 1e3 / 8000.0,
+    print(json.dumps(dict(rows_per_wave=k, us_per_sweep=us, compulsory_GBs=comp / us / 1e3, frac_of_8TBs=comp / us / 1e3 / 8000.0,
                           bit_identical_to_first=bool(torch.equal(Xa, ref)), rows=info[1], updates=info[0])), flush=True)
     _hip.check(L.gemhip_gf_plan_destroy(plan))

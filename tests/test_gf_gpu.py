@@ -211,7 +211,7 @@ def test_rows_per_wave_kernel_is_bit_identical(d, k, sbm1024, karate):
         X0 = (0.01 * np.random.RandomState(3).randn(n, d)).astype(np.float32)
         L = _hip.lib()
         out = {}
-        for kk in (1, k, k | ((37 + 1) << 16)):          # K consecutive rows, and K rows striped 37 apart (the A/B form of the row assignment)
+        for kk in (1, k):
             plan = C.c_void_p()
             _hip.check(L.gemhip_gf_plan_create(n, len(src), _hip.ptr(_hip.as_i32(src), C.c_int32), _hip.ptr(_hip.as_i32(dst), C.c_int32),
                                                _hip.ptr(_hip.as_f32(w), C.c_float), d, 0, n, C.byref(plan)))
@@ -222,7 +222,7 @@ def test_rows_per_wave_kernel_is_bit_identical(d, k, sbm1024, karate):
             _hip.check(L.gemhip_gf_plan_get_embedding(plan, _hip.ptr(X, C.c_float)))
             _hip.check(L.gemhip_gf_plan_destroy(plan))
             out[kk] = X
-        assert np.array_equal(out[1], out[k]) and np.array_equal(out[1], out[k | (38 << 16)]), name
+        assert np.array_equal(out[1], out[k]), name
         if name != 'dense':
             assert_close(out[k], oracle.gf_train_f32(n, src, dst, w, d, 0.02, 0.01, 4, X0))
 

@@ -94,8 +94,8 @@ def test_eigen_path_agrees_with_block_krylov_and_scipy(monkeypatch):
     deg = np.asarray(A.sum(axis=1)).ravel(); dinv = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1e-300)), 0.0)
     M = sp.diags(dinv) @ A @ sp.diags(dinv)
     ref = 1.0 - np.sort(sla.eigsh(M, k=17, which='LA', tol=1e-10)[0])[::-1]            # eigenvalues of L_sym ascending
-    for key in ('0', '1'):
-        assert np.allclose(out[key][1], ref, atol=1e-5), (key, np.abs(out[key][1] - ref).max())
+    for key in ('0', '1'):          # (the forced block-Krylov leg stops at twice the default tolerance: twice the bar)
+        assert np.allclose(out[key][1], ref, atol=2e-5 if key == '0' else 1e-5), (key, np.abs(out[key][1] - ref).max())
     Y0, Y1 = out['0'][0], out['1'][0]
     Ya = align(Y1, Y0)
     assert np.abs(Ya[:, :7] - Y0[:, :7]).max() < 5e-4                                 # the 7 non-trivial community vectors
