@@ -85,3 +85,28 @@ def test_round3_default_line_is_one_run_with_every_baseline_config():
         w = j['workloads'][name]
         pc = w['roofline']['pcie_inclusive']
         assert pc['outputs_identical_to_device_form'] and pc['seconds_per_step'] >= 1e-3 * w['ms_per_step'] * 0.98
+
+
+def test_round4_default_line_carries_api_wall_and_honest_gf_fractions():
+    """profiles/r04_bench_all.json = stdout of ONE un-profiled `python bench.py` of round 4: every roofline fraction is a fraction (GF's compulsory bytes,
+    not the 1548-byte comparability figure that printed 1.6 in rounds 1-3), every BASELINE workload carries the `learn_embedding` API wall
+    with its breakdown, the SNAP leg its own (text dump + binary + load), and the headline reports both parity legs."""
+    j = json.loads(open(os.path.join(ROOT, 'profiles', 'r04_bench_all.json')).read().strip().splitlines()[-1])
+    _check_line(j)
+    assert j['config']['workload'].startswith('sbm1000k_10000k_node2vec')
+    for name, w in [('headline', j)] + list(j['workloads'].items()):
+        if not isinstance(w, dict) or 'roofline' not in w:
+            continue
+        assert 0.0 < w['roofline']['frac'] < 1.0, (name, w['roofline']['frac'])
+        a = w['api_wall']
+        for k in ('seconds', 'ingest_s', 'h2d_s', 'kernels_s', 'd2h_float64_s'):
+            assert k in a and a[k] >= 0.0, (name, k)
+        assert a['seconds'] >= a['kernels_s'] > 0.0
+    g = j['workloads']['gf_sbm1m_10m']['roofline']
+    assert g['kernel'] == 'gf_sweep_rows_kernel' and g['comparability_GBs'] > g['achieved'] and 0.7 < g['frac'] < 0.9
+    assert 'regime' in j['workloads']['gf_sbm10k_100k_run_sbm_setting']['roofline']
+    for leg in ('all_cores', 'single_thread_race_free'):
+        assert j['cpu_baseline'][leg]['api_wall']['seconds'] >= j['cpu_baseline'][leg]['api_wall']['binary_s']
+    q = j['quality']
+    assert q['unigram_layout'].startswith('vocabulary order') and abs(q['map_minus_oracle_map']) <= 0.01 * q['oracle_map']
+    assert abs(q['map_minus_reference_map']) <= 0.02 * q['reference_map']
