@@ -389,3 +389,34 @@ def test_vocab_order_unigram_table_is_the_binarys(name):
     assert KT[:N].tolist() == K64
     np.testing.assert_allclose(UT[:N], np.asarray(U64), rtol=0, atol=1e-6)
     dev.close()
+
+
+@pytest.mark.parametrize('gname,d,window,l,flags', [('karate', 8, 5, 30, 27), ('sbm1024', 128, 10, 24, 27), ('karate', 16, 10, 40, 27 & ~2)])
+def test_sgns_deterministic_with_the_binarys_table_layout_matches_oracle(gname, d, window, l, flags, request):
+    """flags | 16 (GEMHIP_N2V_VOCAB_ORDER): the unigram alias table in the binary's layout, stored in node space (slot table + per-node {U, alias}).  One
+    wavefront in walk order against oracle_sgns_train_vocab_order -- TrainModel with the same two-step lookup -- on the same draws: 2e-4, like the node-id
+    layout.  (Without the RndUnigramInt quirk -- last case -- a slot names its own node instead of its alias.)"""
+    G = request.getfixturevalue(gname)
+    n, src, dst, w, _ = edge_arrays(G)
+    dev = Dev(n, src, dst, w)
+    walks = dev.walks(1.0, 1.0, 10 if gname == 'karate' else 1, l, 21, flags)
+    if gname == 'sbm1024':
+        walks = walks[:96]
+        _hip.check(dev.L.gemhip_n2v_set_walks(dev.h, _hip.ptr(walks, C.c_int32), walks.shape[0], l, 0))
+    _hip.check(dev.L.gemhip_n2v_vocab(dev.h, None))
+    nv = C.c_int64(); order = np.full(n, -1, np.int32); UT = np.zeros(n, np.float32); KT = np.zeros(n, np.int32)
+    _hip.check(dev.L.gemhip_n2v_build_unigram_vocab_order(dev.h, flags, C.byref(nv), _hip.ptr(order, C.c_int32), _hip.ptr(UT, C.c_float), _hip.ptr(KT, C.c_int32)))
+    counts = oracle.n2v_vocab(n, walks)
+    slot_tab, UTn, KTn, back, U, K = oracle.unigram_build_vocab_order(counts, walks, flags)
+    assert nv.value == len(back) and np.array_equal(order[:nv.value], back) and np.array_equal(KT[:nv.value], K) and np.array_equal(UT[:nv.value], U)
+    _hip.check(dev.L.gemhip_sgns_init(dev.h, d, 21, None, None))
+    tot = walks.size
+    _hip.check(dev.L.gemhip_sgns_train(dev.h, window, 5, 0.025, 1, 0, 0, walks.shape[0], tot, 0, 21, flags | 4, None))
+    P = np.empty((n, d), np.float32); N = np.empty((n, d), np.float32)
+    _hip.check(dev.L.gemhip_sgns_get_tables(dev.h, _hip.ptr(P, C.c_float), _hip.ptr(N, C.c_float)))
+    Po, No = oracle.sgns_init(n, d, 21)
+    oracle.sgns_train_vocab_order(walks, window, 0.025, 1, 0, tot, 0, 0, slot_tab, UTn, KTn, 21, flags, Po, No)
+    for got, want in ((P, Po), (N, No)):
+        scale = float(np.abs(want).max())
+        assert float(np.abs(got - want).max()) <= 2e-4 * scale + 1e-6, (np.abs(got - want).max(), scale)
+    dev.close()
