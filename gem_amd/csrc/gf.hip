@@ -47,6 +47,9 @@ struct gemhip_gf_plan {
     bool own_X = false;
     int cur = 0;                      // X[cur] holds the latest table
     int rows_per_wave = 0;            // 0 = auto (gf_rows_per_wave), else forced (gemhip_gf_plan_set_rows_per_wave: tests, A/B)
+    // the sweep's row stores carry the non-temporal hint: a row written in a sweep is not read again before the next one, and at 1M rows the 484 MB a
+    // sweep writes would otherwise share each XCD's 4 MB of L2 with the 5 MB neighbour set the gathers hit in (GEMHIP_GF_NT_STORE, read per plan)
+    int nt_store = getenv("GEMHIP_GF_NT_STORE") ? atoi(getenv("GEMHIP_GF_NT_STORE")) : 0;
 };
 
 namespace {
@@ -70,6 +73,42 @@ __device__ __forceinline__ void load_row(const float *__restrict__ p, int d, int
         else { v[0] = 0.f; v[1] = 0.f; }
     } else {
         v[0] = idx < d ? p[idx] : 0.f;
+    }
+}
+
+// a wave's OWN row: with rows visited in ascending order its last use of the sweep (only lower rows gather it, and they ran before) -- bit 2 of the
+// plan's nt_store asks for the non-temporal hint on this load as well
+template <int VEC>
+__device__ __forceinline__ void load_own_row(const float *__restrict__ p, int d, int lane, int c, float (&v)[VEC], int nt)
+{
+    const int idx = (c * WAVE + lane) * VEC;
+    if (!(nt & 2)) { load_row<VEC>(p, d, lane, c, v); return; }
+    if constexpr (VEC == 2) {
+        typedef float gf_f2 __attribute__((ext_vector_type(2)));
+        if (idx < d) { const gf_f2 t = __builtin_nontemporal_load(reinterpret_cast<const gf_f2 *>(p + idx)); v[0] = t.x; v[1] = t.y; }
+        else { v[0] = 0.f; v[1] = 0.f; }
+    } else {
+        v[0] = idx < d ? __builtin_nontemporal_load(p + idx) : 0.f;
+    }
+}
+
+template <int VEC, int NV>
+__device__ __forceinline__ void store_row(float *po, int d, int lane, const float (&xi)[NV][VEC], int nt)
+{
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int idx = (c * WAVE + lane) * VEC;
+        if (idx < d) {
+            if constexpr (VEC == 2) {
+                typedef float gf_f2 __attribute__((ext_vector_type(2)));
+                gf_f2 v; v.x = xi[c][0]; v.y = xi[c][1];
+                if (nt & 1) __builtin_nontemporal_store(v, reinterpret_cast<gf_f2 *>(po + idx));
+                else *reinterpret_cast<gf_f2 *>(po + idx) = v;
+            } else {
+                if (nt & 1) __builtin_nontemporal_store(xi[c][0], po + idx);
+                else po[idx] = xi[c][0];
+            }
+        }
     }
 }
 
@@ -122,7 +161,7 @@ template <int VEC, int NV>
 __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
                                                             const uint32_t *__restrict__ col, const float *__restrict__ w,
                                                             const float *Xold, float *Xnew, int64_t row0, int64_t nrows, int d,
-                                                            float eta, float regu)
+                                                            float eta, float regu, int nt)
 {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -135,7 +174,7 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_kernel(const int32_t *__res
     float xi[NV][VEC];
     const float *pi = Xold + (int64_t)i * d;
 #pragma unroll
-    for (int c = 0; c < NV; ++c) load_row<VEC>(pi, d, lane, c, xi[c]);
+    for (int c = 0; c < NV; ++c) load_own_row<VEC>(pi, d, lane, c, xi[c], nt);
 
     // hub rows (power-law graphs) are one long dependent chain of updates: only memory latency can be hidden, so full
     // 64-edge chunks keep GF_PREFETCH_DEEP neighbour rows in flight instead of GF_PREFETCH
@@ -148,15 +187,7 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_kernel(const int32_t *__res
         if (cnt == WAVE) gf_chunk<VEC, NV, DEEP>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
         else gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
     }
-    float *po = Xnew + (int64_t)i * d;
-#pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int idx = (c * WAVE + lane) * VEC;
-        if (idx < d) {
-            if constexpr (VEC == 2) *reinterpret_cast<float2 *>(po + idx) = make_float2(xi[c][0], xi[c][1]);
-            else po[idx] = xi[c][0];
-        }
-    }
+    store_row<VEC, NV>(Xnew + (int64_t)i * d, d, lane, xi, nt);
 }
 
 // The same sweep with K consecutive rows per wavefront (large levels; round 4).  A wave that owns ONE row spends its life in a chain of dependent
@@ -168,7 +199,7 @@ template <int VEC, int NV>
 __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
                                                                  const uint32_t *__restrict__ col, const float *__restrict__ w,
                                                                  const float *Xold, float *Xnew, int64_t row0, int64_t nrows, int d,
-                                                                 float eta, float regu, int K)
+                                                                 float eta, float regu, int K, int nt)
 {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -193,7 +224,7 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
     float wj_n = lane < cnt_n ? w[e0_n + lane] : 0.f;
     float xi_n[NV][VEC];
 #pragma unroll
-    for (int c = 0; c < NV; ++c) load_row<VEC>(Xold + (int64_t)i_n * d, d, lane, c, xi_n[c]);
+    for (int c = 0; c < NV; ++c) load_own_row<VEC>(Xold + (int64_t)i_n * d, d, lane, c, xi_n[c], nt);
     for (int k = 0; k < nk; ++k) {
         const int32_t i = i_n;
         const int64_t e0 = e0_n, e1 = e1_n;
@@ -212,7 +243,7 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
             cj_n = lane < cnt_n ? col[e0_n + lane] : 0u;
             wj_n = lane < cnt_n ? w[e0_n + lane] : 0.f;
 #pragma unroll
-            for (int c = 0; c < NV; ++c) load_row<VEC>(Xold + (int64_t)i_n * d, d, lane, c, xi_n[c]);
+            for (int c = 0; c < NV; ++c) load_own_row<VEC>(Xold + (int64_t)i_n * d, d, lane, c, xi_n[c], nt);
         }
         if (cnt0 == WAVE) gf_chunk<VEC, NV, DEEP>(xi, cj0, wj0, cnt0, Xold, Xnew, d, lane, eta, regu);
         else if (cnt0 > 0) gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj0, wj0, cnt0, Xold, Xnew, d, lane, eta, regu);
@@ -223,15 +254,7 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
             if (cnt == WAVE) gf_chunk<VEC, NV, DEEP>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
             else gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
         }
-        float *po = Xnew + (int64_t)i * d;
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            const int idx = (c * WAVE + lane) * VEC;
-            if (idx < d) {
-                if constexpr (VEC == 2) *reinterpret_cast<float2 *>(po + idx) = make_float2(xi[c][0], xi[c][1]);
-                else po[idx] = xi[c][0];
-            }
-        }
+        store_row<VEC, NV>(Xnew + (int64_t)i * d, d, lane, xi, nt);
     }
 }
 
@@ -260,14 +283,14 @@ void launch_sweep(const gemhip_gf_plan *p, int64_t row0, int64_t nrows, const fl
         const int64_t blocks = (waves + GF_WAVES - 1) / GF_WAVES;
         const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
         hipLaunchKernelGGL((gf_sweep_rows_kernel<VEC, NV>), dim3((unsigned)grid), dim3(GF_BLOCK), 0, s, p->d_rows, p->d_ptr, p->d_col,
-                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K);
+                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K, p->nt_store);
         return;
     }
     const int64_t blocks = (nrows + GF_WAVES - 1) / GF_WAVES;
     // round the grid up to a multiple of 8 so the XCD-contiguous map covers every slot
     const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
     hipLaunchKernelGGL((gf_sweep_kernel<VEC, NV>), dim3((unsigned)grid), dim3(GF_BLOCK), 0, s, p->d_rows, p->d_ptr, p->d_col,
-                       p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu);
+                       p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, p->nt_store);
 }
 
 // Hub rows (power-law graphs).  The updates of one row are one dependent chain (exact Gauss-Seidel): a wave that also fetches its

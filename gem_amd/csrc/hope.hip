@@ -257,6 +257,75 @@ __global__ __launch_bounds__(256) void hope_tsgemm_kernel(int64_t n, const float
     }
 }
 
+// ------------------------------------------- Ritz rotation + residual norms in one pass  (MFMA fp32)
+// Out = V C (the Ritz vectors) and, without ever storing it, R = B C - (V C) diag(theta): only the column norms of R are wanted, so every 32 x 32
+// tile leaves its columns' sums of squares in part[row tile][column] (fp32; summed in fp64, in a fixed order, by hope_colsum_kernel).  Same tiling
+// and k relabelling as hope_tsgemm_kernel; V and B rows are read once per column tile.  Replaces three tall-skinny GEMMs and a full m x m Gram of R.
+__global__ __launch_bounds__(256) void hope_ritz_kernel(int64_t n, const float *__restrict__ V, int ldv, const float *__restrict__ B, int ldb, int m,
+                                                        const float *__restrict__ Cm, int ldc, int b2, const float *__restrict__ theta,
+                                                        float *__restrict__ Out, int ldo, float *__restrict__ part, int b2p, int ct_count)
+{
+    const int lane = lane_id();
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t rt = tile / ct_count;
+    const int ct = (int)(tile - rt * ct_count);
+    if (rt * 32 >= n) return;
+    const int64_t irow = rt * 32 + (lane & 31);
+    const int jcol = ct * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const bool vr = irow < n, vc = jcol < b2;
+    const float *pv = V + irow * ldv, *pb = B + irow * ldb;
+    f32x16 av, ab;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { av[q] = 0.f; ab[q] = 0.f; }
+    for (int k0 = 0; k0 < m; k0 += 8) {
+        float a[4], a2[4], bb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = k0 + 4 * h + t;
+            const bool vk = k < m;
+            a[t] = (vr && vk) ? pv[k] : 0.f;
+            a2[t] = (vr && vk) ? pb[k] : 0.f;
+            bb[t] = (vc && vk) ? Cm[(int64_t)k * ldc + jcol] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bb[t], av, 0, 0, 0);
+            ab = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t], bb[t], ab, 0, 0, 0);
+        }
+    }
+    const float th = vc ? theta[jcol] : 0.f;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int64_t row = rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const float r = fmaf(-th, av[q], ab[q]);
+        ss = fmaf(r, r, ss);                                  // (rows beyond n contribute exact zeros: their a, a2 were 0)
+        if (vc && row < n) Out[row * ldo + jcol] = av[q];
+    }
+    ss += __shfl_xor(ss, 32);
+    if (h == 0 && vc) part[rt * b2p + jcol] = ss;
+}
+// out[j] = sum over the row tiles of part[.][j], fp64, fixed order (one block per column)
+__global__ __launch_bounds__(256) void hope_colsum_kernel(const float *__restrict__ part, int64_t ntr, int b2p, double *__restrict__ out)
+{
+    __shared__ double sh[256];
+    const int j = blockIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t t = threadIdx.x;
+    for (; t + 768 < ntr; t += 1024) {
+        a0 += (double)part[t * b2p + j]; a1 += (double)part[(t + 256) * b2p + j]; a2 += (double)part[(t + 512) * b2p + j]; a3 += (double)part[(t + 768) * b2p + j];
+    }
+    for (; t < ntr; t += 256) a0 += (double)part[t * b2p + j];
+    sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = sh[0];
+}
+
 // Out[:, :b] = a X + b2 Y + c Z   (row-major blocks with their own leading dimensions)
 __global__ void hope_lincomb_kernel(int64_t n, int b, float a, const float *X, int ldx, float b2, const float *Y, int ldy, float c, const float *Z,
                                     int ldz, float *Out, int ldo)
@@ -317,6 +386,50 @@ __global__ __launch_bounds__(256) void hope_colmax_kernel(int64_t n, const float
         __syncthreads();
     }
     if (threadIdx.x == 0) val[j] = s_val[0];
+}
+
+// The same selection in two coalesced passes (the one-block-per-column kernel above reads a column with a stride of ld floats: every 4-byte load
+// costs a sector, 120 us at 100k x 96): pass 1 -- blockIdx.x = row chunk, blockIdx.y = group of 64 columns; a wavefront reads 64 consecutive columns
+// of one row (256 contiguous bytes), four rows in flight per block; (|v|, v, row) candidates per (chunk, column) -- pass 2 -- one thread block per
+// column folds the chunks.  Same rule: the largest magnitude, the FIRST such row on ties.
+__global__ __launch_bounds__(256) void hope_colmax1_kernel(int64_t n, const float *__restrict__ X, int ld, int mc, int64_t rows_per_chunk,
+                                                           float *__restrict__ pabs, float *__restrict__ pval, long long *__restrict__ pidx)
+{
+    __shared__ float s_abs[256], s_val[256];
+    __shared__ long long s_idx[256];
+    const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int j = blockIdx.y * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = r0 + rows_per_chunk < n ? r0 + rows_per_chunk : n;
+    float best = -1.f, bv = 0.f; long long bi = 0;
+    if (j < mc)
+        for (int64_t i = r0 + ph; i < r1; i += 4) {
+            const float v = X[i * ld + j], a = fabsf(v);
+            if (a > best) { best = a; bv = v; bi = i; }
+        }
+    s_abs[threadIdx.x] = best; s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    if (ph == 0 && j < mc) {
+        for (int q = 1; q < 4; ++q) {
+            const float a = s_abs[c + 64 * q];
+            const long long ii = s_idx[c + 64 * q];
+            if (a > best || (a == best && ii < bi)) { best = a; bv = s_val[c + 64 * q]; bi = ii; }
+        }
+        const int64_t o = (int64_t)blockIdx.x * mc + j;
+        pabs[o] = best; pval[o] = bv; pidx[o] = bi;
+    }
+}
+__global__ __launch_bounds__(64) void hope_colmax2_kernel(int nchunks, int mc, const float *__restrict__ pabs, const float *__restrict__ pval,
+                                                          const long long *__restrict__ pidx, float *__restrict__ val)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= mc) return;
+    float best = -1.f, bv = 0.f; long long bi = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {                       // chunks ascend in row order: a strict comparison keeps the first row on ties
+        const float a = pabs[(int64_t)ch * mc + j];
+        if (a > best) { best = a; bv = pval[(int64_t)ch * mc + j]; bi = pidx[(int64_t)ch * mc + j]; }
+    }
+    (void)bi;
+    val[j] = bv;
 }
 
 // ------------------------------------------------------------- host: symmetric eigensolver (fp64)
@@ -969,6 +1082,7 @@ struct Hope {
     float *va = nullptr, *vaT = nullptr;
     float *P = nullptr; size_t P_bytes = 0;          // Gram slab partials
     double *G = nullptr; size_t G_elems = 0;         // device fp64 Gram
+    double *G2 = nullptr; size_t G2_elems = 0;       // a second one (gram2: two Gram matrices, one host round trip)
     double *Gpart = nullptr; size_t Gpart_elems = 0; // reduction scratch
     float *Csmall = nullptr; size_t C_elems = 0;     // device small matrix for tsgemm
     hipStream_t s = nullptr;
@@ -982,7 +1096,7 @@ struct Hope {
     int err = 0;
     ~Hope()
     {
-        hipFree(rp); hipFree(rpT); hipFree(ci); hipFree(ciT); hipFree(va); hipFree(vaT); hipFree(P); hipFree(G); hipFree(Gpart); hipFree(Csmall);
+        hipFree(rp); hipFree(rpT); hipFree(ci); hipFree(ciT); hipFree(va); hipFree(vaT); hipFree(P); hipFree(G); hipFree(G2); hipFree(Gpart); hipFree(Csmall);
         for (hipEvent_t e : sp_pool) hipEventDestroy(e);
         for (CoefSlot &c : coef) { if (c.h) hipHostFree(c.h); hipFree(c.d); if (c.done) hipEventDestroy(c.done); }
         for (float *w : ws) hipFree(w);
@@ -1030,7 +1144,7 @@ void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const f
 
 // G (host, fp64, m1 x m2 row-major) = X[:, :m1]^T Y[:, :m2]
 // device part: H.G (fp64, m1 x m2 row-major) = X^T Y ; optionally the same values rounded to fp32 into Gf (device)
-static void gram_launch(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int m2, float *Gf)
+static void gram_launch(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int m2, float *Gf, bool second = false)
 {
     if (H.err || m1 == 0 || m2 == 0) return;
     const int t1 = (m1 + 31) / 32, t2 = (m2 + 31) / 32, m1p = t1 * 32, m2p = t2 * 32;
@@ -1042,7 +1156,8 @@ static void gram_launch(Hope &H, const float *X, int ldx, int m1, const float *Y
     const int nslabs = (int)((H.n + rows_per_slab - 1) / rows_per_slab);
     const size_t need = (size_t)nslabs * m1p * m2p * sizeof(float);
     if (need > H.P_bytes) { hipFree(H.P); H.P = nullptr; H.P_bytes = 0; HOPE_TRY(H, hipMalloc((void **)&H.P, need)); if (!H.err) H.P_bytes = need; }
-    if ((size_t)m1 * m2 > H.G_elems) { hipFree(H.G); H.G = nullptr; H.G_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.G, (size_t)m1 * m2 * sizeof(double))); if (!H.err) H.G_elems = (size_t)m1 * m2; }
+    double *&Gd = second ? H.G2 : H.G; size_t &Gd_elems = second ? H.G2_elems : H.G_elems;
+    if ((size_t)m1 * m2 > Gd_elems) { hipFree(Gd); Gd = nullptr; Gd_elems = 0; HOPE_TRY(H, hipMalloc((void **)&Gd, (size_t)m1 * m2 * sizeof(double))); if (!H.err) Gd_elems = (size_t)m1 * m2; }
     if (H.err) return;
     const int ntiles = t1 * t2;
     hipLaunchKernelGGL(hope_gram_kernel, dim3((ntiles + 3) / 4, nslabs), dim3(256), 0, H.s, H.n, X, ldx, m1, Y, ldy, m2, rows_per_slab, t2, ntiles,
@@ -1051,7 +1166,7 @@ static void gram_launch(Hope &H, const float *X, int ldx, int m1, const float *Y
     if ((size_t)Cr * m1 * m2 > H.Gpart_elems) { hipFree(H.Gpart); H.Gpart = nullptr; H.Gpart_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.Gpart, (size_t)Cr * m1 * m2 * sizeof(double))); if (!H.err) H.Gpart_elems = (size_t)Cr * m1 * m2; }
     if (H.err) return;
     hipLaunchKernelGGL(hope_reduce1_kernel, dim3((m1 * m2 + 255) / 256, Cr), dim3(256), 0, H.s, H.P, nslabs, (int64_t)m1p * m2p, m1, m2, m2p, Cr, H.Gpart);
-    hipLaunchKernelGGL(hope_reduce2_kernel, dim3((m1 * m2 + 255) / 256), dim3(256), 0, H.s, H.Gpart, Cr, m1 * m2, H.G, Gf);
+    hipLaunchKernelGGL(hope_reduce2_kernel, dim3((m1 * m2 + 255) / 256), dim3(256), 0, H.s, H.Gpart, Cr, m1 * m2, Gd, Gf);
 }
 
 void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int m2, std::vector<double> &Gh)
@@ -1061,6 +1176,21 @@ void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int
     gram_launch(H, X, ldx, m1, Y, ldy, m2, nullptr);
     if (H.err) return;
     HOPE_TRY(H, hipMemcpyAsync(Gh.data(), H.G, (size_t)m1 * m2 * sizeof(double), hipMemcpyDeviceToHost, H.s));
+    HOPE_TRY(H, hipStreamSynchronize(H.s));
+}
+
+// Two Gram matrices, ONE host round trip: Ga = Xa^T Ya, Gb = Xb^T Yb (the slab partials and the reduction scratch are reused in stream order; only
+// the fp64 results need a buffer each)
+void gram2(Hope &H, const float *Xa, int ldxa, int ma1, const float *Ya, int ldya, int ma2, std::vector<double> &Ga,
+           const float *Xb, int ldxb, int mb1, const float *Yb, int ldyb, int mb2, std::vector<double> &Gb)
+{
+    Ga.assign((size_t)ma1 * ma2, 0.0); Gb.assign((size_t)mb1 * mb2, 0.0);
+    if (H.err || ma1 == 0 || ma2 == 0 || mb1 == 0 || mb2 == 0) return;
+    gram_launch(H, Xa, ldxa, ma1, Ya, ldya, ma2, nullptr, false);
+    gram_launch(H, Xb, ldxb, mb1, Yb, ldyb, mb2, nullptr, true);
+    if (H.err) return;
+    HOPE_TRY(H, hipMemcpyAsync(Ga.data(), H.G, Ga.size() * sizeof(double), hipMemcpyDeviceToHost, H.s));
+    HOPE_TRY(H, hipMemcpyAsync(Gb.data(), H.G2, Gb.size() * sizeof(double), hipMemcpyDeviceToHost, H.s));
     HOPE_TRY(H, hipStreamSynchronize(H.s));
 }
 
@@ -1089,6 +1219,61 @@ void tsgemm(Hope &H, const float *X, int ldx, int m, const std::vector<double> &
     hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, slot.d, b2, b2, alpha, Src, lds_, Out,
                        ldo, ct);
     HOPE_TRY(H, hipEventRecord(slot.done, H.s));
+}
+
+// Out[:, :b2] = V[:, :m] C  and  res2[j] = || B[:, :m] C[:, j] - theta[j] Out[:, j] ||^2   (C host fp64 m x b2 row-major; one pass over V and B, one
+// host round trip for the b2 norms).  The Rayleigh-Ritz step's rotation and residuals: hope_ritz_kernel + hope_colsum_kernel.
+void ritz_rotate(Hope &H, const float *V, int ldv, const float *B, int ldb, int m, const std::vector<double> &Ch, const std::vector<double> &theta, int b2,
+                 float *Out, int ldo, std::vector<double> &res2)
+{
+    res2.assign(b2, 0.0);
+    if (H.err || b2 == 0 || m == 0) return;
+    Hope::CoefSlot &slot = H.coef[H.coef_next++ % 8];
+    const size_t need = (size_t)m * b2 + b2;
+    if (slot.done) HOPE_TRY(H, hipEventSynchronize(slot.done));
+    else HOPE_TRY(H, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (need > slot.elems && !H.err) {
+        if (slot.h) hipHostFree(slot.h);
+        hipFree(slot.d); slot.h = nullptr; slot.d = nullptr; slot.elems = 0;
+        const size_t cap = std::max<size_t>(need, 16384);
+        HOPE_TRY(H, hipHostMalloc((void **)&slot.h, cap * sizeof(float), hipHostMallocDefault));
+        HOPE_TRY(H, hipMalloc((void **)&slot.d, cap * sizeof(float)));
+        if (!H.err) slot.elems = cap;
+    }
+    const int ct = (b2 + 31) / 32, b2p = ct * 32;
+    const int64_t ntr = (H.n + 31) / 32;
+    const size_t pneed = (size_t)ntr * b2p * sizeof(float);
+    if (pneed > H.P_bytes && !H.err) { HOPE_TRY(H, hipStreamSynchronize(H.s)); hipFree(H.P); H.P = nullptr; H.P_bytes = 0; HOPE_TRY(H, hipMalloc((void **)&H.P, pneed)); if (!H.err) H.P_bytes = pneed; }
+    if ((size_t)b2 > H.G_elems && !H.err) { HOPE_TRY(H, hipStreamSynchronize(H.s)); hipFree(H.G); H.G = nullptr; H.G_elems = 0; HOPE_TRY(H, hipMalloc((void **)&H.G, (size_t)b2 * sizeof(double))); if (!H.err) H.G_elems = (size_t)b2; }
+    if (H.err) return;
+    for (size_t i = 0; i < (size_t)m * b2; ++i) slot.h[i] = (float)Ch[i];
+    for (int j = 0; j < b2; ++j) slot.h[(size_t)m * b2 + j] = (float)theta[j];
+    HOPE_TRY(H, hipMemcpyAsync(slot.d, slot.h, need * sizeof(float), hipMemcpyHostToDevice, H.s));
+    const int64_t tiles = ntr * ct;
+    hipLaunchKernelGGL(hope_ritz_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, V, ldv, B, ldb, m, slot.d, b2, b2, slot.d + (size_t)m * b2, Out, ldo,
+                       H.P, b2p, ct);
+    HOPE_TRY(H, hipEventRecord(slot.done, H.s));
+    hipLaunchKernelGGL(hope_colsum_kernel, dim3(b2), dim3(256), 0, H.s, H.P, ntr, b2p, H.G);
+    HOPE_TRY(H, hipMemcpyAsync(res2.data(), H.G, (size_t)b2 * sizeof(double), hipMemcpyDeviceToHost, H.s));
+    HOPE_TRY(H, hipStreamSynchronize(H.s));
+}
+
+// val[j] = the entry of column j of X (n x mc, ld) with the largest magnitude, the first such row on ties (hope_colmax1/2_kernel; scratch: H.P)
+void colmax(Hope &H, const float *X, int ld, int mc, float *val)
+{
+    if (H.err || mc <= 0) return;
+    static const int two_pass = getenv("GEMHIP_HOPE_COLMAX2") ? atoi(getenv("GEMHIP_HOPE_COLMAX2")) : 1;
+    if (!two_pass) { hipLaunchKernelGGL(hope_colmax_kernel, dim3(mc), dim3(256), 0, H.s, H.n, X, ld, val); return; }
+    const int nchunks = (int)std::min<int64_t>(512, (H.n + 63) / 64);
+    const int64_t rows_per_chunk = (H.n + nchunks - 1) / nchunks;
+    const size_t per = (size_t)nchunks * mc;
+    const size_t need = per * (sizeof(float) * 2 + sizeof(long long)) + 64;
+    if (need > H.P_bytes) { HOPE_TRY(H, hipStreamSynchronize(H.s)); hipFree(H.P); H.P = nullptr; H.P_bytes = 0; HOPE_TRY(H, hipMalloc((void **)&H.P, need)); if (!H.err) H.P_bytes = need; }
+    if (H.err) return;
+    long long *pidx = reinterpret_cast<long long *>(H.P);                    // (8-byte aligned part first)
+    float *pabs = reinterpret_cast<float *>(pidx + per), *pval = pabs + per;
+    hipLaunchKernelGGL(hope_colmax1_kernel, dim3(nchunks, (mc + 63) / 64), dim3(256), 0, H.s, H.n, X, ld, mc, rows_per_chunk, pabs, pval, pidx);
+    hipLaunchKernelGGL(hope_colmax2_kernel, dim3((mc + 63) / 64), dim3(64), 0, H.s, nchunks, mc, pabs, pval, pidx, val);
 }
 
 // W[:, :cols] -= V[:, :m] (V[:, :m]^T W[:, :cols]) with the coefficients kept in HBM: Gram, fp64 slab reduction, fp32 rounding and
@@ -1436,7 +1621,7 @@ static int krylov_svd(Hope &H, int64_t n, int32_t k, int32_t oversample, int32_t
         if (!H.err) tsgemm(H, U_sqrtS ? Ball : Vall, ldm, mc, Cref, k, 1.0f, nullptr, 0, Tmp, k);           // compact [n][k]
         std::vector<float> cm(k, 0.f);
         if (!H.err) {
-            hipLaunchKernelGGL(hope_colmax_kernel, dim3(k), dim3(256), 0, H.s, n, Tmp, k, d_cm);
+            colmax(H, Tmp, k, k, d_cm);
             HOPE_TRY(H, hipMemcpyAsync(cm.data(), d_cm, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, H.s));
             HOPE_TRY(H, hipStreamSynchronize(H.s));
         }
@@ -1578,6 +1763,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
     double amp = 1e4, amp0 = 1e3;
     if (const char *e = getenv("GEMHIP_HOPE_SYM_AMP")) amp = std::max(10.0, atof(e));
     if (const char *e = getenv("GEMHIP_HOPE_SYM_AMP0")) amp0 = std::max(10.0, atof(e));
+    const bool fused_rr = !(getenv("GEMHIP_HOPE_SYM_FUSED_RR") && atoi(getenv("GEMHIP_HOPE_SYM_FUSED_RR")) == 0);
     int max_degree = 32;                                    // measured at SBM 100k/1M: 30-32 per cycle is cheapest (scripts/ab_hope_sym.py)
     if (const char *e = getenv("GEMHIP_HOPE_SYM_MAXDEG")) max_degree = std::max(2, atoi(e));
     float *Vall = nullptr, *Bm = nullptr, *F[3] = {nullptr, nullptr, nullptr}, *Tmp = nullptr, *colv = nullptr;
@@ -1640,9 +1826,58 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         float *Va = Vall + nl;
         cheb_filter(H, kind, Va, ldv, ma, m, c, e, F, ldv, Bm, Vall, ldv, nl, q);
         degree_total += m;
-        // CholeskyQR2; with locked vectors the projection is repeated between the two passes (the first pass rescales the block)
+        // CholeskyQR2 + Rayleigh-Ritz on A over the active block.  With locked vectors the projection is repeated between the two passes (the first pass
+        // rescales the block).  FUSED (default; GEMHIP_HOPE_SYM_FUSED_RR=0 for the A/B): the second CholeskyQR pass is not applied to the block -- after the
+        // first pass Y1 is orthonormal to ~1e-3, so G2 = Y1^T Y1 and H1 = Y1^T (A Y1) are taken in ONE host round trip (gram2), C2 = chol(G2)^-1 and
+        // the projected matrix (Y1 C2)^T A (Y1 C2) = C2^T H1 C2 are formed on the host in fp64, and the Ritz rotation below takes Y1 straight to the Ritz
+        // vectors with the coefficients C2 W: one synchronisation, one Gram, one tall-skinny GEMM and one block copy less per cycle, and Q = Y1 C2 is
+        // never rounded to fp32.  A Cholesky that loses a pivot (rank loss) falls back to the two-pass sequence.
         int keep;
-        if (nl) {
+        std::vector<double> Hh, ev, C2;                           // C2: empty = identity
+        bool rr_have = false;
+        if (fused_rr) {
+            if (nl) project_out(H, Vall, ldv, nl, Va, ldv, ma);
+            keep = orth_scaled(H, Va, ldv, ma, Tmp, ldv, 1);
+            if (keep > 0 && nl) project_out(H, Vall, ldv, nl, Va, ldv, keep);
+            if (H.err) break;
+            if (nl + keep < k + 1 || keep < 2) { if (debug) fprintf(stderr, "[hope-sym] block collapsed to %d columns\n", keep); break; }
+            { SpmmTimer timer(H); apply_sym_op(H, kind, 1.0f, Va, ldv, keep, F[0], ldv, Bm, ldv, 1.0f, nullptr, 0, 0.f, nullptr, 0); }
+            std::vector<double> G2;
+            gram2(H, Va, ldv, keep, Va, ldv, keep, G2, Va, ldv, keep, Bm, ldv, keep, Hh);
+            if (H.err) break;
+            std::vector<double> dinv(keep, 0.0);
+            for (int i = 0; i < keep; ++i) { const double g = G2[(size_t)i * keep + i]; dinv[i] = (g > 0.0 && std::isfinite(g)) ? 1.0 / std::sqrt(g) : 0.0; }
+            for (int i = 0; i < keep; ++i)
+                for (int j = 0; j < keep; ++j) G2[(size_t)i * keep + j] *= dinv[i] * dinv[j];
+            bool ok = true;
+            for (int i = 0; i < keep; ++i) if (dinv[i] == 0.0) ok = false;
+            if (ok && chol_inverse(keep, G2, 1e-5, C2)) {
+                for (int i = 0; i < keep; ++i)
+                    for (int j = 0; j < keep; ++j) C2[(size_t)i * keep + j] *= dinv[i];
+                // Hq = C2^T sym(H1) C2 (C2 upper triangular)
+                for (int i = 0; i < keep; ++i)
+                    for (int j = i + 1; j < keep; ++j) { const double v = 0.5 * (Hh[(size_t)i * keep + j] + Hh[(size_t)j * keep + i]); Hh[(size_t)i * keep + j] = Hh[(size_t)j * keep + i] = v; }
+                std::vector<double> T((size_t)keep * keep, 0.0), Hq((size_t)keep * keep, 0.0);
+                for (int i = 0; i < keep; ++i)                      // T = H1 C2
+                    for (int l = 0; l < keep; ++l) {
+                        const double h = Hh[(size_t)i * keep + l];
+                        if (h == 0.0) continue;
+                        for (int j = l; j < keep; ++j) T[(size_t)i * keep + j] += h * C2[(size_t)l * keep + j];
+                    }
+                for (int l = 0; l < keep; ++l)                      // Hq = C2^T T
+                    for (int i = l; i < keep; ++i) {
+                        const double c = C2[(size_t)l * keep + i];
+                        if (c == 0.0) continue;
+                        for (int j = 0; j < keep; ++j) Hq[(size_t)i * keep + j] += c * T[(size_t)l * keep + j];
+                    }
+                Hh.swap(Hq);
+                rr_have = true;
+            } else {
+                C2.clear();
+                keep = orth_scaled(H, Va, ldv, keep, Tmp, ldv, 1);      // (rank loss: the rank-revealing second pass, then the plain Rayleigh-Ritz step)
+                if (H.err) break;
+            }
+        } else if (nl) {
             project_out(H, Vall, ldv, nl, Va, ldv, ma);
             keep = orth_scaled(H, Va, ldv, ma, Tmp, ldv, 1);
             if (keep > 0) { project_out(H, Vall, ldv, nl, Va, ldv, keep); keep = orth_scaled(H, Va, ldv, keep, Tmp, ldv, 1); }
@@ -1650,11 +1885,11 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         if (H.err) break;
         if (nl + keep < k + 1 || keep < 2) { if (debug) fprintf(stderr, "[hope-sym] block collapsed to %d columns\n", keep); break; }
         ma = keep;
-        // Rayleigh-Ritz on A over the active block
-        std::vector<double> Hh, ev;
-        { SpmmTimer timer(H); apply_sym_op(H, kind, 1.0f, Va, ldv, ma, F[0], ldv, Bm, ldv, 1.0f, nullptr, 0, 0.f, nullptr, 0); }
-        gram(H, Va, ldv, ma, Bm, ldv, ma, Hh);
-        if (H.err) break;
+        if (!rr_have) {
+            { SpmmTimer timer(H); apply_sym_op(H, kind, 1.0f, Va, ldv, ma, F[0], ldv, Bm, ldv, 1.0f, nullptr, 0, 0.f, nullptr, 0); }
+            gram(H, Va, ldv, ma, Bm, ldv, ma, Hh);
+            if (H.err) break;
+        }
         for (int i = 0; i < ma; ++i)
             for (int j = i + 1; j < ma; ++j) { const double v = 0.5 * (Hh[(size_t)i * ma + j] + Hh[(size_t)j * ma + i]); Hh[(size_t)i * ma + j] = Hh[(size_t)j * ma + i] = v; }
         sym_eig(ma, Hh, ev);                                                          // ascending; column j of Hh = eigenvector j
@@ -1665,18 +1900,39 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         std::vector<double> C((size_t)ma * ma), Ct((size_t)ma * ma);
         for (int j = 0; j < ma; ++j) {
             th[j] = ev[order[j]];
-            for (int i = 0; i < ma; ++i) { C[(size_t)i * ma + j] = Hh[(size_t)i * ma + order[j]]; Ct[(size_t)i * ma + j] = -th[j] * C[(size_t)i * ma + j]; }
+            for (int i = 0; i < ma; ++i) C[(size_t)i * ma + j] = Hh[(size_t)i * ma + order[j]];
         }
-        // residuals R = B C - V C diag(theta) (into F[0]), then the block becomes its Ritz vectors V C
-        tsgemm(H, Va, ldv, ma, Ct, ma, 1.0f, nullptr, 0, F[0], ldv);
-        tsgemm(H, Bm, ldv, ma, C, ma, 1.0f, F[0], ldv, F[0], ldv);
-        tsgemm(H, Va, ldv, ma, C, ma, 1.0f, nullptr, 0, Tmp, ldv);
-        HOPE_TRY(H, hipMemcpy2DAsync(Va, (size_t)ldv * sizeof(float), Tmp, (size_t)ldv * sizeof(float), (size_t)ma * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
-        std::vector<double> RR;
-        gram(H, F[0], ldv, ma, F[0], ldv, ma, RR);
-        if (H.err) break;
+        if (!C2.empty()) {                                                            // the block is Y1, not Q = Y1 C2: its coefficients are C2 W
+            std::vector<double> M((size_t)ma * ma, 0.0);
+            for (int i = 0; i < ma; ++i)
+                for (int l = i; l < ma; ++l) {
+                    const double c = C2[(size_t)i * ma + l];
+                    if (c == 0.0) continue;
+                    for (int j = 0; j < ma; ++j) M[(size_t)i * ma + j] += c * C[(size_t)l * ma + j];
+                }
+            C.swap(M);
+        }
+        for (int j = 0; j < ma; ++j)
+            for (int i = 0; i < ma; ++i) Ct[(size_t)i * ma + j] = -th[j] * C[(size_t)i * ma + j];
+        // residuals R = B C - V C diag(theta), then the block becomes its Ritz vectors V C.  FUSED (default with the fused Rayleigh-Ritz step): one
+        // pass computes V C and the column norms of R without storing R (ritz_rotate); otherwise three tall-skinny GEMMs and the Gram matrix of R
         res.assign(ma, 0.0);
-        for (int j = 0; j < ma; ++j) res[j] = std::sqrt(std::max(RR[(size_t)j * ma + j], 0.0));
+        if (fused_rr) {
+            std::vector<double> r2;
+            ritz_rotate(H, Va, ldv, Bm, ldv, ma, C, th, ma, Tmp, ldv, r2);
+            HOPE_TRY(H, hipMemcpy2DAsync(Va, (size_t)ldv * sizeof(float), Tmp, (size_t)ldv * sizeof(float), (size_t)ma * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
+            if (H.err) break;
+            for (int j = 0; j < ma; ++j) res[j] = std::sqrt(std::max(r2[j], 0.0));
+        } else {
+            tsgemm(H, Va, ldv, ma, Ct, ma, 1.0f, nullptr, 0, F[0], ldv);
+            tsgemm(H, Bm, ldv, ma, C, ma, 1.0f, F[0], ldv, F[0], ldv);
+            tsgemm(H, Va, ldv, ma, C, ma, 1.0f, nullptr, 0, Tmp, ldv);
+            HOPE_TRY(H, hipMemcpy2DAsync(Va, (size_t)ldv * sizeof(float), Tmp, (size_t)ldv * sizeof(float), (size_t)ma * sizeof(float), n, hipMemcpyDeviceToDevice, H.s));
+            std::vector<double> RR;
+            gram(H, F[0], ldv, ma, F[0], ldv, ma, RR);
+            if (H.err) break;
+            for (int j = 0; j < ma; ++j) res[j] = std::sqrt(std::max(RR[(size_t)j * ma + j], 0.0));
+        }
         // wanted values so far: the k largest |f| over the locked eigenvalues and the active Ritz values
         {
             std::vector<double> all;
@@ -1729,7 +1985,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.s > y.s; });
         const int mc = nl + ma;
         // sign convention (largest-magnitude entry of each left vector positive) from the basis columns themselves
-        hipLaunchKernelGGL(hope_colmax_kernel, dim3(mc), dim3(256), 0, H.s, n, Vall, ldv, colv);
+        colmax(H, Vall, ldv, mc, colv);
         std::vector<float> cm(mc, 0.f);
         HOPE_TRY(H, hipMemcpyAsync(cm.data(), colv, (size_t)mc * sizeof(float), hipMemcpyDeviceToHost, H.s));
         HOPE_TRY(H, hipStreamSynchronize(H.s));

@@ -122,6 +122,8 @@ struct gemhip_n2v {
     int64_t m_start = 0;
     int32_t *d_start = nullptr;
     float *d_w = nullptr;
+    std::vector<int32_t> hub_rows;    // rows with at least ALIAS_HUB_DEG neighbours (n2v_alias_hub_kernel builds their tables: a workgroup per row)
+    std::vector<int64_t> hub_off;     // ... and the offset of each one's scratch segment (prefix sum of their degrees)
     float *d_U = nullptr;             // first-order alias tables (per-row segments)
     int32_t *d_K = nullptr;
     // walks
@@ -136,6 +138,10 @@ struct gemhip_n2v {
     int32_t *d_KT = nullptr;
     uint2 *d_UK = nullptr;             // {bits of UT[i], KT[i]} interleaved: one 8-byte gather instead of two 4-byte gathers
     bool unigram_ready = false;
+    // slot tables of the window kernels (SgnsArgs::SK): {X, UT[X], KT[X]} by SLOT, built on the device from the tables above on the first launch
+    // after a table build, once per RndUnigramInt-quirk setting (sk_state / skp_state: -1 stale, else the quirk bit they were built for)
+    uint4 *d_SK = nullptr; int64_t sk_cap = 0; int sk_state = -1;
+    uint4 *d_SKp = nullptr; int skp_state = -1;
     // vocabulary-order layout (gemhip_n2v_build_unigram_vocab_order): the slot table of RndUnigramInt, and how many slots it has
     int32_t *d_KTslot = nullptr; int64_t n_vocab = 0; bool vocab_order = false;
     unsigned long long *d_first = nullptr;   // first token index of every node (scratch of that builder)
@@ -160,6 +166,7 @@ struct gemhip_n2v {
 namespace {
 
 // ------------------------------------------------------------------ alias tables
+constexpr int ALIAS_HUB_DEG = 2048;      // rows from this many neighbours on take n2v_alias_hub_kernel (oracle: ORACLE_ALIAS_HUB_DEG)
 // GetNodeAlias (ELF @0x4115f0): one thread per CSR row, sequential Vose in fp32.  The two
 // stacks share the row's segment of `work` (small grows up from 0, large down from N-1).
 __global__ void n2v_alias_rows_kernel(int64_t n, const int64_t *__restrict__ row_ptr, const float *__restrict__ w,
@@ -169,7 +176,7 @@ __global__ void n2v_alias_rows_kernel(int64_t n, const int64_t *__restrict__ row
     if (v >= n) return;
     const int64_t a = row_ptr[v];
     const int32_t N = (int32_t)(row_ptr[v + 1] - a);
-    if (N == 0) return;
+    if (N == 0 || N >= ALIAS_HUB_DEG) return;                  // (hub rows: n2v_alias_hub_kernel)
     const float *wt = w + a; float *Ur = U + a; int32_t *Kr = K + a; int32_t *work = work_all + a;
     float sum = 0.0f;
     for (int32_t i = 0; i < N; ++i) sum += wt[i];
@@ -190,6 +197,94 @@ __global__ void n2v_alias_rows_kernel(int64_t n, const int64_t *__restrict__ row
     }
     while (ns > 0) Ur[work[--ns]] = 1.0f;
     while (nl > 0) { Ur[work[N - nl]] = 1.0f; --nl; }
+}
+
+// GetNodeAlias for HUB rows (N >= ALIAS_HUB_DEG): one workgroup per row, no N-step chain.  The stacks of GetNodeAlias are filled in index order and
+// popped from the back, so smalls and larges are met in descending index order and the loop's outcome is closed form in two prefix sums -- D_j, the
+// deficits of the first j smalls, and E_m, the excesses of the first m larges (both in stack order):
+//   small s_j -> K = L_m, m = min{m : E_m >= D_{j-1}};   large L_m turns small at the first j with D_j > E_m: U = 1 + E_m - D_j, K = L_{m+1}
+// (derivation and the proof by test against the sequential loop: oracle/n2v_oracle.c oracle_alias_build_hub, tests/test_oracle_n2v.py).  fp64, with
+// the order of every sum FIXED exactly as the oracle fixes it -- chunks of 256 entries in stack order, sequential inside a chunk (one thread per
+// chunk), chunk totals accumulated sequentially (thread 0), entry = chunk base + running sum -- so the table is the oracle's bit for bit whatever the
+// block size.  scr: per row 2 N int32 (S, L) then 2 N double (D, E) then per-chunk {double d, e; int32 s, l}; a 94 115-neighbour R-MAT hub takes
+// ~0.1 ms instead of a 94k-step dependent chain on one lane.
+constexpr int ALIAS_CHUNK = 256;
+__global__ __launch_bounds__(256) void n2v_alias_hub_kernel(const int32_t *__restrict__ hubs, const int64_t *__restrict__ hub_off, const int64_t *__restrict__ row_ptr,
+                                                            const float *__restrict__ w, float *__restrict__ U, int32_t *__restrict__ K, unsigned char *__restrict__ scr_all)
+{
+#pragma clang fp contract(off)          // the oracle is built with -ffp-contract=off: `1.0 - (w / total) * N` must round the product first, here too
+    const int32_t v = hubs[blockIdx.x];
+    const int64_t a = row_ptr[v];
+    const int32_t N = (int32_t)(row_ptr[v + 1] - a);
+    const int32_t nch = (N + ALIAS_CHUNK - 1) / ALIAS_CHUNK;
+    const float *wt = w + a; float *Ur = U + a; int32_t *Kr = K + a;
+    // scratch segment of this row: hub_off counts entries; every entry owns 24 bytes, every chunk 24 more (chunks of row b start after all entries)
+    unsigned char *scr = scr_all + (size_t)hub_off[blockIdx.x] * 24 + (size_t)(hub_off[blockIdx.x] / ALIAS_CHUNK + blockIdx.x) * 24;
+    double *D = reinterpret_cast<double *>(scr), *E = D + N;
+    int32_t *S = reinterpret_cast<int32_t *>(E + N), *L = S + N;
+    double *cd = reinterpret_cast<double *>(scr + (size_t)N * 24), *ce = cd + nch;
+    int32_t *cs = reinterpret_cast<int32_t *>(ce + nch), *cl = cs + nch;
+    __shared__ double sh_total;
+    __shared__ int32_t sh_ns, sh_nl;
+    // total weight: chunk sums in INDEX order (into cd), accumulated sequentially
+    for (int32_t c = threadIdx.x; c < nch; c += blockDim.x) {
+        double t = 0.0;
+        const int32_t i1 = (c + 1) * ALIAS_CHUNK < N ? (c + 1) * ALIAS_CHUNK : N;
+        for (int32_t i = c * ALIAS_CHUNK; i < i1; ++i) t += (double)wt[i];
+        cd[c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int32_t c = 0; c < nch; ++c) t += cd[c]; sh_total = t; }
+    __syncthreads();
+    const double total = sh_total, dN = (double)N;
+    // per chunk of the STACK order (r = 0 is the top of both stacks, i = N - 1 - r): deficit / excess sums and counts
+    for (int32_t c = threadIdx.x; c < nch; c += blockDim.x) {
+        double ds = 0.0, es = 0.0; int32_t ns = 0, nl = 0;
+        const int32_t r1 = (c + 1) * ALIAS_CHUNK < N ? (c + 1) * ALIAS_CHUNK : N;
+        for (int32_t r = c * ALIAS_CHUNK; r < r1; ++r) {
+            const double u = ((double)wt[N - 1 - r] / total) * dN;
+            if (u < 1.0) { ds += 1.0 - u; ++ns; } else { es += u - 1.0; ++nl; }
+        }
+        cd[c] = ds; ce[c] = es; cs[c] = ns; cl[c] = nl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                  // exclusive prefix over the chunks, sequential
+        double bd = 0.0, be = 0.0; int32_t bs = 0, bl = 0;
+        for (int32_t c = 0; c < nch; ++c) {
+            const double ds = cd[c], es = ce[c]; const int32_t ns = cs[c], nl = cl[c];
+            cd[c] = bd; ce[c] = be; cs[c] = bs; cl[c] = bl;
+            bd += ds; be += es; bs += ns; bl += nl;
+        }
+        sh_ns = bs; sh_nl = bl;
+    }
+    __syncthreads();
+    for (int32_t c = threadIdx.x; c < nch; c += blockDim.x) {
+        double ds = 0.0, es = 0.0; int32_t ns = cs[c], nl = cl[c];
+        const double bd = cd[c], be = ce[c];
+        const int32_t r1 = (c + 1) * ALIAS_CHUNK < N ? (c + 1) * ALIAS_CHUNK : N;
+        for (int32_t r = c * ALIAS_CHUNK; r < r1; ++r) {
+            const int32_t i = N - 1 - r;
+            const double u = ((double)wt[i] / total) * dN;
+            Kr[i] = 0;
+            if (u < 1.0) { ds += 1.0 - u; S[ns] = i; D[ns] = bd + ds; ++ns; Ur[i] = (float)u; }
+            else { es += u - 1.0; L[nl] = i; E[nl] = be + es; ++nl; Ur[i] = 1.0f; }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int32_t NS = sh_ns, NL = sh_nl;
+    for (int32_t j = threadIdx.x; j < NS; j += blockDim.x) {  // smalls: first m with E[m] >= D[j-1]
+        const double dp = j ? D[j - 1] : 0.0;
+        int32_t lo = 0, hi = NL;
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (E[mid] >= dp) hi = mid; else lo = mid + 1; }
+        if (lo < NL) Kr[S[j]] = L[lo]; else Ur[S[j]] = 1.0f;
+    }
+    for (int32_t m = threadIdx.x; m < NL; m += blockDim.x) {  // larges: first j with D[j] > E[m]
+        const double em = E[m];
+        int32_t lo = 0, hi = NS;
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (D[mid] > em) hi = mid; else lo = mid + 1; }
+        if (lo < NS && m + 1 < NL) { Ur[L[m]] = (float)(1.0 + em - D[lo]); Kr[L[m]] = L[m + 1]; }
+    }
 }
 
 // ------------------------------------------------------------------------- walks
@@ -296,6 +391,17 @@ __global__ void iota_kernel(int32_t *p, int64_t n)
     if (i < n) p[i] = (int32_t)i;
 }
 
+// SgnsArgs::SK.  RndUnigramInt draws slot = floor(u n), X = KT[slot] (quirk) or slot, then reads {UTable[X], KTable[X]}: the second gather depends on
+// the first.  SK[slot] = {X, bits of UTable[X], KTable[X], 0} answers both with one 16-byte read (same values: the draws are unchanged bit for bit).
+__global__ void n2v_slot_table_kernel(int64_t nslots, const int32_t *__restrict__ KT, const uint2 *__restrict__ UK, int quirk, uint4 *__restrict__ SK)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    const int32_t X = quirk ? KT[s] : (int32_t)s;
+    const uint2 uk = UK[X];
+    SK[s] = make_uint4((uint32_t)X, uk.x, uk.y, 0u);
+}
+
 __global__ void sgns_init_kernel(float *SynPos, float *SynNeg, int64_t total, int32_t d, uint64_t seed)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,6 +468,11 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     }
     auto *h = new gemhip_n2v();
     h->n = n; h->nnz = nnz; h->uniform_rows = uniform; h->m_start = (int64_t)start.size();
+    if (!uniform) {
+        h->hub_off.push_back(0);
+        for (int64_t v = 0; v < n; ++v)
+            if (row_ptr[v + 1] - row_ptr[v] >= ALIAS_HUB_DEG) { h->hub_rows.push_back((int32_t)v); h->hub_off.push_back(h->hub_off.back() + (row_ptr[v + 1] - row_ptr[v])); }
+    }
     // A/B knobs: read ONCE, here (the launch path reads no environment); the setters below override them per handle
     if (const char *e = getenv("GEMHIP_SGNS_MAX_WAVES")) h->kn.max_waves = std::max(0, atoi(e));
     if (const char *e = getenv("GEMHIP_SGNS_CACHE_R")) h->kn.cache_radius = std::min(31, std::max(-1, atoi(e)));
@@ -396,7 +507,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
     hipFree(h->d_start);
     hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_scratch);
     if (h->own_counts) hipFree(h->d_counts);
-    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_KTslot); hipFree(h->d_first); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp);
+    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_SK); hipFree(h->d_SKp); hipFree(h->d_KTslot); hipFree(h->d_first); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
     delete h;
     return GEMHIP_OK;
@@ -413,8 +524,22 @@ extern "C" int gemhip_n2v_build_alias(gemhip_n2v_t h, void *stream)
     hipLaunchKernelGGL(n2v_alias_rows_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->n,
                        h->d_row_ptr, h->d_w, h->d_U, h->d_K, work);
     GEMHIP_CHECK(hipGetLastError());
+    int32_t *d_hubs = nullptr; int64_t *d_hoff = nullptr; unsigned char *d_scr = nullptr;
+    if (!h->hub_rows.empty()) {                        // hub rows: a workgroup each (the one-lane kernel skipped them)
+        const size_t nh = h->hub_rows.size();
+        const size_t entries = (size_t)h->hub_off.back();
+        const size_t scr_bytes = entries * 24 + (entries / ALIAS_CHUNK + nh + 1) * 24;
+        GEMHIP_CHECK(hipMalloc((void **)&d_hubs, nh * sizeof(int32_t)));
+        GEMHIP_CHECK(hipMalloc((void **)&d_hoff, (nh + 1) * sizeof(int64_t)));
+        GEMHIP_CHECK(hipMalloc((void **)&d_scr, scr_bytes));
+        GEMHIP_CHECK(hipMemcpyAsync(d_hubs, h->hub_rows.data(), nh * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+        GEMHIP_CHECK(hipMemcpyAsync(d_hoff, h->hub_off.data(), (nh + 1) * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+        hipLaunchKernelGGL(n2v_alias_hub_kernel, dim3((unsigned)nh), dim3(256), 0, (hipStream_t)stream, d_hubs, d_hoff, h->d_row_ptr, h->d_w, h->d_U, h->d_K, d_scr);
+        GEMHIP_CHECK(hipGetLastError());
+    }
     GEMHIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     GEMHIP_CHECK(hipFree(work));
+    hipFree(d_hubs); hipFree(d_hoff); hipFree(d_scr);
     return GEMHIP_OK;
 }
 
@@ -600,7 +725,7 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
         if (!h->d_UK) GEMHIP_CHECK(hipMalloc((void **)&h->d_UK, n * sizeof(uint2)));
         GEMHIP_CHECK(hipMemcpy(h->d_UK, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
     }
-    h->unigram_ready = true; h->vocab_order = false;
+    h->unigram_ready = true; h->vocab_order = false; h->sk_state = -1;
     if (counts_out) std::copy(cnt.begin(), cnt.end(), counts_out);
     if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
     if (KT_out) std::copy(K.begin(), K.end(), KT_out);
@@ -664,7 +789,7 @@ extern "C" int gemhip_n2v_build_unigram_vocab_order(gemhip_n2v_t h, int32_t flag
     { PhaseScope ph(PH_H2D);
       GEMHIP_CHECK(hipMemcpy(h->d_KTslot, slot.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
       GEMHIP_CHECK(hipMemcpy(h->d_UK, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice)); }
-    h->n_vocab = N; h->vocab_order = true; h->unigram_ready = true;
+    h->n_vocab = N; h->vocab_order = true; h->unigram_ready = true; h->sk_state = -1;
     if (n_vocab_out) *n_vocab_out = N;
     if (order_out) std::copy(back.begin(), back.end(), order_out);
     if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
@@ -708,7 +833,8 @@ extern "C" int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, flo
         for (int64_t i = 0; i < n; ++i) { uint32_t ub; memcpy(&ub, &Uall[i], 4); UK[i] = make_uint2(ub, (uint32_t)Kall[i]); }
         GEMHIP_CHECK(hipMemcpy(h->d_UKp, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
     }
-    h->parts = parts;
+    h->parts = parts; h->skp_state = -1;
+    hipFree(h->d_SKp); h->d_SKp = nullptr;
     if (UT_out) std::copy(Uall.begin(), Uall.end(), UT_out);
     if (KT_out) std::copy(Kall.begin(), Kall.end(), KT_out);
     return GEMHIP_OK;
@@ -865,6 +991,36 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
     return P;
 }
 
+// The slot table the window kernels draw negatives from (SgnsArgs::SK), for the table currently held and the given quirk bit.  Built on `stream`,
+// in front of the launch that needs it; rebuilt only after a table build or when the quirk bit changes.
+static int ensure_slot_table(gemhip_n2v_t h, const int32_t *KT, int64_t nslots, int quirk, hipStream_t stream)
+{
+    if (h->sk_state == quirk && h->d_SK) return GEMHIP_OK;
+    if (nslots > h->sk_cap) {
+        if (h->d_SK) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_SK); h->d_SK = nullptr; h->sk_cap = 0; }
+        GEMHIP_CHECK(hipMalloc((void **)&h->d_SK, (size_t)nslots * sizeof(uint4)));
+        h->sk_cap = nslots;
+    }
+    hipLaunchKernelGGL(n2v_slot_table_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, stream, nslots, KT, h->d_UK, quirk, h->d_SK);
+    GEMHIP_CHECK(hipGetLastError());
+    h->sk_state = quirk;
+    return GEMHIP_OK;
+}
+// ... and of the per-partition tables: partition p's slots occupy [part_off[p], part_off[p+1]) of d_SKp, entries in LOCAL indices like d_KTp / d_UKp
+static int ensure_slot_table_parts(gemhip_n2v_t h, int quirk, hipStream_t stream)
+{
+    if (h->skp_state == quirk && h->d_SKp) return GEMHIP_OK;
+    if (!h->d_SKp) GEMHIP_CHECK(hipMalloc((void **)&h->d_SKp, (size_t)h->n * sizeof(uint4)));
+    for (int32_t p = 0; p < h->parts; ++p) {
+        const int64_t off = h->part_off[p], np = h->part_off[p + 1] - off;
+        if (np <= 0) continue;
+        hipLaunchKernelGGL(n2v_slot_table_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, h->d_KTp + off, h->d_UKp + off, quirk, h->d_SKp + off);
+    }
+    GEMHIP_CHECK(hipGetLastError());
+    h->skp_state = quirk;
+    return GEMHIP_OK;
+}
+
 extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0, int32_t epochs, int32_t epoch,
                                  int64_t walk_lo, int64_t walk_hi, int64_t tokens_total, int64_t token_offset, uint64_t seed,
                                  int32_t flags, void *stream)
@@ -886,6 +1042,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     if (h->vocab_order) {      // the binary's table layout: slots over the nodes that occur, in first-appearance order; the slot table is always consulted
         A.KT = h->d_KTslot; A.n = (uint32_t)h->n_vocab; A.flags = flags | 2; A.UT = nullptr;
     }
+    A.SK = nullptr;
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->kn.prefetch; A.reload = h->kn.reload; A.counts = nullptr; A.hot_thr = 0;
     A.parts = 0; A.ctx_part = 0; A.word_part = 0; A.seg = nullptr; A.nseg = 0; A.seg_len = 0; A.scratch = nullptr;
@@ -893,6 +1050,8 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     GEMHIP_REQUIRE(P.lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for LDS staging (%zu bytes)", P.lds);
     A.nwaves = (int32_t)P.waves; A.cache_radius = P.R;
     if (P.window) {
+        { const int rc = ensure_slot_table(h, A.KT, (int64_t)A.n, (A.flags & 2) ? 1 : 0, (hipStream_t)stream); if (rc) return rc; }
+        A.SK = h->d_SK;
         // hot rows (sgns_win_kernel): never cached; the launch then takes the instantiation that handles uncached contexts
         A.counts = h->d_counts; A.hot_thr = P.hot_thr;
         const size_t need = (size_t)P.waves * sgns_win_row_floats(h->d) * sizeof(float);
@@ -968,6 +1127,8 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     const int64_t off = h->part_off[word_part];
     A.UT = h->d_UTp + off; A.KT = h->d_KTp + off; A.UK = h->d_UKp + off; A.n = (uint32_t)(h->part_off[word_part + 1] - off);
     A.seed = seed; A.flags = flags; A.d = d;
+    { const int rc = ensure_slot_table_parts(h, (flags & 2) ? 1 : 0, (hipStream_t)stream); if (rc) return rc; }
+    A.SK = h->d_SKp + off;
     A.SynPos = (float *)dSynPos_part; A.SynNeg = (float *)dSynNeg_part; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.prefetch = 2; A.reload = 1; A.counts = h->d_counts; A.hot_thr = 0;
     A.parts = h->parts; A.ctx_part = ctx_part; A.word_part = word_part; A.seg = (const int64_t *)d_seg; A.nseg = nseg; A.seg_len = seg_len;

@@ -18,6 +18,11 @@ struct SgnsArgs {
     // negative sampling (RndUnigramInt): slot = floor(u n) -> X = KT[slot] (flags & 2; else X = slot) -> target = u' < UK[X].x ? X : UK[X].y.  KT is indexed
     // by SLOT, UK = {UTable, KTable} by NODE: the same arrays in the node-id layout, different ones in the binary's vocabulary-order layout (n2v.hip)
     const float *UT; const int32_t *KT; const uint2 *UK; uint32_t n; uint64_t seed; int32_t flags; int32_t d;
+    // sgns_win_kernel: the same draw through ONE gather.  SK[slot] = {X, bits of UTable[X], KTable[X], 0} with X = KT[slot] (flags & 2) or slot: what the
+    // two dependent gathers KT[slot] -> UK[X] return, laid out by slot (n2v.hip: n2v_slot_table_kernel, built once per table and quirk setting).  One
+    // 16-byte random read per draw instead of a 4-byte and an 8-byte one: half the table sectors per pair (5 x 64 B less of ~6.5 KB, the counters
+    // charge every sector) and one dependent round trip less in the negative-target pipeline
+    const uint4 *SK;
     float *SynPos; float *SynNeg; int32_t nwaves; unsigned long long *pairs;
     float *dummy;               // sgns_win_kernel: nwaves rows, never read for their value
     unsigned long long *prof;   // GEMHIP_SGNS_PROFILE builds only: per-phase cycle sums (s_memtime)
@@ -381,7 +386,6 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     if (gw >= A.nwaves) return;
     const int d = A.d, win = A.window, len = A.walk_len, R = A.cache_radius, S = 2 * R + 1;
     const int nsamp = 2 * win * SGNS_NEG;
-    const bool quirk = (A.flags & 2) != 0;
     int32_t *tok = lds;
     constexpr int32_t PT_ROW = (1 << 29) - 1, PT_WORD = 1 << 29, PT_CTX = 1 << 30;
     // the token at position k as a centre word / as a context: its (local) row, or -1 when it is none in this launch (padding; PART: another partition)
@@ -467,12 +471,11 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         // slot directory: lane s < S describes slot s
         int32_t slot_node = -1, slot_ref = 0;
 
-        // --- negative-target pipeline: stage A (table slot -> X) for centre p, stage B (UT[X], KT[X]), finalize -> LDS
-        int32_t XA[NS], XB[NS], KTv[NS]; float uA[NS], uB[NS], UTv[NS];
+        // --- negative-target pipeline: stage A for centre p (Philox draws + one gather of {X, UT[X], KT[X]} per sample, A.SK), finalize -> LDS one centre later
+        int32_t XA[NS], KA[NS]; float uA[NS], UA[NS];
         // Only the samples of contexts the centre will train on are drawn: the window shrink b of centre p is itself a Philox draw, the
-        // draws are counter-based (skipping one changes no other), and the 2 x 3 uncoalesced table gathers per centre turned out to be what
+        // draws are counter-based (skipping one changes no other), and the uncoalesced table gathers per centre turned out to be what
         // caps the kernel (scripts/microbench/rows.hip "mix": 6.2 -> 4.5 G rows/s with them) -- 45 % of the slots are never used.
-        bool liveA[NS], liveB[NS];
         auto stage_a = [&](int p) {
             int bp = 0;
             if constexpr (PART) { if (p < len && __builtin_amdgcn_readfirstlane(tok_w(p)) < 0) p = len; }      // not a centre of this bucket: nothing is drawn
@@ -483,28 +486,20 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int s = lane + k * WAVE;
-                XA[k] = 0; uA[k] = 0.f; liveA[k] = false;
+                XA[k] = 0; uA[k] = 0.f; UA[k] = 2.f; KA[k] = 0;             // (a sample that is not drawn finalizes to target 0, which nothing reads)
                 if (p < len && s < nsamp) {
                     const int ai = s / SGNS_NEG;
                     const int a = ai < win ? ai : ai + 1;
                     const int cp = p - win + a;
                     if (a >= bp && a < 2 * win + 1 - bp && cp >= 0 && cp < len) {
-                        liveA[k] = true;
                         const int j = s - ai * SGNS_NEG + 1;
                         const u32x4 rn = philox4x32_10(A.seed, w_lo, w_hi, (uint32_t)p | ((uint32_t)a << 16),
                                                        (uint32_t)TAG_NEG | ((uint32_t)A.epoch << 8) | ((uint32_t)j << 16));
-                        const uint32_t slot = mulhi_range(rn.x, A.n);
-                        XA[k] = quirk ? A.KT[slot] : (int32_t)slot;          // RndUnigramInt (ELF @0x40d5f0)
+                        const uint4 e = A.SK[mulhi_range(rn.x, A.n)];          // RndUnigramInt (ELF @0x40d5f0): slot -> {X, UTable[X], KTable[X]}, one 16-byte gather
+                        XA[k] = (int32_t)e.x; UA[k] = __builtin_bit_cast(float, e.y); KA[k] = (int32_t)e.z;
                         uA[k] = u01(rn.y);
                     }
                 }
-            }
-        };
-        auto stage_b = [&]() {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                XB[k] = XA[k]; uB[k] = uA[k]; liveB[k] = liveA[k]; UTv[k] = 2.f; KTv[k] = 0;
-                if (liveB[k]) { const uint2 uk = A.UK[XB[k]]; UTv[k] = __builtin_bit_cast(float, uk.x); KTv[k] = (int32_t)uk.y; }   // one 8-byte gather
             }
         };
         // ... and the "special" mask of centre p: bit ai is set when the (centre, context) pair of slot ai cannot take the
@@ -517,7 +512,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int s = lane + k * WAVE;
-                if (s < nsamp) dst[s] = (uB[k] < UTv[k]) ? XB[k] : KTv[k];
+                if (s < nsamp) dst[s] = (uA[k] < UA[k]) ? XA[k] : KA[k];
             }
             if (p >= len) return 0u;
             const int32_t wordn = __builtin_amdgcn_readfirstlane(tok_w(p));
@@ -571,13 +566,11 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         uint32_t spec_next;
         if constexpr (PART) {
             pos_first = whole ? next_act(0) : 0;
-            stage_a(pos_first); stage_b();
+            stage_a(pos_first);
             spec_next = stage_fin(pos_first, 0);
-            stage_a(whole ? next_act(pos_first + 1) : 1);
         } else {
-            stage_a(0); stage_b();
+            stage_a(0);
             spec_next = stage_fin(0, 0);
-            stage_a(1);
         }
 
         // --- cache: enter token q (directory now, row through `rowE` -> LDS by the caller), leave token q
@@ -638,10 +631,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
         };
         int pos_next = 0, par = 1;                              // (par: PART whole-walk mode -- parity of the centre's ordinal among the visited ones; toggled at the top of an iteration)
         for (int pos = PART ? pos_first : 0; pos < len; pos = PART ? pos_next : pos + 1) {
-            // the next two positions the loop will visit (whole-walk mode: the next two that hold a centre word of this bucket)
-            int nx1 = pos + 1, nx2 = pos + 2;
+            // the next position the loop will visit (whole-walk mode: the next one that holds a centre word of this bucket)
+            int nx1 = pos + 1;
             if constexpr (PART) {
-                if (whole) { nx1 = next_act(pos + 1); nx2 = next_act(nx1 + 1); }
+                if (whole) nx1 = next_act(pos + 1);
                 pos_next = nx1; par ^= 1;
             }
             const int32_t word = __builtin_amdgcn_readfirstlane(tok_w(pos));
@@ -676,11 +669,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     }
                 }
             }
-            // negatives: B for centre pos+1, A for centre pos+2
+            // negatives of the next centre the loop will visit: drawn and gathered now, finalized inside this centre's first pair step
             PROF_LAP(0);
-            stage_b();
-            if constexpr (PART) stage_a(nx2); else stage_a(pos + 2);
-            PROF_LAP(5);                                             // negative-target pipeline: stage B gathers, stage A Philox + table gather
+            if constexpr (PART) stage_a(nx1); else stage_a(pos + 1);
+            PROF_LAP(5);                                             // negative-target pipeline: Philox + table gather
 
             float yp[NV][VEC], yp0[NV][VEC];                         // the centre's positive row SynNeg[word] (and, RELOAD, as it was loaded)
             float *pp = A.SynNeg + (int64_t)(word >= 0 ? word : 0) * d;
@@ -801,7 +793,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     PROF_LAP(3);                                     // waiting for this pair's rows (the younger prefetches may stay in flight)
                     tail_keep();                                     // (no instruction: the previous centre's store registers stay reserved up to here)
                     if (!fin_done) {
-                        // the negative targets of the NEXT centre: their table gather (stage_b, issued before this centre's first prefetch) is older than
+                        // the negative targets of the NEXT centre: their table gather (stage_a, issued before this centre's first prefetch) is older than
                         // the rows just waited for, so consuming it HERE costs no wait; after the pair loop it would be a full drain
                         if constexpr (PART) spec_next = stage_fin(nx1, whole ? (par ^ 1) : (nx1 & 1));
                         else spec_next = stage_fin(pos + 1, (pos + 1) & 1);

@@ -52,6 +52,8 @@ def lib():
         L.oracle_perm.restype = C.c_uint32
         L.oracle_alias_build_f32.argtypes = [C.c_int32, f32p, f32p, i32p, i32p]
         L.oracle_n2v_alias_rows.argtypes = [C.c_int64, i64p, f32p, f32p, i32p]
+        L.oracle_alias_build_hub.argtypes = [C.c_int32, f32p, f32p, i32p]
+        L.oracle_alias_build_hub.restype = None
         L.oracle_n2v_walks.argtypes = [C.c_int64, i64p, i32p, f32p, i32p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_uint64,
                                        C.c_int32, C.c_int64, C.c_int64, i32p, C.c_int64, i32p]
         L.oracle_n2v_vocab.argtypes = [C.c_int64, C.c_int64, i32p, i32p]

@@ -127,6 +127,76 @@ void oracle_alias_build_f32(int32_t N, const float *wts, float *U, int32_t *K, i
     while (nl > 0) { U[work[N - nl]] = 1.0f; --nl; }
 }
 
+/* ------------------------------------------------- Vose alias for HUB rows (N >= ORACLE_ALIAS_HUB_DEG)
+ * The same table GetNodeAlias builds, without its N-step sequential loop.  Its two stacks are filled in index order and popped from the back, so
+ * the smalls are met in DESCENDING index order s_1, s_2, ... and so are the larges L_1, L_2, ...; a large stays on top of its stack until it has
+ * absorbed more than its excess, then turns small and is absorbed at once by the NEXT large.  With D_j = sum_{i<=j} (1 - u[s_i]) (deficits met so
+ * far) and E_m = sum_{i<=m} (u[L_i] - 1) (excess spent so far) the loop's outcome is closed form:
+ *   small s_j goes to  K = L_m,  m = min{m : E_m >= D_{j-1}}               (none: the larges ran out, U = 1)
+ *   large L_m turns small when  D_j > E_m  first holds: U = 1 + E_m - D_j, K = L_{m+1}   (never, or no L_{m+1}: U = 1)
+ * i.e. two prefix sums and two binary searches per entry -- what gem_amd/csrc/n2v.hip's n2v_alias_hub_kernel runs with a workgroup per row (a
+ * 94 115-neighbour R-MAT hub is a 94k-step chain on ONE lane otherwise).  fp64, and the ORDER of every sum is fixed -- chunks of 256 entries in
+ * stack order, sequential inside a chunk, chunk totals accumulated sequentially, entry = chunk base + running sum inside the chunk -- so that this
+ * file and the kernel round identically: tables bit for bit.  Equal to the sequential loop in fp64 (tests/test_oracle_n2v.py: same K as the
+ * restatement pinned to the binary, U to 1e-12). */
+#define ORACLE_ALIAS_HUB_DEG 2048
+#define ORACLE_ALIAS_CHUNK 256
+void oracle_alias_build_hub(int32_t N, const float *wts, float *U, int32_t *K)
+{
+    const int32_t nch = (N + ORACLE_ALIAS_CHUNK - 1) / ORACLE_ALIAS_CHUNK;
+    double *cd = (double *)malloc(sizeof(double) * (size_t)nch * 2), *ce = cd + nch;
+    int32_t *cs = (int32_t *)malloc(sizeof(int32_t) * (size_t)nch * 2), *cl = cs + nch;
+    int32_t *S = (int32_t *)malloc(sizeof(int32_t) * (size_t)N * 2), *L = S + N;
+    double *D = (double *)malloc(sizeof(double) * (size_t)N * 2), *E = D + N;
+    double total = 0.0;
+    for (int32_t c = 0; c < nch; ++c) {                       /* chunks of the INDEX order for the total */
+        double t = 0.0;
+        const int32_t i1 = (c + 1) * ORACLE_ALIAS_CHUNK < N ? (c + 1) * ORACLE_ALIAS_CHUNK : N;
+        for (int32_t i = c * ORACLE_ALIAS_CHUNK; i < i1; ++i) t += (double)wts[i];
+        total += t;
+    }
+    /* stack order: r = 0 is the top of both stacks, i = N - 1 - r */
+    for (int32_t c = 0; c < nch; ++c) {
+        double ds = 0.0, es = 0.0; int32_t ns = 0, nl = 0;
+        const int32_t r1 = (c + 1) * ORACLE_ALIAS_CHUNK < N ? (c + 1) * ORACLE_ALIAS_CHUNK : N;
+        for (int32_t r = c * ORACLE_ALIAS_CHUNK; r < r1; ++r) {
+            const double u = ((double)wts[N - 1 - r] / total) * (double)N;
+            if (u < 1.0) { ds += 1.0 - u; ++ns; } else { es += u - 1.0; ++nl; }
+        }
+        cd[c] = ds; ce[c] = es; cs[c] = ns; cl[c] = nl;
+    }
+    double bd = 0.0, be = 0.0; int32_t bs = 0, bl = 0;        /* exclusive prefix over the chunks, sequential */
+    for (int32_t c = 0; c < nch; ++c) {
+        const double ds = cd[c], es = ce[c]; const int32_t ns = cs[c], nl = cl[c];
+        cd[c] = bd; ce[c] = be; cs[c] = bs; cl[c] = bl;
+        bd += ds; be += es; bs += ns; bl += nl;
+    }
+    const int32_t NS = bs, NL = bl;
+    for (int32_t c = 0; c < nch; ++c) {
+        double ds = 0.0, es = 0.0; int32_t ns = cs[c], nl = cl[c];
+        const int32_t r1 = (c + 1) * ORACLE_ALIAS_CHUNK < N ? (c + 1) * ORACLE_ALIAS_CHUNK : N;
+        for (int32_t r = c * ORACLE_ALIAS_CHUNK; r < r1; ++r) {
+            const int32_t i = N - 1 - r;
+            const double u = ((double)wts[i] / total) * (double)N;
+            K[i] = 0;
+            if (u < 1.0) { ds += 1.0 - u; S[ns] = i; D[ns] = cd[c] + ds; ++ns; U[i] = (float)u; }
+            else { es += u - 1.0; L[nl] = i; E[nl] = ce[c] + es; ++nl; U[i] = 1.0f; }
+        }
+    }
+    for (int32_t j = 0; j < NS; ++j) {                        /* smalls: first m with E[m] >= D[j-1] */
+        const double dp = j ? D[j - 1] : 0.0;
+        int32_t lo = 0, hi = NL;
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (E[mid] >= dp) hi = mid; else lo = mid + 1; }
+        if (lo < NL) K[S[j]] = L[lo]; else U[S[j]] = 1.0f;
+    }
+    for (int32_t m = 0; m < NL; ++m) {                        /* larges: first j with D[j] > E[m] */
+        int32_t lo = 0, hi = NS;
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (D[mid] > E[m]) hi = mid; else lo = mid + 1; }
+        if (lo < NS && m + 1 < NL) { U[L[m]] = (float)(1.0 + E[m] - D[lo]); K[L[m]] = L[m + 1]; }
+    }
+    free(cd); free(cs); free(S); free(D);
+}
+
 /* per-row first-order tables over a CSR graph */
 void oracle_n2v_alias_rows(int64_t n, const int64_t *row_ptr, const float *w, float *U, int32_t *K)
 {
@@ -136,7 +206,8 @@ void oracle_n2v_alias_rows(int64_t n, const int64_t *row_ptr, const float *w, fl
     int32_t *work = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxdeg);
     for (int64_t v = 0; v < n; ++v) {
         const int64_t a = row_ptr[v], deg = row_ptr[v + 1] - a;
-        if (deg > 0) oracle_alias_build_f32((int32_t)deg, w + a, U + a, K + a, work);
+        if (deg >= ORACLE_ALIAS_HUB_DEG) oracle_alias_build_hub((int32_t)deg, w + a, U + a, K + a);
+        else if (deg > 0) oracle_alias_build_f32((int32_t)deg, w + a, U + a, K + a, work);
     }
     free(work);
 }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """HOPE at BASELINE configs[2] (SBM 100k/1M, k=64, beta=0.01): the symmetric eigen-path (Chebyshev-filtered subspace iteration on A)
 against the general block-Krylov solver on S^T S -- seconds per solve, SpMM launches/columns, and the 64 singular values of each
-against the ARPACK golden (tests/golden/hope_sigma_sbm100k.json).  One JSON line per variant."""
+against the ARPACK golden (tests/golden/hope_sigma_sbm100k.json).  One JSON line per variant.  Arguments, if any, replace the variants:
+name:ENV=VAL,ENV=VAL (eigen-path forced on)."""
 import ctypes as C, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,6 +24,8 @@ stats = (C.c_double * 12)()
 variants = [('block_krylov', {'GEMHIP_HOPE_SYM': '0'}), ('sym', {'GEMHIP_HOPE_SYM': '1'})] + \
            [('sym_' + '_'.join('%s%s' % (a[16:].lower(), b) for a, b in sorted(e.items())), dict(e, GEMHIP_HOPE_SYM='1')) for e in (
                {'GEMHIP_HOPE_SYM_AMP': '1e5'}, {'GEMHIP_HOPE_SYM_MAXDEG': '30'})]
+if sys.argv[1:]:      # python scripts/ab_hope_sym.py name:ENV=VAL,ENV=VAL ...   (e.g. fused:GEMHIP_HOPE_SYM_FUSED_RR=1 two_pass:GEMHIP_HOPE_SYM_FUSED_RR=0)
+    variants = [(a.split(':', 1)[0], dict(GEMHIP_HOPE_SYM='1', **dict(kv.split('=', 1) for kv in a.split(':', 1)[1].split(',') if kv))) for a in sys.argv[1:]]
 s_ref = np.asarray(ref['sigma_ascending'])
 for name, env in variants:
     for kk in list(os.environ):

@@ -27,8 +27,23 @@ def _orth_scaled(Y, passes):
     return Y
 
 
-def sym_filter_svd(A, beta, k, oversample=16, tol=1e-5, max_cycles=60, amp=1e4, amp0=1e3, max_degree=32, seed=0, L=None, trace=None):
-    """A: scipy CSR float32, symmetric.  Returns (sigma descending [k], U [n,k], V [n,k], info)."""
+def _chol_coef(G):
+    """C with (Y C)^T (Y C) = I for G = Y^T Y, through the column-normalised Gram matrix; None when a pivot is lost (orth_scaled / the fused step)."""
+    d = 1.0 / np.sqrt(np.maximum(np.diag(G), 1e-300))
+    Gs = G * d[:, None] * d[None, :]
+    try:
+        R = np.linalg.cholesky(Gs).T
+    except np.linalg.LinAlgError:
+        return None
+    if (np.diag(R) ** 2 <= 1e-5).any():
+        return None
+    return np.linalg.inv(R) * d[:, None]
+
+
+def sym_filter_svd(A, beta, k, oversample=16, tol=1e-5, max_cycles=60, amp=1e4, amp0=1e3, max_degree=32, seed=0, L=None, trace=None, fused_rr=True):
+    """A: scipy CSR float32, symmetric.  Returns (sigma descending [k], U [n,k], V [n,k], info).
+    fused_rr (the kernel's default since round 4): the second CholeskyQR pass is not applied to the block; G2 = Y1^T Y1 and H1 = Y1^T A Y1 come from
+    one round trip, C2 = chol(G2)^-1 and C2^T H1 C2 are formed in fp64 and the Ritz rotation uses the coefficients C2 W."""
     n = A.shape[0]
     f = lambda x: beta * x / (1.0 - beta * x)
     b = min(k + oversample, n)
@@ -74,18 +89,34 @@ def sym_filter_svd(A, beta, k, oversample=16, tol=1e-5, max_cycles=60, amp=1e4, 
             rho_m = ta + np.sqrt(max(ta * ta - 1, 0.0))
         m = int(max(2, min(max_degree, np.floor(np.log(amp0 if cyc == 0 else amp) / np.log(max(rho_m, 1.0001))))))
         V = cheb(V, m, c, e, Q, q)
-        if Q.shape[1]:
+        C2 = None
+        if fused_rr:
+            V = _orth_scaled(V - Q @ (Q.T @ V), 1) if Q.shape[1] else _orth_scaled(V, 1)
+            if Q.shape[1]:
+                V = V - Q @ (Q.T @ V)
+            if Q.shape[1] + V.shape[1] < k + 1:
+                break
+            B = spmm(V)
+            C2 = _chol_coef((V.T @ V).astype(np.float64))
+            if C2 is None:
+                V = _orth_scaled(V, 1)
+        elif Q.shape[1]:
             V = _orth_scaled(V - Q @ (Q.T @ V), 1)
             V = _orth_scaled(V - Q @ (Q.T @ V), 1)
         else:
             V = _orth_scaled(V, 2)
         if Q.shape[1] + V.shape[1] < k + 1:
             break
-        B = spmm(V)
+        if C2 is None:
+            B = spmm(V)
         H = (V.T @ B).astype(np.float64); H = 0.5 * (H + H.T)
+        if C2 is not None:
+            H = C2.T @ H @ C2; H = 0.5 * (H + H.T)
         ev, Z = np.linalg.eigh(H)
         order = np.argsort(-np.abs(f(ev)), kind='stable')
         th, C = ev[order], Z[:, order]
+        if C2 is not None:
+            C = C2 @ C
         R = B @ C.astype(np.float32) + V @ (-(C * th)).astype(np.float32)
         V = V @ C.astype(np.float32)
         res = np.linalg.norm(R.astype(np.float64), axis=0)

@@ -85,6 +85,43 @@ def test_walks_and_tables_bit_exact(p, q, weighted):
     dev.close()
 
 
+def test_hub_row_alias_tables_bit_exact():
+    """A weighted graph with hub rows (2 500 and 9 000 neighbours, heavy-tailed weights): n2v_alias_hub_kernel -- a workgroup per hub row, the closed
+    form of GetNodeAlias's loop -- against oracle_alias_build_hub, whose summation order it shares: U and K bit for bit on every row (the short rows
+    keep the one-lane sequential build), then the walks that draw from them."""
+    rng = np.random.RandomState(5)
+    n = 12000
+    hubs = {0: 2500, 7: 9000}
+    src, dst = [], []
+    for hv, dg in hubs.items():
+        nb = rng.choice(np.setdiff1d(np.arange(n), [hv]), size=dg, replace=False)
+        src += [hv] * dg; dst += nb.tolist()
+        src += nb.tolist(); dst += [hv] * dg
+    extra = rng.randint(0, n, size=(30000, 2))
+    extra = extra[extra[:, 0] != extra[:, 1]]
+    src += extra[:, 0].tolist(); dst += extra[:, 1].tolist()
+    e = np.unique(np.stack([src, dst], 1), axis=0)
+    src, dst = e[:, 0].astype(np.int32), e[:, 1].astype(np.int32)
+    w = (rng.pareto(1.1, len(src)) + 0.01).astype(np.float32)
+    dev = Dev(n, src, dst, w)
+    row_ptr, col, ww = oracle.sorted_csr(n, src, dst, w)
+    assert (np.diff(row_ptr) >= 2048).sum() == 2
+    U, K = oracle.n2v_alias_rows(row_ptr, ww)
+    _hip.check(dev.L.gemhip_n2v_build_alias(dev.h, None))
+    Ud = np.empty(len(col), np.float32); Kd = np.empty(len(col), np.int32); cd = np.empty(len(col), np.int32)
+    assert dev.L.gemhip_n2v_get_alias(dev.h, _hip.ptr(Ud, C.c_float), _hip.ptr(Kd, C.c_int32), _hip.ptr(cd, C.c_int32)) == 0
+    assert np.array_equal(cd, col)
+    for v in (0, 7, 1, 100):
+        a, b = row_ptr[v], row_ptr[v + 1]
+        assert np.array_equal(Kd[a:b], K[a:b]), v
+        assert np.array_equal(Ud[a:b].view(np.int32), U[a:b].view(np.int32)), v
+    assert np.array_equal(Kd, K) and np.array_equal(Ud.view(np.int32), U.view(np.int32))
+    for p, q in ((1.0, 1.0), (0.5, 2.0)):
+        got = dev.walks(p, q, 2, 40, 7, SNAP)
+        assert np.array_equal(got, oracle.n2v_walks(row_ptr, col, U, K, p, q, 2, 40, 7, SNAP))
+    dev.close()
+
+
 def test_isolated_nodes_never_start_a_walk():
     """The reference binary builds its graph from the edge list: a node without any edge does not exist for it."""
     n = 40

@@ -201,6 +201,40 @@ def test_counter_based_oracle_builds_the_alias_tables_the_pinned_restatement_bui
         np.testing.assert_allclose(alias_implied(U, K), alias_implied(np.asarray(U64), K64), atol=2e-6)
 
 
+def test_hub_rows_closed_form_vose_is_get_node_alias():
+    """Rows of >= 2048 neighbours take the closed form of GetNodeAlias's loop (two prefix sums in stack order + binary searches: what the device's
+    n2v_alias_hub_kernel runs with a workgroup per row, same fixed summation order, bit for bit).  Against snap_stream.node_alias -- the sequential
+    loop in fp64, pinned to the binary through its walks: the SAME alias target for every entry that has one, U to fp32 rounding, the same entries at
+    U = 1, and the table encodes the weights.  Shapes: uniform, heavy-tailed (a hub's neighbours on a weighted power-law graph), all equal, one giant
+    weight among dust, and a size that is not a multiple of the 256-entry chunk."""
+    from oracle import snap_stream as ss
+    rng = np.random.RandomState(11)
+    cases = [(2048, rng.rand(2048)), (5000, rng.pareto(1.1, 5000) + 0.01), (20011, rng.pareto(0.9, 20011) + 1e-3), (3000, np.ones(3000)),
+             (4097, np.where(np.arange(4097) == 7, 100.0, 1e-3))]
+    for N, w in cases:
+        w = w.astype(np.float32)
+        U = np.zeros(N, np.float32); K = np.zeros(N, np.int32)
+        oracle.lib().oracle_alias_build_hub(N, oracle._p(w, C.c_float), oracle._p(U, C.c_float), oracle._p(K, C.c_int32))
+        P = w.astype(np.float64) / w.astype(np.float64).sum()
+        K64, U64 = ss.node_alias(P.tolist())
+        K64 = np.asarray(K64); U64 = np.asarray(U64)
+        has = U64 < 1.0
+        assert np.array_equal(K[has], K64[has])
+        np.testing.assert_allclose(U, U64, atol=1e-7)
+        assert np.array_equal(U64 >= 1.0, U.astype(np.float64) >= 1.0 - 1e-7)
+        np.testing.assert_allclose(alias_implied(U, K), P, atol=2e-7)
+    # oracle_n2v_alias_rows switches per row: a CSR with one hub row and short rows
+    deg = [5, 3000, 0, 17]
+    row_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    ww = (rng.pareto(1.3, row_ptr[-1]) + 0.05).astype(np.float32)
+    U, K = oracle.n2v_alias_rows(row_ptr, ww)
+    for v, dg in enumerate(deg):
+        if dg == 0:
+            continue
+        a = row_ptr[v]
+        np.testing.assert_allclose(alias_implied(U[a:a + dg], K[a:a + dg]), ww[a:a + dg].astype(np.float64) / ww[a:a + dg].astype(np.float64).sum(), atol=3e-6)
+
+
 def test_counter_based_oracle_walks_follow_the_pinned_transition_tables():
     """The rejection sampler of n2v_oracle.c (what the HIP walk kernel equals bit for bit) against the per-(t, v) alias tables of the
     restatement that reproduces the binary: the probabilities those tables encode are what its (t, v) -> x frequencies must follow."""
