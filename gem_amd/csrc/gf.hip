@@ -47,9 +47,13 @@ struct gemhip_gf_plan {
     bool own_X = false;
     int cur = 0;                      // X[cur] holds the latest table
     int rows_per_wave = 0;            // 0 = auto (gf_rows_per_wave), else forced (gemhip_gf_plan_set_rows_per_wave: tests, A/B)
-    // the sweep's row stores carry the non-temporal hint: a row written in a sweep is not read again before the next one, and at 1M rows the 484 MB a
-    // sweep writes would otherwise share each XCD's 4 MB of L2 with the 5 MB neighbour set the gathers hit in (GEMHIP_GF_NT_STORE, read per plan)
-    int nt_store = getenv("GEMHIP_GF_NT_STORE") ? atoi(getenv("GEMHIP_GF_NT_STORE")) : 0;
+    // Non-temporal hints of the sweep kernels (GEMHIP_GF_NT_STORE, read per plan; -1 = auto).  bit 1 (value 2): the load of a wave's OWN row -- with rows
+    // visited in ascending order it is the row's last use of the sweep (only lower rows gather it, and they ran before), and at SBM 1M/10M an XCD's 4 MB
+    // of L2 cannot even hold the 5 MB neighbour set the gathers hit in: marking the own-row stream evict-first took a sweep from 548 to 515 us
+    // (profiles/r04_ab_gf_nt.jsonl); bit 0 (value 1): the row stores (measured: no effect); bit 2 (value 4): the (col, w) / row-id / offset streams.
+    // Auto: 2 on the K-rows-per-wavefront kernel (the big levels), 0 on the one-row kernel (small, L2-resident levels, where nothing needs evicting).
+    // A hint only: results are bit-identical either way.
+    int nt_store = getenv("GEMHIP_GF_NT_STORE") ? atoi(getenv("GEMHIP_GF_NT_STORE")) : -1;
 };
 
 namespace {
@@ -210,7 +214,12 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
     if (first >= nrows) return;
     const int nk = (int)((nrows - first) < (int64_t)K ? (nrows - first) : (int64_t)K);
     int32_t rv = 0; int64_t pa = 0, pb = 0;
-    if (lane < nk) { rv = rows[row0 + first + lane]; pa = ptr[row0 + first + lane]; pb = ptr[row0 + first + lane + 1]; }
+    if (lane < nk) {
+        if (nt & 4) { rv = __builtin_nontemporal_load(rows + row0 + first + lane); pa = __builtin_nontemporal_load(ptr + row0 + first + lane); pb = __builtin_nontemporal_load(ptr + row0 + first + lane + 1); }
+        else { rv = rows[row0 + first + lane]; pa = ptr[row0 + first + lane]; pb = ptr[row0 + first + lane + 1]; }
+    }
+    auto ld_col = [&](int64_t e) -> uint32_t { return (nt & 4) ? __builtin_nontemporal_load(col + e) : col[e]; };
+    auto ld_w = [&](int64_t e) -> float { return (nt & 4) ? __builtin_nontemporal_load(w + e) : w[e]; };
     auto lane64 = [&](int64_t v, int k) -> int64_t {
         const uint32_t lo = bcast_lane((uint32_t)v, k), hi = bcast_lane((uint32_t)((uint64_t)v >> 32), k);
         return (int64_t)(((uint64_t)hi << 32) | lo);
@@ -220,8 +229,8 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
     int32_t i_n = bcast_lane(rv, 0);
     int64_t e0_n = lane64(pa, 0), e1_n = lane64(pb, 0);
     int cnt_n = (int)((e1_n - e0_n) < (int64_t)WAVE ? (e1_n - e0_n) : (int64_t)WAVE);
-    uint32_t cj_n = lane < cnt_n ? col[e0_n + lane] : 0u;
-    float wj_n = lane < cnt_n ? w[e0_n + lane] : 0.f;
+    uint32_t cj_n = lane < cnt_n ? ld_col(e0_n + lane) : 0u;
+    float wj_n = lane < cnt_n ? ld_w(e0_n + lane) : 0.f;
     float xi_n[NV][VEC];
 #pragma unroll
     for (int c = 0; c < NV; ++c) load_own_row<VEC>(Xold + (int64_t)i_n * d, d, lane, c, xi_n[c], nt);
@@ -240,8 +249,8 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
             i_n = bcast_lane(rv, k + 1);
             e0_n = lane64(pa, k + 1); e1_n = lane64(pb, k + 1);
             cnt_n = (int)((e1_n - e0_n) < (int64_t)WAVE ? (e1_n - e0_n) : (int64_t)WAVE);
-            cj_n = lane < cnt_n ? col[e0_n + lane] : 0u;
-            wj_n = lane < cnt_n ? w[e0_n + lane] : 0.f;
+            cj_n = lane < cnt_n ? ld_col(e0_n + lane) : 0u;
+            wj_n = lane < cnt_n ? ld_w(e0_n + lane) : 0.f;
 #pragma unroll
             for (int c = 0; c < NV; ++c) load_own_row<VEC>(Xold + (int64_t)i_n * d, d, lane, c, xi_n[c], nt);
         }
@@ -249,8 +258,8 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_rows_kernel(const int32_t *
         else if (cnt0 > 0) gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj0, wj0, cnt0, Xold, Xnew, d, lane, eta, regu);
         for (int64_t e = e0 + WAVE; e < e1; e += WAVE) {
             const int cnt = (int)((e1 - e) < (int64_t)WAVE ? (e1 - e) : (int64_t)WAVE);
-            const uint32_t cj = lane < cnt ? col[e + lane] : 0u;
-            const float wj = lane < cnt ? w[e + lane] : 0.f;
+            const uint32_t cj = lane < cnt ? ld_col(e + lane) : 0u;
+            const float wj = lane < cnt ? ld_w(e + lane) : 0.f;
             if (cnt == WAVE) gf_chunk<VEC, NV, DEEP>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
             else gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
         }
@@ -283,14 +292,14 @@ void launch_sweep(const gemhip_gf_plan *p, int64_t row0, int64_t nrows, const fl
         const int64_t blocks = (waves + GF_WAVES - 1) / GF_WAVES;
         const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
         hipLaunchKernelGGL((gf_sweep_rows_kernel<VEC, NV>), dim3((unsigned)grid), dim3(GF_BLOCK), 0, s, p->d_rows, p->d_ptr, p->d_col,
-                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K, p->nt_store);
+                           p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, K, p->nt_store < 0 ? 2 : p->nt_store);
         return;
     }
     const int64_t blocks = (nrows + GF_WAVES - 1) / GF_WAVES;
     // round the grid up to a multiple of 8 so the XCD-contiguous map covers every slot
     const int64_t grid = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
     hipLaunchKernelGGL((gf_sweep_kernel<VEC, NV>), dim3((unsigned)grid), dim3(GF_BLOCK), 0, s, p->d_rows, p->d_ptr, p->d_col,
-                       p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, p->nt_store);
+                       p->d_w, Xold, Xnew, row0, nrows, (int)p->d, eta, regu, p->nt_store < 0 ? 0 : p->nt_store);
 }
 
 // Hub rows (power-law graphs).  The updates of one row are one dependent chain (exact Gauss-Seidel): a wave that also fetches its
