@@ -89,7 +89,7 @@ template <int CPL16, int U>
 __global__ __launch_bounds__(256) void hope_spmm16_kernel(int64_t n, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
                                                           const float *__restrict__ val, float alpha, const float *__restrict__ X, int ldx,
                                                           const float *__restrict__ Wadd, int ldw, float *__restrict__ Y, int ldy, int b,
-                                                          float wa, const float *__restrict__ W2, int ldw2, float wb, int nt)
+                                                          float wa, const float *__restrict__ W2, int ldw2, float wb)
 {
     const int l16 = threadIdx.x & 15;
     const int64_t i = xcd_contiguous_block(blockIdx.x, gridDim.x) * 16 + (threadIdx.x >> 4);
@@ -131,11 +131,9 @@ __global__ __launch_bounds__(256) void hope_spmm16_kernel(int64_t n, const int64
         const int cc = l16 + c * 16;
         if (cc >= b) continue;
         if (!W2 && wa == 1.0f) Y[i * ldy + cc] = alpha * acc[c] + (Wadd ? Wadd[i * ldw + cc] : 0.f);
-        else {
-            // (nt: W2 is the oldest term of a three-term recurrence -- this read is its last use; the hint keeps it from evicting the block's gathered rows)
-            const float w2 = W2 ? wb * (nt ? __builtin_nontemporal_load(W2 + i * ldw2 + cc) : W2[i * ldw2 + cc]) : 0.f;
-            Y[i * ldy + cc] = fmaf(alpha, acc[c], fmaf(wa, Wadd ? Wadd[i * ldw + cc] : 0.f, w2));
-        }
+        else Y[i * ldy + cc] = fmaf(alpha, acc[c], fmaf(wa, Wadd ? Wadd[i * ldw + cc] : 0.f, W2 ? wb * W2[i * ldw2 + cc] : 0.f));
+        // (measured and dropped, round 4: reading W2 -- the oldest term of the three-term recurrence, its last use -- with the non-temporal hint: 12.65 ms per
+        // solve either way, profiles/r04_ab_hope_spmm_nt.jsonl; the block and its addends fit the chip's caches)
     }
 }
 
@@ -1122,8 +1120,7 @@ void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const f
         const int64_t blocks16 = (H.n + 15) / 16;
         const dim3 grid16((unsigned)((blocks16 + NUM_XCD - 1) / NUM_XCD * NUM_XCD));
         const int c16 = (b + 15) / 16;
-        static const int nt16 = getenv("GEMHIP_HOPE_SPMM_NT") ? atoi(getenv("GEMHIP_HOPE_SPMM_NT")) : 0;
-#define SPMM16(C, U) hipLaunchKernelGGL((hope_spmm16_kernel<C, U>), grid16, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb, nt16)
+#define SPMM16(C, U) hipLaunchKernelGGL((hope_spmm16_kernel<C, U>), grid16, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
         // neighbours in flight per row and round.  With the next round's (column, value) pairs prefetched, short rounds win: measured 2 / 4 / 8 / 16 at
         // SBM 100k/1M (about 20 neighbours per row): see the dispatch below; round 2, without the prefetch: 4 / 8 / 16 = 5.5 / 5.2 / 5.8 ms of SpMM per solve
         static const int uu = getenv("GEMHIP_HOPE_SPMM16_U") ? atoi(getenv("GEMHIP_HOPE_SPMM16_U")) : 4;
