@@ -36,7 +36,7 @@ def test_gram_mfma(n, m1, m2):
     assert np.abs(G - ref).max() <= 3e-6 * np.sqrt(n) * 4 + 1e-5 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize('n,m,b2', [(34, 18, 16), (5000, 80, 80), (4097, 320, 64), (1000, 37, 5), (33, 9, 70)])
+@pytest.mark.parametrize('n,m,b2', [(34, 18, 16), (5000, 80, 80), (4097, 320, 64), (1000, 37, 5), (33, 9, 70), (3001, 448, 128), (515, 40, 160), (100, 65, 97)])
 def test_tsgemm_mfma(n, m, b2):
     rng = np.random.RandomState(m)
     X = rng.randn(n, m).astype(np.float32); Cm = rng.randn(m, b2); S = rng.randn(n, b2).astype(np.float32)
