@@ -259,69 +259,10 @@ __global__ __launch_bounds__(256) void hope_tsgemm_kernel(int64_t n, const float
     }
 }
 
-// The same product with the X tile staged through LDS (round 4).  hope_tsgemm_kernel above gives every (32-row, 32-column) tile its own wavefront and lets
-// each lane read ITS row of X 16 bytes at a time: 32 different rows per load instruction, and the whole row block again for every column tile.  Here a
-// wavefront owns a 32-row block for ALL column tiles (CT <= 4 accumulator tiles, b2 <= 128): it copies the block's X rows into LDS 64 columns at a time
-// with coalesced 256-byte row reads, feeds the MFMAs from LDS (one ds_read_b128 per lane and k-step) and reads X from memory exactly once.  The
-// MFMA sequence per accumulator -- k pairs and their order -- is the one of hope_tsgemm_kernel: results are bit-identical.
-template <int CT>
-__global__ __launch_bounds__(256) void hope_tsgemm_lds_kernel(int64_t n, const float *__restrict__ X, int ldx, int m, const float *__restrict__ Cm,
-                                                              int ldc, int b2, float alpha, const float *Src, int lds_, float *Out, int ldo)
-{
-    constexpr int KC = 64, XS = KC + 4;                         // (row stride 272 bytes: 16-byte aligned for the b128 reads)
-    __shared__ __attribute__((aligned(16))) float sm[4 * 32 * XS];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int64_t rt = (int64_t)blockIdx.x * 4 + wave;
-    if (rt * 32 >= n) return;                                    // (no block-wide barrier below: a wavefront only ever touches its own quarter of sm)
-    float *xs = sm + wave * 32 * XS;
-    const int r = lane & 31, h = lane >> 5;
-    f32x16 acc[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
-    for (int kc = 0; kc < m; kc += KC) {
-        const int kn = (m - kc) < KC ? (m - kc) : KC;
-#pragma unroll 8
-        for (int rr = 0; rr < 32; ++rr) {
-            const int64_t row = rt * 32 + rr;
-            xs[rr * XS + lane] = (row < n && lane < kn) ? X[row * ldx + kc + lane] : 0.f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int k0 = 0; k0 < kn; k0 += 8) {
-            float a[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = xs[r * XS + k0 + 4 * h + t];       // (columns >= kn hold zeros)
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int jcol = c * 32 + r;
-                float bb[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int k = kc + k0 + 4 * h + t;
-                    bb[t] = (jcol < b2 && k < m) ? Cm[(int64_t)k * ldc + jcol] : 0.f;
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bb[t], acc[c], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int jcol = c * 32 + r;
-        if (jcol >= b2) continue;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int64_t row = rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (row < n) {
-                const float sv = Src ? Src[row * lds_ + jcol] : 0.f;
-                Out[row * ldo + jcol] = sv + alpha * acc[c][q];
-            }
-        }
-    }
-}
-
+// (Measured and dropped, round 4: the same product with a wavefront owning a 32-row block for ALL column tiles and the X tile staged through LDS with
+// coalesced row reads -- bit-identical, X read once instead of once per column tile: 11.87 against 11.61 ms per symmetric solve, 100.0 against 101.1 ms
+// per directed solve, profiles/r04_ab_hope_tsgemm_lds_dropped.jsonl.  The 16-byte-per-lane row reads above already hit the L1 lines the previous k steps
+// brought in, and the LDS kernels' registers and 35-70 KB of LDS per block cost the occupancy the short k loops need.)
 // ------------------------------------------- Ritz rotation + residual norms in one pass  (MFMA fp32)
 // Out = V C (the Ritz vectors) and, without ever storing it, R = B C - (V C) diag(theta): only the column norms of R are wanted, so every 32 x 32
 // tile leaves its columns' sums of squares in part[row tile][column] (fp32; summed in fp64, in a fixed order, by hope_colsum_kernel).  Same tiling
@@ -370,74 +311,6 @@ __global__ __launch_bounds__(256) void hope_ritz_kernel(int64_t n, const float *
     }
     ss += __shfl_xor(ss, 32);
     if (h == 0 && vc) part[rt * b2p + jcol] = ss;
-}
-// hope_ritz_kernel with the V and B tiles staged through LDS: a wavefront owns a 32-row block for all CT <= 4 column tiles (see hope_tsgemm_lds_kernel);
-// same MFMA sequence per accumulator, same per-tile sums of squares: bit-identical outputs.
-template <int CT>
-__global__ __launch_bounds__(256) void hope_ritz_lds_kernel(int64_t n, const float *__restrict__ V, int ldv, const float *__restrict__ B, int ldb, int m,
-                                                            const float *__restrict__ Cm, int ldc, int b2, const float *__restrict__ theta,
-                                                            float *__restrict__ Out, int ldo, float *__restrict__ part, int b2p)
-{
-    constexpr int KC = 64, XS = KC + 4;
-    __shared__ __attribute__((aligned(16))) float sm[4 * 2 * 32 * XS];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int64_t rt = (int64_t)blockIdx.x * 4 + wave;
-    if (rt * 32 >= n) return;
-    float *vs = sm + wave * 2 * 32 * XS, *bs = vs + 32 * XS;
-    const int r = lane & 31, h = lane >> 5;
-    f32x16 av[CT], ab[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { av[c][q] = 0.f; ab[c][q] = 0.f; }
-    for (int kc = 0; kc < m; kc += KC) {
-        const int kn = (m - kc) < KC ? (m - kc) : KC;
-#pragma unroll 8
-        for (int rr = 0; rr < 32; ++rr) {
-            const int64_t row = rt * 32 + rr;
-            const bool ok = row < n && lane < kn;
-            vs[rr * XS + lane] = ok ? V[row * ldv + kc + lane] : 0.f;
-            bs[rr * XS + lane] = ok ? B[row * ldb + kc + lane] : 0.f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int k0 = 0; k0 < kn; k0 += 8) {
-            float a[4], a2[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { a[t] = vs[r * XS + k0 + 4 * h + t]; a2[t] = bs[r * XS + k0 + 4 * h + t]; }
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int jcol = c * 32 + r;
-                float bb[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int k = kc + k0 + 4 * h + t;
-                    bb[t] = (jcol < b2 && k < m) ? Cm[(int64_t)k * ldc + jcol] : 0.f;
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    av[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bb[t], av[c], 0, 0, 0);
-                    ab[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t], bb[t], ab[c], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int jcol = c * 32 + r;
-        const bool vc = jcol < b2;
-        const float th = vc ? theta[jcol] : 0.f;
-        float ss = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int64_t row = rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            const float rs = fmaf(-th, av[c][q], ab[c][q]);
-            ss = fmaf(rs, rs, ss);
-            if (vc && row < n) Out[row * ldo + jcol] = av[c][q];
-        }
-        ss += __shfl_xor(ss, 32);
-        if (h == 0 && vc) part[rt * b2p + jcol] = ss;
-    }
 }
 // out[j] = sum over the row tiles of part[.][j], fp64, fixed order (one block per column)
 __global__ __launch_bounds__(256) void hope_colsum_kernel(const float *__restrict__ part, int64_t ntr, int b2p, double *__restrict__ out)
@@ -1312,19 +1185,10 @@ void gram(Hope &H, const float *X, int ldx, int m1, const float *Y, int ldy, int
     HOPE_TRY(H, hipStreamSynchronize(H.s));
 }
 
-// Out = Src + alpha X C with the coefficients already on the device: the LDS-staged kernel for up to 128 output columns, else one wavefront per tile
+// Out = Src + alpha X C with the coefficients already on the device
 static void tsgemm_launch(Hope &H, const float *X, int ldx, int m, const float *Cd, int b2, float alpha, const float *Src, int lds_, float *Out, int ldo)
 {
-    static const int use_lds = getenv("GEMHIP_HOPE_TSGEMM_LDS") ? atoi(getenv("GEMHIP_HOPE_TSGEMM_LDS")) : 1;
     const int ct = (b2 + 31) / 32;
-    if (use_lds && ct <= 4) {
-        const int64_t ntr = (H.n + 31) / 32;
-        const dim3 grid((unsigned)((ntr + 3) / 4)), blk(256);
-#define TSG(C) hipLaunchKernelGGL((hope_tsgemm_lds_kernel<C>), grid, blk, 0, H.s, H.n, X, ldx, m, Cd, b2, b2, alpha, Src, lds_, Out, ldo)
-        if (ct <= 1) TSG(1); else if (ct == 2) TSG(2); else if (ct == 3) TSG(3); else TSG(4);
-#undef TSG
-        return;
-    }
     const int64_t tiles = ((H.n + 31) / 32) * ct;
     hipLaunchKernelGGL(hope_tsgemm_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, X, ldx, m, Cd, b2, b2, alpha, Src, lds_, Out, ldo, ct);
 }
@@ -1396,17 +1260,9 @@ void ritz_rotate(Hope &H, const float *V, int ldv, const float *B, int ldb, int 
     for (size_t i = 0; i < (size_t)m * b2; ++i) slot.h[i] = (float)Ch[i];
     for (int j = 0; j < b2; ++j) slot.h[(size_t)m * b2 + j] = (float)theta[j];
     HOPE_TRY(H, hipMemcpyAsync(slot.d, slot.h, need * sizeof(float), hipMemcpyHostToDevice, H.s));
-    static const int use_lds = getenv("GEMHIP_HOPE_TSGEMM_LDS") ? atoi(getenv("GEMHIP_HOPE_TSGEMM_LDS")) : 1;
-    if (use_lds && ct <= 4) {
-        const dim3 grid((unsigned)((ntr + 3) / 4)), blk(256);
-#define RITZ(C) hipLaunchKernelGGL((hope_ritz_lds_kernel<C>), grid, blk, 0, H.s, H.n, V, ldv, B, ldb, m, slot.d, b2, b2, slot.d + (size_t)m * b2, Out, ldo, H.P, b2p)
-        if (ct <= 1) RITZ(1); else if (ct == 2) RITZ(2); else if (ct == 3) RITZ(3); else RITZ(4);
-#undef RITZ
-    } else {
-        const int64_t tiles = ntr * ct;
-        hipLaunchKernelGGL(hope_ritz_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, V, ldv, B, ldb, m, slot.d, b2, b2, slot.d + (size_t)m * b2, Out, ldo,
-                           H.P, b2p, ct);
-    }
+    const int64_t tiles = ntr * ct;
+    hipLaunchKernelGGL(hope_ritz_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, H.s, H.n, V, ldv, B, ldb, m, slot.d, b2, b2, slot.d + (size_t)m * b2, Out, ldo,
+                       H.P, b2p, ct);
     HOPE_TRY(H, hipEventRecord(slot.done, H.s));
     hipLaunchKernelGGL(hope_colsum_kernel, dim3(b2), dim3(256), 0, H.s, H.P, ntr, b2p, H.G);
     HOPE_TRY(H, hipMemcpyAsync(res2.data(), H.G, (size_t)b2 * sizeof(double), hipMemcpyDeviceToHost, H.s));
