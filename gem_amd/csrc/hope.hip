@@ -424,18 +424,32 @@ __global__ __launch_bounds__(256) void hope_colmax1_kernel(int64_t n, const floa
         pabs[o] = best; pval[o] = bv; pidx[o] = bi;
     }
 }
-__global__ __launch_bounds__(64) void hope_colmax2_kernel(int nchunks, int mc, const float *__restrict__ pabs, const float *__restrict__ pval,
-                                                          const long long *__restrict__ pidx, float *__restrict__ val)
+__global__ __launch_bounds__(256) void hope_colmax2_kernel(int nchunks, int mc, const float *__restrict__ pabs, const float *__restrict__ pval,
+                                                           const long long *__restrict__ pidx, float *__restrict__ val)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= mc) return;
-    float best = -1.f, bv = 0.f; long long bi = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {                       // chunks ascend in row order: a strict comparison keeps the first row on ties
+    // one block per column: every thread folds the chunks t, t + 256, ... (ascending), then the block's candidates meet in LDS under the same rule --
+    // larger magnitude, or equal magnitude and the smaller row.  (The first version walked a column's 512 chunk candidates on ONE thread: 135 us.)
+    __shared__ float s_abs[256], s_val[256];
+    __shared__ long long s_idx[256];
+    const int j = blockIdx.x;
+    float best = -1.f, bv = 0.f; long long bi = 0x7fffffffffffffffLL;
+    for (int ch = threadIdx.x; ch < nchunks; ch += 256) {
         const float a = pabs[(int64_t)ch * mc + j];
-        if (a > best) { best = a; bv = pval[(int64_t)ch * mc + j]; bi = pidx[(int64_t)ch * mc + j]; }
+        const long long ii = pidx[(int64_t)ch * mc + j];
+        if (a > best || (a == best && ii < bi)) { best = a; bv = pval[(int64_t)ch * mc + j]; bi = ii; }
     }
-    (void)bi;
-    val[j] = bv;
+    s_abs[threadIdx.x] = best; s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            const float a = s_abs[threadIdx.x + st];
+            if (a > s_abs[threadIdx.x] || (a == s_abs[threadIdx.x] && s_idx[threadIdx.x + st] < s_idx[threadIdx.x])) {
+                s_abs[threadIdx.x] = a; s_val[threadIdx.x] = s_val[threadIdx.x + st]; s_idx[threadIdx.x] = s_idx[threadIdx.x + st];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) val[j] = s_val[0];
 }
 
 // ------------------------------------------------------------- host: symmetric eigensolver (fp64)
@@ -1284,7 +1298,7 @@ void colmax(Hope &H, const float *X, int ld, int mc, float *val)
     long long *pidx = reinterpret_cast<long long *>(H.P);                    // (8-byte aligned part first)
     float *pabs = reinterpret_cast<float *>(pidx + per), *pval = pabs + per;
     hipLaunchKernelGGL(hope_colmax1_kernel, dim3(nchunks, (mc + 63) / 64), dim3(256), 0, H.s, H.n, X, ld, mc, rows_per_chunk, pabs, pval, pidx);
-    hipLaunchKernelGGL(hope_colmax2_kernel, dim3((mc + 63) / 64), dim3(64), 0, H.s, nchunks, mc, pabs, pval, pidx, val);
+    hipLaunchKernelGGL(hope_colmax2_kernel, dim3(mc), dim3(256), 0, H.s, nchunks, mc, pabs, pval, pidx, val);
 }
 
 // W[:, :cols] -= V[:, :m] (V[:, :m]^T W[:, :cols]) with the coefficients kept in HBM: Gram, fp64 slab reduction, fp32 rounding and
@@ -1760,6 +1774,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
                           float *U_sqrtS, float *V_sqrtS, float *sigma, double *stats, bool *fell_back)
 {
     *fell_back = false;
+    const auto ht0 = std::chrono::steady_clock::now();       // host timeline of the call (printed under GEMHIP_HOPE_DEBUG)
     const double beta = H.beta;
     auto fk = [&](double x) { return kind == 1 ? 1.0 + x : kind == 2 ? beta - x : beta * x / (1.0 - beta * x); };
     const int b = (int)std::min<int64_t>((int64_t)k + oversample, n);
@@ -1782,9 +1797,11 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
             hipFree(H.ws[slot]); H.ws[slot] = nullptr; H.ws_elems[slot] = 0;
             HOPE_TRY(H, hipMalloc((void **)&H.ws[slot], elems * sizeof(float)));
             if (!H.err) H.ws_elems[slot] = elems;
+            // zeroed when allocated: the padding columns (b .. ldv) are never written and never read as data, but they must not hold NaN patterns for
+            // the tools that scan whole buffers; a reused block holds the finite values of the previous solve (seven memsets per solve saved)
+            if (!H.err) HOPE_TRY(H, hipMemsetAsync(H.ws[slot], 0, elems * sizeof(float), H.s));
         }
         *p = H.ws[slot];
-        if (!H.err) HOPE_TRY(H, hipMemsetAsync(*p, 0, elems * sizeof(float), H.s));
     };
     walloc(0, &Vall, (size_t)n * ldv); walloc(1, &Bm, (size_t)n * ldv); walloc(2, &F[0], (size_t)n * ldv); walloc(3, &F[1], (size_t)n * ldv);
     walloc(4, &F[2], (size_t)n * ldv); walloc(5, &Tmp, (size_t)n * ldv); walloc(6, &colv, 512);
@@ -1799,6 +1816,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
     if (!H.err) { HOPE_TRY(H, hipEventCreate(&ev0)); HOPE_TRY(H, hipEventCreate(&ev1)); HOPE_TRY(H, hipEventCreate(&H.sp0)); HOPE_TRY(H, hipEventCreate(&H.sp1)); H.time_spmm = (stats != nullptr); }
     if (H.err) { cleanup(); return H.err; }
     hipEventRecord(ev0, H.s);
+    const auto ht1 = std::chrono::steady_clock::now();
 
     const int64_t threads = (n * (int64_t)b + 3) / 4;
     hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, H.s, Vall, n, b, ldv, seed);
@@ -1985,6 +2003,7 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         }
     }
     if (!H.err && !converged) { *fell_back = true; cleanup(); return GEMHIP_OK; }
+    const auto ht2 = std::chrono::steady_clock::now();
     if (!H.err) {
         struct Cand { double s, lam; int col; };
         std::vector<Cand> cand;
@@ -2015,8 +2034,15 @@ static int sym_filter_svd(Hope &H, int kind, int64_t n, int32_t k, int32_t overs
         // (measured: forming both outputs first and copying them out from two host threads side by side is 0.3 ms SLOWER per solve)
     }
     float ms = 0.f;
+    const auto ht3 = std::chrono::steady_clock::now();
     if (!H.err) { hipEventRecord(ev1, H.s); hipEventSynchronize(ev1); hipEventElapsedTime(&ms, ev0, ev1); }
+    const auto ht4 = std::chrono::steady_clock::now();
     if (!H.err) spmm_time_collect(H); else H.sp_used = 0;
+    if (debug) {
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double, std::micro>(b2 - a).count(); };
+        fprintf(stderr, "[hope-sym] host timeline (us): set-up %.0f | cycles %.0f | outputs %.0f | final event %.0f | spmm timers %.0f ; device window %.0f\n",
+                us(ht0, ht1), us(ht1, ht2), us(ht2, ht3), us(ht3, ht4), us(ht4, std::chrono::steady_clock::now()), ms * 1e3);
+    }
     if (stats && !H.err) {
         stats[0] = ms * 1e-3; stats[1] = H.spmm_count; stats[2] = H.spmm_cols; stats[3] = kind >= 1 ? -(double)kind : 0.0 /* no Katz series: f on the eigenvalues (-1: the Laplacian-Eigenmaps map, -2: LLE) */; stats[4] = nl + ma;
         stats[5] = cycles; stats[6] = last_change; stats[7] = br; stats[8] = g_eig_seconds; stats[9] = g_eig_calls; stats[10] = last_residual;
