@@ -110,3 +110,28 @@ def test_round4_default_line_carries_api_wall_and_honest_gf_fractions():
     q = j['quality']
     assert q['unigram_layout'].startswith('vocabulary order') and abs(q['map_minus_oracle_map']) <= 0.01 * q['oracle_map']
     assert abs(q['map_minus_reference_map']) <= 0.02 * q['reference_map']
+
+
+def test_round4_closing_line():
+    """profiles/r04b_bench_all.json = stdout of ONE un-profiled `python bench.py` at the end of round 4 (scripts/profile_round4b.sh bench): the contract
+    fields, fractions that are fractions, the API wall in every BASELINE workload -- and the round's kernel work visible in the line itself: the SGNS
+    traffic replayed from the slot-table PMC passes (6 054 B per pair), a headline no slower than the first session's, GF's sweep above 0.82 of the peak."""
+    j = json.loads(open(os.path.join(ROOT, 'profiles', 'r04b_bench_all.json')).read().strip().splitlines()[-1])
+    before = json.loads(open(os.path.join(ROOT, 'profiles', 'r04_bench_all.json')).read().strip().splitlines()[-1])
+    _check_line(j)
+    assert j['config']['workload'].startswith('sbm1000k_10000k_node2vec') and j['n_gpus'] == 1 and j['dtype'] == 'f32'
+    r = j['roofline']
+    assert r['kernel'] == 'sgns_win_kernel' and 0.75 < r['frac'] < 1.0 and r['frac'] > before['roofline']['frac']
+    assert 'r04b_pmc_traffic.json' in r['traffic_source'] and abs(r['traffic'] / r['pairs_per_launch'] - 6054.3) < 1.0
+    assert r['traffic'] < r['algorithmic_bytes_per_launch'] and j['value'] >= before['value']
+    for name, w in [('headline', j)] + list(j['workloads'].items()):
+        if not isinstance(w, dict) or 'roofline' not in w:
+            continue
+        assert 0.0 < w['roofline']['frac'] < 1.0, (name, w['roofline']['frac'])
+        assert w['api_wall']['seconds'] >= w['api_wall']['kernels_s'] > 0.0, name
+    g = j['workloads']['gf_sbm1m_10m']['roofline']
+    assert g['kernel'] == 'gf_sweep_rows_kernel' and 0.82 < g['frac'] < 0.9
+    q = j['quality']
+    assert abs(q['map_minus_oracle_map']) <= 0.01 * q['oracle_map'] and abs(q['map_minus_reference_map']) <= 0.02 * q['reference_map']
+    assert j['cpu_baseline']['kind'] == 'reference' and j['cpu_baseline']['value'] > 0
+
