@@ -492,9 +492,33 @@ static inline double eig_hypot(double a, double b) { const double r = std::sqrt(
     ATTR static void eig_rot##SFX(double *__restrict p0, double *__restrict p1, int n, double c, double s)            \
     {                                                                                                                  \
         for (int k = 0; k < n; ++k) { const double h = p1[k]; p1[k] = s * p0[k] + c * h; p0[k] = c * p0[k] - s * h; }  \
+    }                                                                                                                  \
+    /* two columns of the symmetric matrix-vector product at once: dots c0.d, c1.d and e += f0 c0 + f1 c1 -- d and e are  \
+       loaded once for both columns (5 loads + 1 store per 4 multiply-adds instead of 6 + 2) */                          \
+    ATTR static void eig_symv2##SFX(const double *__restrict c0, const double *__restrict c1, const double *__restrict d, \
+                                    double *__restrict e, double f0, double f1, int n, double *__restrict out)         \
+    {                                                                                                                  \
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                       \
+        int k = 0;                                                                                                     \
+        for (; k + 8 <= n; k += 8)                                                                                     \
+            for (int u = 0; u < 8; ++u) {                                                                              \
+                const double x0 = c0[k + u], x1 = c1[k + u], dk = d[k + u];                                            \
+                a[u] += x0 * dk; b[u] += x1 * dk;                                                                      \
+                e[k + u] += f0 * x0 + f1 * x1;                                                                         \
+            }                                                                                                          \
+        for (; k < n; ++k) { const double x0 = c0[k], x1 = c1[k], dk = d[k]; a[0] += x0 * dk; b[0] += x1 * dk; e[k] += f0 * x0 + f1 * x1; } \
+        out[0] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));                                    \
+        out[1] = ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));                                    \
+    }                                                                                                                  \
+    /* ... and of the rank-2 update: y0 -= f0 x + g0 z, y1 -= f1 x + g1 z */                                           \
+    ATTR static void eig_axpy22##SFX(double *__restrict y0, double *__restrict y1, const double *__restrict x, const double *__restrict z, \
+                                     double f0, double g0, double f1, double g1, int n)                                \
+    {                                                                                                                  \
+        for (int k = 0; k < n; ++k) { const double xk = x[k], zk = z[k]; y0[k] -= f0 * xk + g0 * zk; y1[k] -= f1 * xk + g1 * zk; } \
     }
 EIG_KERNELS(_base, )
 EIG_KERNELS(_avx2, __attribute__((target("avx2,fma"))))
+EIG_KERNELS(_avx512, __attribute__((target("avx512f,avx512dq,avx512vl,fma"))))
 #undef EIG_KERNELS
 
 struct EigOps {
@@ -502,13 +526,42 @@ struct EigOps {
     void (*axpy)(double *, double, const double *, int);
     void (*axpy2)(double *, double, const double *, double, const double *, int);
     void (*rot)(double *, double *, int, double, double);
+    void (*symv2)(const double *, const double *, const double *, double *, double, double, int, double *);
+    void (*axpy22)(double *, double *, const double *, const double *, double, double, double, double, int);
 };
+// Which build of the inner loops this host runs: GEMHIP_EIG_ISA=base|avx2|avx512 forces one (if the CPU has it); otherwise the widest the CPU
+// supports -- AVX-512 only where it is actually faster on THIS host (a 512-bit unit that is double-pumped, or a core that drops its clock for
+// 512-bit work, gains nothing): decided once by timing the reduction's two hot loops (dot + axpy over 2 048 doubles, ~50 us in total).
 static const EigOps &eig_ops()
 {
-    static const EigOps base = {eig_dot_base, eig_axpy_base, eig_axpy2_base, eig_rot_base};
-    static const EigOps avx2 = {eig_dot_avx2, eig_axpy_avx2, eig_axpy2_avx2, eig_rot_avx2};
-    static const bool has = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
-    return has ? avx2 : base;
+    static const EigOps base = {eig_dot_base, eig_axpy_base, eig_axpy2_base, eig_rot_base, eig_symv2_base, eig_axpy22_base};
+    static const EigOps avx2 = {eig_dot_avx2, eig_axpy_avx2, eig_axpy2_avx2, eig_rot_avx2, eig_symv2_avx2, eig_axpy22_avx2};
+    static const EigOps avx512 = {eig_dot_avx512, eig_axpy_avx512, eig_axpy2_avx512, eig_rot_avx512, eig_symv2_avx512, eig_axpy22_avx512};
+    static const EigOps *chosen = []() -> const EigOps * {
+        const bool has2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+        const bool has512 = has2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
+        if (const char *e = getenv("GEMHIP_EIG_ISA")) {
+            if (!strcmp(e, "base")) return &base;
+            if (!strcmp(e, "avx2") && has2) return &avx2;
+            if (!strcmp(e, "avx512") && has512) return &avx512;
+        }
+        if (!has2) return &base;
+        if (!has512) return &avx2;
+        std::vector<double> x(2048), y(2048, 0.0);
+        for (int k = 0; k < 2048; ++k) x[k] = 1.0 / (1.0 + k);
+        auto time_ops = [&](const EigOps &op) {
+            double best = 1e30, sink = 0.0;
+            for (int rep = 0; rep < 5; ++rep) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int it = 0; it < 16; ++it) { sink += op.dot(x.data(), y.data(), 2048); op.axpy(y.data(), 1e-9, x.data(), 2048); op.axpy2(y.data(), 1e-9, x.data(), 1e-9, x.data(), 2048); }
+                best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            }
+            return best + (sink == 12345.678 ? 1.0 : 0.0);
+        };
+        const double t2 = time_ops(avx2), t5 = time_ops(avx512);
+        return t5 < 0.9 * t2 ? &avx512 : &avx2;
+    }();
+    return *chosen;
 }
 
 // Host threads for the O(n^3) phases of the eigensolver (the reduction's matrix-vector product and rank-2 update, the
@@ -580,7 +633,25 @@ static void eig_reduce_steps(int n, std::vector<double> &V, std::vector<double> 
             h -= f * g;
             d[i - 1] = f - g;
             for (int j = 0; j < i; ++j) e[j] = 0.0;
-            for (int j = 0; j < i; ++j) {
+            int j = 0;
+            static const bool pairs = !(getenv("GEMHIP_EIG_PAIRS") && atoi(getenv("GEMHIP_EIG_PAIRS")) == 0);
+            for (; pairs && j + 1 < i; j += 2) {              // columns j and j + 1 together (eig_symv2: d and e travel once for both)
+                const double f0 = d[j], f1 = d[j + 1];
+                A(j, i) = f0; A(j + 1, i) = f1;
+                double g0 = e[j] + A(j, j) * f0;
+                const double a = A(j + 1, j);                 // column j's first element below the diagonal belongs to column j alone
+                g0 += a * f1;
+                e[j + 1] += f0 * a;
+                double g1 = e[j + 1] + A(j + 1, j + 1) * f1;
+                const int len = i - 2 - j;                    // k = j+2 .. i-1
+                if (len > 0) {
+                    double s2[2];
+                    op.symv2(col(j) + j + 2, col(j + 1) + j + 2, d.data() + j + 2, e.data() + j + 2, f0, f1, len, s2);
+                    g0 += s2[0]; g1 += s2[1];
+                }
+                e[j] = g0; e[j + 1] = g1;
+            }
+            for (; j < i; ++j) {
                 f = d[j];
                 A(j, i) = f;
                 g = e[j] + A(j, j) * f;
@@ -592,10 +663,18 @@ static void eig_reduce_steps(int n, std::vector<double> &V, std::vector<double> 
                 e[j] = g;
             }
             f = 0.0;
-            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            for (int jj = 0; jj < i; ++jj) { e[jj] /= h; f += e[jj] * d[jj]; }
             const double hh = f / (h + h);
-            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
-            for (int j = 0; j < i; ++j) {
+            for (int jj = 0; jj < i; ++jj) e[jj] -= hh * d[jj];
+            j = 0;
+            for (; pairs && j + 1 < i; j += 2) {
+                const double f0 = d[j], g0 = e[j], f1 = d[j + 1], g1 = e[j + 1];
+                A(j, j) -= f0 * g0 + g0 * f0;                 // k = j of column j
+                op.axpy22(col(j) + j + 1, col(j + 1) + j + 1, e.data() + j + 1, d.data() + j + 1, f0, g0, f1, g1, i - j - 1);     // k = j+1 .. i-1 of both
+                d[j] = A(i - 1, j); d[j + 1] = A(i - 1, j + 1);
+                A(i, j) = 0.0; A(i, j + 1) = 0.0;
+            }
+            for (; j < i; ++j) {
                 f = d[j]; g = e[j];
                 op.axpy2(col(j) + j, f, e.data() + j, g, d.data() + j, i - j);     // k = j .. i-1
                 d[j] = A(i - 1, j);
