@@ -168,7 +168,11 @@ int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr, const int3
                       const float *w, gemhip_n2v_t *out);
 int gemhip_n2v_destroy(gemhip_n2v_t h);
 /* PreprocessTransitionProbs: first-order Vose alias tables per row (no-op when every
- * row has equal weights).  2nd-order bias is applied by rejection inside the walk. */
+ * row has equal weights).  2nd-order bias is applied by rejection inside the walk.
+ * Rows of fewer than 2048 neighbours: GetNodeAlias's loop on one lane, fp32, bit for bit
+ * oracle_alias_build_f32; longer (hub) rows: the loop's closed form on a workgroup, fp64
+ * sums in a fixed order, bit for bit oracle_alias_build_hub (same alias targets as the
+ * sequential loop). */
 int gemhip_n2v_build_alias(gemhip_n2v_t h, void *stream);
 /* InitUnigramTable in the binary's layout (flags bit GEMHIP_N2V_VOCAB_ORDER of the one-shot call): see n2v.hip.  Needs the walks and the counts
  * (gemhip_n2v_vocab) of the whole corpus on this handle.  `flags`: bit 2 (the RndUnigramInt quirk) decides what a slot maps to.  n_vocab_out: nodes
