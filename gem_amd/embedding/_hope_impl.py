@@ -38,6 +38,8 @@ def learn(model, graph):
     model._stats['solver'] = 'symmetric_chebyshev_filter' if model._stats['katz_terms'] == 0 else 'block_krylov'   # hope.hip: A == A^T takes the eigen-path
     _hip.warn_if_unconverged(model._stats, float(getattr(model, '_tol', 1e-5)), int(getattr(model, '_max_restarts', 20)), 'HOPE')
     model._node_num = n
-    X64 = np.concatenate((U, V), axis=1).astype(np.float64)
+    X64 = np.empty((n, 2 * k), dtype=np.float64)              # [U sqrt(S) | V sqrt(S)] (hope.py:34-36), each half converted in place: one pass, no float32 concatenate
+    X64[:, :k] = U
+    X64[:, k:] = V
     model._api_wall = _hip.api_wall(t0, t1, t2, time.perf_counter())
     return X64
