@@ -9,12 +9,12 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p gem_amd/build/asan
-for f in eval gf hope runtime n2v sgns_hogwild sgns_det; do
+for f in eval gf hope runtime n2v sgns_hogwild sgns_det sgns_part multi; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer -w \
         -c gem_amd/csrc/$f.hip -o gem_amd/build/asan/$f.hip.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -o gem_amd/libgem_hip_asan.so gem_amd/build/asan/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -o gem_amd/libgem_hip_asan.so gem_amd/build/asan/*.o -ldl
 echo gem_amd/libgem_hip_asan.so
 if [ "$1" = test ]; then
     ASAN=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1)
