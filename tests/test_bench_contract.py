@@ -135,3 +135,27 @@ def test_round4_closing_line():
     assert abs(q['map_minus_oracle_map']) <= 0.01 * q['oracle_map'] and abs(q['map_minus_reference_map']) <= 0.02 * q['reference_map']
     assert j['cpu_baseline']['kind'] == 'reference' and j['cpu_baseline']['value'] > 0
 
+
+def test_round4_pmc_traffic_follows_from_the_committed_raw_counters():
+    """profiles/r04b_pmc_traffic.json (what bench.py replays into roofline.traffic) is arithmetic on the committed counter sums: FETCH_SIZE / WRITE_SIZE in
+    KiB per dispatch x 1024 x the calibration factor of the access pattern / the units of the launch (scripts/make_pmc_traffic.py)."""
+    import re
+    t = json.load(open(os.path.join(ROOT, 'profiles', 'r04b_pmc_traffic.json')))
+    ff, wf = t['calibration']['fetch_factor'], t['calibration']['write_factor']
+
+    def raw(path, kern, counter):
+        for line in open(os.path.join(ROOT, 'profiles', path)):
+            m = re.search(r'dispatches=(\d+) %s = ([0-9.e+]+)' % counter, line)
+            if m and kern in line:
+                return float(m.group(2)) / int(m.group(1))
+        raise AssertionError((path, kern, counter))
+    s = t['sgns_win_kernel']
+    assert abs(raw('r04b_pmc_raw_counters_sgns.txt', 'sgns_win_kernel', 'FETCH_SIZE') * 1024 * ff / s['pairs'] - s['fetch_bytes_per_pair']) < 0.5
+    assert abs(raw('r04b_pmc_raw_counters_sgns.txt', 'sgns_win_kernel', 'WRITE_SIZE') * 1024 * wf / s['pairs'] - s['write_bytes_per_pair']) < 0.5
+    assert abs(s['fetch_bytes_per_pair'] + s['write_bytes_per_pair'] - s['traffic_bytes_per_pair']) < 1e-6 and s['traffic_bytes_per_pair'] < s['algorithmic_bytes_per_pair']
+    g = t['gf_sweep_rows_kernel']
+    assert abs(raw('r04b_pmc_raw_counters_gf.txt', 'gf_sweep_rows_kernel', 'FETCH_SIZE') * 1024 * ff / g['fetch_bytes_per_launch'] - 1.0) < 1e-3
+    assert abs(raw('r04b_pmc_raw_counters_gf.txt', 'gf_sweep_rows_kernel', 'WRITE_SIZE') * 1024 * wf / g['write_bytes_per_launch'] - 1.0) < 1e-3
+    # the GF sweep writes every row once: rows x 512 B at d = 128 (WRITE_SIZE is exact for this access pattern)
+    assert abs(g['write_bytes_per_launch'] / (946188 * 512.0) - 1.0) < 1e-3
+
