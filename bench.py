@@ -708,6 +708,107 @@ def time_workload(name, args, rank, world, comm, K=None, W=None, with_cpu=True):
     return out, wl
 
 
+ROOFLINE_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'achieved_traffic_GBs', 'achieved_traffic_frac', 'avg_launch_us',
+                 'algorithmic_bytes_per_launch', 'regime_short')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample')
+QUALITY_KEYS = ('sampled_map', 'nodes_sampled', 'unigram_layout_short', 'reference_map', 'map_minus_reference_map', 'map_minus_reference_map_se', 'oracle_map',
+                'map_minus_oracle_map', 'map_minus_oracle_map_se', 'bit_identical_to_one_gpu', 'deviation_relative_to_largest_change')
+MAX_LINE_BYTES = 4000        # the driver parses the LAST stdout line from a bounded tail: round 4's 23 KB line came back as parsed = null
+
+
+def _pick(d, keys, maxlen=160):
+    out = {}
+    for k in keys:
+        if d is not None and k in d:
+            v = d[k]
+            out[k] = (v[:maxlen - 3] + '...') if isinstance(v, str) and len(v) > maxlen else v
+    return out
+
+
+def compact_line(full, detail_path=None):
+    """The ONE stdout line of the bench contract, <= MAX_LINE_BYTES: the contract fields of the headline workload, its `roofline` and `cpu_baseline`
+    objects reduced to their numbers, the parity gaps of `quality`, and a five-number summary of every other workload timed in the same process.
+    Everything else (notes, sources, API walls, launch plans, the full per-workload objects) goes to the detail record (stderr + file)."""
+    line = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                                 'dtype', 'data') if k in full}
+    line['config'] = _pick(full.get('config'), ('workload', 'nodes', 'directed_edges', 'd', 'sharding', 'driver'))
+
+    def roof(r):
+        if r is None:
+            return None
+        r = dict(r)
+        if 'regime' in r:
+            r['regime_short'] = 'launch-bound (tables L2-resident)'
+        return _pick(r, ROOFLINE_KEYS)
+    if 'roofline' in full:
+        line['roofline'] = roof(full['roofline'])
+    if 'cpu_baseline' in full:
+        line['cpu_baseline'] = _pick(full['cpu_baseline'], CPU_KEYS, 200)
+    if full.get('quality'):
+        q = dict(full['quality'])
+        if 'unigram_layout' in q:
+            q['unigram_layout_short'] = 'vocab-order' if q['unigram_layout'].startswith('vocab') else 'node-id'
+        line['quality'] = _pick(q, QUALITY_KEYS)
+    if full.get('phases'):
+        line['phases'] = {k: v for k, v in full['phases'].items() if isinstance(v, (int, float))}
+    if full.get('workloads'):
+        wl = {}
+        for name, w in full['workloads'].items():
+            if not isinstance(w, dict):
+                wl[name] = str(w)[:80]
+                continue
+            e = {'value': w.get('value'), 'unit': w.get('unit'), 'ms_per_step': w.get('ms_per_step')}
+            r = w.get('roofline') or {}
+            e.update({'kernel': r.get('kernel'), 'frac': r.get('frac'), 'traffic_frac': r.get('achieved_traffic_frac')})
+            c = w.get('cpu_baseline') or {}
+            if c.get('value'):
+                e['cpu'] = c['value']
+            q = w.get('quality') or {}
+            for k in ('oracle_map', 'map_minus_oracle_map', 'sampled_map'):
+                if q.get(k) is not None:
+                    e[k] = q[k]
+            wl[name] = {k: (float('%.6g' % v) if isinstance(v, float) else v) for k, v in e.items() if v is not None}
+        line['workloads'] = wl
+    if detail_path:
+        line['detail'] = detail_path
+
+    def rnd(o):
+        if isinstance(o, float):
+            return float('%.7g' % o)
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        return o
+    line = rnd(line)
+    s = json.dumps(line)
+    for victim in ('workloads', 'phases', 'quality'):          # never exceed the budget: drop the optional summaries, most voluminous first
+        if len(s) <= MAX_LINE_BYTES:
+            break
+        line.pop(victim, None)
+        s = json.dumps(line)
+    assert len(s) <= MAX_LINE_BYTES, len(s)
+    return s
+
+
+def emit(full):
+    """Rank 0: the detail record (everything measured, tens of KB) to a file and to stderr; then the compact line -- the only line on stdout."""
+    detail_path = None
+    text = json.dumps(full)
+    for d in (os.environ.get('GEM_BENCH_DETAIL_DIR'), os.path.join(ROOT, 'gpurun_out'), tempfile.gettempdir()):
+        if not d:
+            continue
+        try:
+            os.makedirs(d, exist_ok=True)
+            detail_path = os.path.join(d, 'bench_detail_latest.json')
+            with open(detail_path, 'w') as fh:
+                fh.write(text + '\n')
+            break
+        except OSError:
+            detail_path = None
+    log('BENCH_DETAIL ' + text)
+    rel = os.path.relpath(detail_path, ROOT) if detail_path and detail_path.startswith(ROOT) else detail_path
+    print(compact_line(full, rel), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -808,7 +909,7 @@ def main():
         out['workloads'] = extra
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()                       # rank 0 scores the embedding after the timed region: nobody tears the group down under it
         dist.destroy_process_group()

@@ -2138,6 +2138,7 @@ struct gemhip_hope_plan {
     int terms = 1;
     double br = 0.0;
     bool symmetric = false;                          // A == A^T entry for entry (columns sorted within rows): the eigen-path applies
+    double frob2_A = 0.0;                            // sum of the squared edge weights: ||beta A||_F^2 = beta^2 x this (gemhip_hope_plan_svd_error)
 };
 
 // Graph-dependent setup of the Katz operator: A and A^T in CSR on the device, number of series terms from sigma_max(A).
@@ -2154,6 +2155,7 @@ static int hope_setup(gemhip_hope_plan &P, int64_t n, int64_t nnz, const int64_t
     for (int64_t e = 0; e < nnz; ++e) {
         GEMHIP_REQUIRE(col[e] >= 0 && col[e] < n, "hope: column %d outside [0,%lld)", col[e], (long long)n);
         va[e] = w ? w[e] : 1.0f;
+        P.frob2_A += (double)va[e] * (double)va[e];
         ++rpT[col[e] + 1];
     }
     for (int64_t i = 0; i < n; ++i) rpT[i + 1] += rpT[i];
@@ -2312,6 +2314,53 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     phase_acc()[PH_D2H] = std::max(0.0, (t_done - t_solve) - st[0]);
     gemhip_hope_plan_destroy(P);
     phase_acc()[PH_TOTAL] = phase_now() - t_call;
+    return rc;
+}
+
+// hope.py:38-40 prints `SVD error (low rank): ||u diag(s) vt - S||_F` from the dense S it formed.  For the exact truncated SVD that norm is
+// sqrt(||S||_F^2 - sum_{i<=k} sigma_i^2), and ||S||_F^2 = trace(S^T S) = E ||S z||^2 over z ~ N(0, I) (Hutchinson): one application of the Katz
+// series to a block of `probes` random columns with the SpMM kernel the solve itself uses.  S = B + B^2 + ... with B = beta A, and ||B||_F^2 =
+// beta^2 sum w^2 is known exactly, so the probes only estimate the remainder: ||S||_F^2 ~ ||B||_F^2 + mean_z (||S z||^2 - ||B z||^2) -- on the
+// reference's graphs (beta x degree << 1) that remainder is a few percent of the total and the estimate is good to ~1e-3 relative with 32 probes.
+extern "C" int gemhip_hope_plan_svd_error(gemhip_hope_plan_t P, int32_t k, const float *sigma, int32_t probes, uint64_t seed, double *err_out, double *frob2_out)
+{
+    GEMHIP_REQUIRE(P != nullptr && sigma != nullptr && err_out != nullptr && k >= 1, "hope_plan_svd_error: bad arguments");
+    GEMHIP_REQUIRE(probes >= 1 && probes <= 128, "hope_plan_svd_error: probes=%d (1..128)", probes);
+    Hope &H = P->H;
+    GEMHIP_REQUIRE(H.mode == 0, "hope_plan_svd_error: the plan is not a Katz (HOPE) operator");
+    H.err = 0;
+    const int64_t n = H.n;
+    const int ld = (probes + 31) / 32 * 32;
+    float *blk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // Z, T0, T1, W0 (= B Z after apply_S), Out (= S Z)
+    for (float *&b : blk) { HOPE_TRY(H, hipMalloc((void **)&b, (size_t)n * ld * sizeof(float))); if (!H.err) HOPE_TRY(H, hipMemsetAsync(b, 0, (size_t)n * ld * sizeof(float), H.s)); }
+    if (!H.err) {
+        hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((n * probes / 4 + 256) / 256)), dim3(256), 0, H.s, blk[0], n, probes, ld, seed ^ 0x5356444572726F72ull);
+        apply_S(H, blk[0], ld, probes, P->terms, blk[1], blk[2], blk[3], ld, blk[4], ld);           // W0 keeps the first term B Z
+    }
+    std::vector<double> Gs, Gb;
+    gram(H, blk[4], ld, probes, blk[4], ld, probes, Gs);
+    gram(H, blk[3], ld, probes, blk[3], ld, probes, Gb);
+    for (float *b : blk) hipFree(b);
+    if (H.err) return H.err;
+    double rem = 0.0;
+    for (int j = 0; j < probes; ++j) rem += Gs[(size_t)j * probes + j] - Gb[(size_t)j * probes + j];
+    const double frob2 = (double)H.beta * (double)H.beta * P->frob2_A + rem / probes;
+    double top = 0.0;
+    for (int i = 0; i < k; ++i) top += (double)sigma[i] * (double)sigma[i];
+    *err_out = std::sqrt(std::max(0.0, frob2 - top));
+    if (frob2_out) *frob2_out = frob2;
+    return GEMHIP_OK;
+}
+
+// One-shot form for the plugin's verbose mode (hope.py:38-40): the plan is rebuilt (transpose + uploads), which costs about as much as the estimate itself.
+extern "C" int gemhip_hope_svd_error(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
+                                     const float *sigma, int32_t probes, uint64_t seed, double *err_out, double *frob2_out)
+{
+    gemhip_hope_plan_t P = nullptr;
+    int rc = gemhip_hope_plan_create(n, nnz, row_ptr, col, w, beta, &P);
+    if (rc) return rc;
+    rc = gemhip_hope_plan_svd_error(P, k, sigma, probes, seed, err_out, frob2_out);
+    gemhip_hope_plan_destroy(P);
     return rc;
 }
 

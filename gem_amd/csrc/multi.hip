@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <vector>
+#include <string>
 #include <algorithm>
 #include <cstring>
 #include <chrono>
@@ -30,6 +31,7 @@ namespace {
 
 struct RcclApi {
     void *lib = nullptr;
+    std::string why;                         // dlerror() text of the failed dlopen / the first missing symbol (dlerror clears itself when read)
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
@@ -49,9 +51,16 @@ RcclApi &rccl()
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         R.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (R.lib) break;
+        const char *e = dlerror();
+        if (R.why.empty() && e) R.why = e;
     }
     if (!R.lib) return R;
-#define GEMHIP_RCCL_SYM(f) R.f = (decltype(R.f))dlsym(R.lib, "nccl" #f)
+    R.why.clear();
+#define GEMHIP_RCCL_SYM(f)                                                                             \
+    do {                                                                                               \
+        R.f = (decltype(R.f))dlsym(R.lib, "nccl" #f);                                                  \
+        if (!R.f && R.why.empty()) R.why = "symbol nccl" #f " missing";                                \
+    } while (0)
     GEMHIP_RCCL_SYM(CommInitAll); GEMHIP_RCCL_SYM(CommDestroy); GEMHIP_RCCL_SYM(AllGather); GEMHIP_RCCL_SYM(AllReduce); GEMHIP_RCCL_SYM(Send);
     GEMHIP_RCCL_SYM(Recv); GEMHIP_RCCL_SYM(GroupStart); GEMHIP_RCCL_SYM(GroupEnd); GEMHIP_RCCL_SYM(GetErrorString);
 #undef GEMHIP_RCCL_SYM
@@ -63,6 +72,16 @@ RcclApi &rccl()
     do {                                                                                                                \
         ncclResult_t _r = (x);                                                                                          \
         if (_r != ncclSuccess) return fail(GEMHIP_E_HIP, "%s failed: %s (%s:%d)", #x, rccl().GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+// inside an open ncclGroupStart: the group is closed before the error is returned (a dangling group would swallow every later call of the thread)
+#define NCCL_TRY_IN_GROUP(x)                                                                                            \
+    do {                                                                                                                \
+        ncclResult_t _r = (x);                                                                                          \
+        if (_r != ncclSuccess) {                                                                                        \
+            rccl().GroupEnd();                                                                                          \
+            return fail(GEMHIP_E_HIP, "%s failed: %s (%s:%d)", #x, rccl().GetErrorString(_r), __FILE__, __LINE__);      \
+        }                                                                                                               \
     } while (0)
 
 __global__ void add_i32_kernel(int32_t *__restrict__ acc, const int32_t *__restrict__ x, int64_t n)
@@ -109,7 +128,7 @@ struct Fabric {
             GEMHIP_CHECK(hipStreamCreateWithFlags(&st[r], hipStreamNonBlocking));
         }
         RcclApi &R = rccl();
-        if (!R.ok) return fail(GEMHIP_E_UNSUPPORTED, "librccl.so.1 could not be loaded (%s): the multi-GPU entry points need RCCL", dlerror() ? dlerror() : "symbols missing");
+        if (!R.ok) return fail(GEMHIP_E_UNSUPPORTED, "librccl.so.1 could not be loaded (%s): the multi-GPU entry points need RCCL", R.why.empty() ? "unknown reason" : R.why.c_str());
         comm.assign(N, nullptr);
         NCCL_TRY(R.CommInitAll(comm.data(), N, dev.data()));
         return GEMHIP_OK;
@@ -140,7 +159,7 @@ struct Fabric {
         }
         RcclApi &R = rccl();
         NCCL_TRY(R.GroupStart());
-        for (int r = 0; r < N; ++r) NCCL_TRY(R.AllGather((const char *)buf[r] + (size_t)r * bytes, buf[r], bytes, ncclInt8, comm[r], st[r]));
+        for (int r = 0; r < N; ++r) NCCL_TRY_IN_GROUP(R.AllGather((const char *)buf[r] + (size_t)r * bytes, buf[r], bytes, ncclInt8, comm[r], st[r]));
         NCCL_TRY(R.GroupEnd());
         return GEMHIP_OK;
     }
@@ -155,7 +174,7 @@ struct Fabric {
         }
         RcclApi &R = rccl();
         NCCL_TRY(R.GroupStart());
-        for (int r = 0; r < N; ++r) NCCL_TRY(R.AllReduce(buf[r], buf[r], (size_t)count, ncclInt32, ncclSum, comm[r], st[r]));
+        for (int r = 0; r < N; ++r) NCCL_TRY_IN_GROUP(R.AllReduce(buf[r], buf[r], (size_t)count, ncclInt32, ncclSum, comm[r], st[r]));
         NCCL_TRY(R.GroupEnd());
         return GEMHIP_OK;
     }
@@ -170,8 +189,8 @@ struct Fabric {
         RcclApi &R = rccl();
         NCCL_TRY(R.GroupStart());
         for (int r = 0; r < N; ++r) {
-            NCCL_TRY(R.Send(send[r], bytes, ncclInt8, (r + N - 1) % N, comm[r], st[r]));
-            NCCL_TRY(R.Recv(recv[r], bytes, ncclInt8, (r + 1) % N, comm[r], st[r]));
+            NCCL_TRY_IN_GROUP(R.Send(send[r], bytes, ncclInt8, (r + N - 1) % N, comm[r], st[r]));
+            NCCL_TRY_IN_GROUP(R.Recv(recv[r], bytes, ncclInt8, (r + 1) % N, comm[r], st[r]));
         }
         NCCL_TRY(R.GroupEnd());
         return GEMHIP_OK;
@@ -193,6 +212,7 @@ struct DevBuf {          // frees on the device it was allocated on
 extern "C" int gemhip_rccl_selftest(int32_t n_gpus, const int32_t *devices, int64_t bytes, double *seconds)
 {
     GEMHIP_REQUIRE(bytes >= 4 && bytes % 4 == 0 && bytes <= ((int64_t)1 << 30), "rccl_selftest: bytes=%lld (multiple of 4, <= 1 GiB)", (long long)bytes);
+    GEMHIP_REQUIRE(n_gpus >= 1 && n_gpus <= 64, "rccl_selftest: n_gpus=%d (1..64)", n_gpus);
     Fabric F;
     F.always_rccl = true;                    // n_gpus = 1 exercises RCCL itself: a 1-rank all-gather / all-reduce / self send-recv
     int rc = F.init(n_gpus, devices);
@@ -244,6 +264,7 @@ extern "C" int gemhip_gf_train_multi(int64_t n, int64_t m, const int32_t *src, c
                                      int32_t max_iter, int32_t n_gpus, const int32_t *devices, float *X_inout, double *stats)
 {
     GEMHIP_REQUIRE(X_inout != nullptr && max_iter >= 0 && n > 0 && m >= 0 && d >= 1, "gf_train_multi: bad arguments");
+    GEMHIP_REQUIRE(n_gpus >= 1 && n_gpus <= 64, "gf_train_multi: n_gpus=%d (1..64)", n_gpus);          // before anything is sized or divided by it
     if (n_gpus > 1) {
         // ranks read each other's rows from the PREVIOUS sweep's table: that is the reference's sweep only when no firing edge reads a row the
         // reference has already updated in the same sweep, i.e. when the firing sources are first visited in ascending id order (gf.py:93-100 over
@@ -319,6 +340,7 @@ extern "C" int gemhip_n2v_train_multi(int64_t n, int64_t nnz, const int64_t *row
                                       const int32_t *devices, int32_t episodes, float *X_out, double *stats)
 {
     GEMHIP_REQUIRE(X_out != nullptr && episodes >= 1 && epochs >= 1 && epochs < 256, "n2v_train_multi: bad arguments (episodes=%d epochs=%d)", episodes, epochs);
+    GEMHIP_REQUIRE(n_gpus >= 1 && n_gpus <= 64, "n2v_train_multi: n_gpus=%d (1..64)", n_gpus);         // before anything is sized or divided by it
     Fabric F;
     int rc = F.init(n_gpus, devices);
     const int N = n_gpus;

@@ -12,6 +12,16 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'hogwild_stat: asserts a STATISTIC of a Hogwild (racy by design) launch -- collected after every deterministic test')
+
+
+def pytest_collection_modifyitems(config, items):
+    """The tier runs with -x.  Bit-exact / fixed-tolerance tests are deterministic; the Hogwild MAP assertions are not (their margins: tests/README.md).
+    A stable partition puts every `hogwild_stat` test AFTER the deterministic ones, whatever file it lives in, so that one statistical flake can never
+    hide a deterministic result (round 4's driver run stopped at test 190 of 195 and never reached run_karate / run_sbm)."""
+    det = [it for it in items if it.get_closest_marker('hogwild_stat') is None]
+    stat = [it for it in items if it.get_closest_marker('hogwild_stat') is not None]
+    items[:] = det + stat
 
 
 def golden_path(name):

@@ -74,6 +74,7 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
         assert r.returncode != 0 and 'GPU(s) visible' in r.stderr
 
 
+@pytest.mark.hogwild_stat
 def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference():
     """north_star's parity clause at BASELINE's own size (SBM 1M/10M): MAP within 1 % of the reference -- a flat 1 %, no allowance.
     Reference runs take 8-12 h of CPU each (scripts/make_golden_n2v_scale.py --nodes 1000000 --edges 10000000 --blocks 100): the
@@ -128,6 +129,7 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
         assert abs(np.mean(gaps)) <= 0.02, (gaps, ref['MAP'])
 
 
+@pytest.mark.hogwild_stat
 def test_node2vec_map_at_100k_within_one_percent_of_the_reference_binary():
     """north_star: MAP within 1 % of the reference.  gem/c_exe/node2vec (race-free, OMP_NUM_THREADS=1: 57 minutes of CPU) on
     SBM 100k/1M gives MAP 0.9127 over a fixed 1024-node sample; the HIP path on the same graph is scored on the same nodes

@@ -116,6 +116,7 @@ def test_n2v_train_multi_deterministic_equals_the_oracle_schedule(sbm1024, ranks
     assert np.abs(X - want).max() <= 2e-4 * np.abs(want).max() + 1e-6
 
 
+@pytest.mark.hogwild_stat
 @pytest.mark.parametrize('ranks', [1, 4])
 def test_n2v_train_multi_quality(sbm1024, ranks):
     """Hogwild buckets: graph-reconstruction MAP of the N-rank run against the sequential algorithm (same bar as the partitioned driver of

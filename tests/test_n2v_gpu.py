@@ -237,6 +237,7 @@ def test_sgns_window_cache_equals_round1_kernel(gname, d, window, l, radius, del
     dev.close()
 
 
+@pytest.mark.hogwild_stat
 def test_sgns_window_cache_hogwild_quality(sbm1024):
     """Multi-wave launches: MAP of the window kernel (full radius and a partial one: uncached contexts take atomic adds) against the SEQUENTIAL oracle on
     the same seed (same walks, same negatives), and the pair count (the unit of the roofline) identical to the round-1 kernel's.  Measured (round 3):
@@ -285,6 +286,7 @@ def test_init_tables_bit_exact():
     dev.close()
 
 
+@pytest.mark.hogwild_stat
 def test_hogwild_map_parity_with_oracle_and_snap(karate, sbm1024):
     """The production (parallel) mode through the plugin API: MAP within 3% of the sequential
     oracle's and of the real binary run race-free (n2v_ref.json *_t1); never below the racy 8-thread binary."""
@@ -382,6 +384,7 @@ def test_baseline_full_size_properties():
     assert MAP > 0.4, MAP                              # 0.48-0.49 in every bench.py run; chance is ~1e-5
 
 
+@pytest.mark.hogwild_stat
 @pytest.mark.parametrize('p,q', [(0.25, 4.0), (4.0, 0.25)])
 def test_second_order_walks_match_the_snap_binary_on_map(p, q, sbm1024):
     """p, q != 1 against the reference binary itself.  gem/c_exe/node2vec, race-free, on the reference's SBM-1024 graph

@@ -101,6 +101,7 @@ def test_train_part_with_one_partition_is_train(sbm1024):
     b.close()
 
 
+@pytest.mark.hogwild_stat
 @pytest.mark.parametrize('parts', [1, 4])
 def test_partitioned_schedule_quality_on_one_gpu(sbm1024, parts):
     """The episode schedule through the HIP backend with `parts` virtual ranks (Node2VecPartitioned.run_virtual; parts = 1 is the real world-1 run):
@@ -122,6 +123,7 @@ def test_partitioned_schedule_quality_on_one_gpu(sbm1024, parts):
     b.close()
 
 
+@pytest.mark.hogwild_stat
 def test_partitioned_16k_four_virtual_ranks_match_race_free_snap():
     """SBM 16384 / d = 128 with FOUR virtual ranks (16 buckets per episode, 64 episodes): the MAP of the partitioned schedule equals the reference
     binary's race-free run (tests/golden/n2v_ref_16k.json: 0.926) within 1 % -- the N > 1 counterpart of the single-GPU test below."""
@@ -137,6 +139,7 @@ def test_partitioned_16k_four_virtual_ranks_match_race_free_snap():
     b.close()
 
 
+@pytest.mark.hogwild_stat
 def test_sbm16k_map_matches_race_free_snap():
     """SBM 16384 nodes / 164k edges, d=128: the real binary single-threaded reaches MAP 0.926 (8 threads: 0.289,
     tests/golden/n2v_ref_16k.json, scripts/make_golden_n2v_16k.py).  The HIP path (Hogwild, auto width) must match the

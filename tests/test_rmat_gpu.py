@@ -44,6 +44,7 @@ def test_walks_weighted_second_order_on_hubs(rmat):
     dev.close()
 
 
+@pytest.mark.hogwild_stat
 def test_node2vec_hogwild_map_on_power_law_graph(rmat):
     """Hub rows are the contended ones under Hogwild: the GPU path must still land on the sequential oracle's MAP."""
     from gem_amd.embedding.node2vec import node2vec
@@ -67,6 +68,7 @@ def test_node2vec_hogwild_map_on_power_law_graph(rmat):
     assert abs(got - ref11) <= 0.15 * ref11 and ref11 > 1.2 * ref, (got, ref11, ref)
 
 
+@pytest.mark.hogwild_stat
 @pytest.mark.parametrize('layout', ['node_id', 'vocab_order'])
 def test_rmat17_default_concurrency_lands_on_the_sequential_oracle(layout):
     """The Hogwild defaults on a SECOND graph family at >= scale 17: R-MAT scale 17 -- 131 072 nodes, 1.86 M edges, max degree 9 510,

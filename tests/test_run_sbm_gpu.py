@@ -45,6 +45,7 @@ def test_hope_run_sbm_setting_matches_the_dense_oracle(sbm1024):
     assert np.linalg.norm(R - Ro) <= 3e-3 * np.linalg.norm(Ro)
 
 
+@pytest.mark.hogwild_stat
 def test_node2vec_run_sbm_setting_d182(sbm1024):
     """(1) TrainModel at d = 182 on one wavefront in walk order against the sequential oracle (2e-4, a slice of the corpus); (2) the full
     learn_embedding() call of run_sbm.py (Hogwild): reconstruction MAP against the sequential oracle's on the same seed -- the oracle's MAP at this
