@@ -645,6 +645,73 @@ class HopeWorkload(object):
 WORKLOADS = {'gf': GFWorkload, 'node2vec': N2VWorkload, 'hope': HopeWorkload}
 
 
+def capi_multi(args, rank, world):
+    """`--driver capi`: the N-GPU entry points of the C ABI themselves (include/gem_hip.h gemhip_gf_train_multi / gemhip_n2v_train_multi: ONE host
+    process drives n_gpus devices, RCCL loaded by the library) -- the interface INTEGRATION.md hands a GEM maintainer -- instead of the
+    torch.distributed stand-in of gem_amd/multi_gpu.py.  Under torch.distributed.run the call is made by rank 0 with devices 0..N-1 while the other
+    ranks wait at the barrier; `--virtual-ranks` (or a box with fewer GPUs than ranks under the gloo test backend) repeats device 0 in the list: the
+    library then runs the ranks as VIRTUAL ranks on one GPU (collectives become copies; sharding, schedule and kernels are the production code).
+    The entry points are one-shot drop-ins (host arrays in and out), so the timed region is the one the library reports in `stats`: GF = the K sweeps
+    including every exchange; node2vec = walks + vocabulary + corpus gather + training of one pass.  Returns the full bench record (rank 0) or None."""
+    name = 'node2vec' if args.workload == 'all' else args.workload
+    if name not in ('gf', 'node2vec'):
+        raise SystemExit('bench.py --driver capi: gf and node2vec shard (SURVEY 8e); hope is replicas only')
+    if rank != 0:
+        return None
+    g = make_graph(args)
+    n, src, dst, w, _ = edge_arrays(g)
+    N = args.gpus
+    virt = args.virtual_ranks or torch.cuda.device_count() < N
+    devs = (C.c_int32 * N)(*([0] * N if virt else list(range(N))))
+    L = _hip.lib()
+    K = args.steps if args.steps is not None else WORKLOADS[name].default_steps
+    W = args.warmup if args.warmup is not None else WORKLOADS[name].default_warmup
+    out = {'metric': 'edges/sec', 'unit': 'edges/s', 'n_gpus': N, 'steps': K, 'warmup': W, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+           'dtype': 'f32', 'data': 'synthetic'}
+    t_all = time.perf_counter()
+    if name == 'gf':
+        X = (0.01 * np.random.RandomState(1234).randn(n, args.d)).astype(np.float32)
+        st = (C.c_double * 8)()
+        call = lambda it: _hip.check(L.gemhip_gf_train_multi(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, args.d, args.gf_eta, args.gf_regu,
+                                                             it, N, devs, _hip.ptr(X, C.c_float), st))
+        if W:
+            call(W)
+        call(K)
+        el = st[0]
+        assert np.isfinite(X).all()
+        out.update({'value': g.number_of_edges() * K / el, 'ms_per_step': el * 1e3 / K,
+                    'config': {'workload': '%s%dk_%dk_gf_d%d_eta%g_regu%g' % (args.graph, args.nodes // 1000, args.edges // 1000, args.d, args.gf_eta, args.gf_regu),
+                               'nodes': n, 'directed_edges': g.number_of_edges(), 'd': args.d, 'sharding': 'source-node x%d' % N,
+                               'driver': 'capi gemhip_gf_train_multi' + (' (virtual ranks on one GPU)' if virt else '')},
+                    'phases': {'exchange_bytes_per_rank_per_sweep': st[3], 'updates_per_sweep': st[1], 'virtual_ranks': st[5]}})
+    else:
+        row_ptr, col, ww = to_csr(n, src, dst, w)
+        X = np.empty((n, args.d), np.float32)
+        st = (C.c_double * 8)()
+        secs = []
+        for it in range(W + K):
+            _hip.check(L.gemhip_n2v_train_multi(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, args.d, args.walk_len, args.num_walks,
+                                                args.window, 1, float(args.ret_p), float(args.inout_q), 20260923, _hip.N2V_SNAP_COMPAT, N, devs, args.episodes,
+                                                _hip.ptr(X, C.c_float), st))
+            if it >= W:
+                secs.append(st[0] + st[1])
+        el = float(np.sum(secs))
+        assert np.isfinite(X).all()
+        from gem_amd.evaluation import reconstruction as gr
+        nodes = np.random.RandomState(0).choice(n, size=min(1024, n), replace=False)
+        ap = gr.sampled_ap_gpu(g, None, X, nodes)
+        out.update({'value': g.number_of_edges() * K / el, 'ms_per_step': el * 1e3 / K,
+                    'config': {'workload': '%s%dk_%dk_node2vec_d%d_r%d_l%d_k%d' % (args.graph, args.nodes // 1000, args.edges // 1000, args.d, args.num_walks, args.walk_len, args.window),
+                               'nodes': n, 'directed_edges': g.number_of_edges(), 'd': args.d, 'sharding': 'start-node x%d, partitioned tables' % N,
+                               'driver': 'capi gemhip_n2v_train_multi' + (' (virtual ranks on one GPU)' if virt else '')},
+                    'phases': {'walks_vocab_gather_s': st[0], 'train_s': st[1], 'pairs_trained': st[3], 'ring_shift_bytes_per_rank_per_round': st[4],
+                               'bucket_launches_per_rank': st[7], 'virtual_ranks': st[6]},
+                    'quality': {'sampled_map': float(ap.mean()), 'nodes_sampled': int(len(nodes))}})
+    out['config']['world_size_seen'] = world
+    out['call_wall_s_incl_uploads_and_planning'] = time.perf_counter() - t_all
+    return out
+
+
 def time_workload(name, args, rank, world, comm, K=None, W=None, with_cpu=True):
     """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
     Returns (result dict on rank 0 else None, workload)."""
@@ -832,12 +899,23 @@ def main():
                     's > 1 is NOT the single-GPU algorithm: rows of other ranks are up to s-1 sweeps stale, `quality` reports the deviation)')
     ap.add_argument('--hope-directed', action='store_true', help='hope: orient every undirected edge in one random direction (A != A^T: the general case of hope.py)')
     ap.add_argument('--episodes', type=int, default=64, help='N>1 node2vec: episodes of the partitioned schedule')
+    ap.add_argument('--driver', default='torch', choices=['torch', 'capi'], help="N>1: 'torch' = one process per GPU over torch.distributed (gem_amd/multi_gpu.py, "
+                    "what the driver's command launches); 'capi' = rank 0 calls the library's own N-GPU entry points (gemhip_*_train_multi: one process, n_gpus devices)")
+    ap.add_argument('--virtual-ranks', action='store_true', help='--driver capi: run the N ranks as virtual ranks on device 0 (the one-GPU test box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api-wall', action='store_true', help='skip the extra learn_embedding() pass that fills `api_wall` (outside the timed region)')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    if args.gpus > 1 and args.driver == 'capi' and 'WORLD_SIZE' not in os.environ:
+        # one process IS the product's N-GPU shape: no ranks to spawn
+        if torch.cuda.device_count() < args.gpus and not args.virtual_ranks:
+            raise SystemExit('bench.py --gpus %d --driver capi: only %d GPU(s) visible (--virtual-ranks runs them on device 0)' % (args.gpus, torch.cuda.device_count()))
+        torch.cuda.set_device(0)
+        _hip.check(_hip.lib().gemhip_set_device(0))
+        emit(capi_multi(args, 0, 1))
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- N ranks of this very command under torch.distributed.run, one per GPU
         # (what the driver's N>1 command does explicitly).  Never fall back to one GPU silently: fewer devices than ranks is an error
@@ -868,6 +946,16 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.driver == 'capi' and args.gpus > 1:
+        if world > 1:
+            dist.barrier()
+        out = capi_multi(args, rank, world)
+        if rank == 0:
+            emit(out)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     comm = multi_gpu.TorchComm(world)
     headline = 'node2vec' if args.workload == 'all' else args.workload
     out, wl = time_workload(headline, args, rank, world, comm, args.steps, args.warmup, with_cpu=not args.no_cpu_baseline)

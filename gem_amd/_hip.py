@@ -178,6 +178,7 @@ def ptr(a, ctype):
     return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
 
 
+E_INVALID, E_HIP, E_UNSUPPORTED, E_NOTCONVERGED = -1, -2, -3, -4          # include/gem_hip.h GEMHIP_E_*
 N2V_PAD_ZERO, N2V_UNIGRAM_QUIRK, N2V_DETERMINISTIC, N2V_UNIFORM_FIRST_HOP = 1, 2, 4, 8
 N2V_SNAP_COMPAT = 11
 N2V_VOCAB_ORDER = 16              # unigram table in the binary's layout (first-appearance order over the nodes that occur)

@@ -291,6 +291,14 @@ int gemhip_n2v_copy_walks(gemhip_n2v_t h, int64_t walk_lo, int64_t walk_hi, void
  * shards and the partitioned-table schedule (`episodes` slices of every shard; rank g trains bucket (g, (g+s) % n_gpus) of each with
  * gemhip_sgns_train_part and passes its SynNeg partition around a ring).  stats (optional, 8 doubles): {walk + vocabulary + gather
  * seconds, training seconds, tokens, pairs trained, ring bytes per rank per round, n_gpus, virtual (0/1), bucket launches per rank}.
+ * Unigram-table layout: the per-partition alias tables are built over each partition's nodes in NODE-ID order.  flags with
+ * GEMHIP_N2V_VOCAB_ORDER (bit 16, the plugin default on one GPU) are therefore honoured only where they can be: n_gpus = 1 IS
+ * gemhip_n2v_train with those flags (same table, same model); n_gpus > 1 returns GEMHIP_E_UNSUPPORTED instead of silently training with
+ * another negative-sampling table -- pass GEMHIP_N2V_SNAP_COMPAT (11).
+ * STATUS of n_gpus > 1 on DISTINCT devices: the RCCL path (grouped in-place ncclAllGather, ncclAllReduce, ncclSend/ncclRecv ring, one
+ * non-blocking stream per device, all driven from one host thread) has only ever run with ONE rank (a 1-GPU test pool); with n_gpus > 1
+ * it has been exercised as virtual ranks only, where the three collectives are copies on one stream.  Treat the multi-device path as
+ * unvalidated until tests/test_multi_capi_gpu.py::test_real_devices_* has run on a box with >= 2 GPUs (they skip otherwise).
  * gemhip_rccl_selftest: communicator create -> all-gather / all-reduce / ring shift of `bytes` per rank on known patterns, every word
  * checked -> destroy. */
 int gemhip_gf_train_multi(int64_t n, int64_t m, const int32_t *src, const int32_t *dst, const float *w, int32_t d, float eta,

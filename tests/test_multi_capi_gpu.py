@@ -133,3 +133,74 @@ def test_n2v_train_multi_quality(sbm1024, ranks):
     Xs, _ = oracle.n2v_train(n, src, dst, None, 16, 80, 10, 10, 1, 1.0, 1.0, 1, 9)
     MAPs = gr.evaluateStaticGraphReconstruction(sbm1024, m, Xs.astype(np.float64), None)[0]
     assert abs(np.mean(maps) - MAPs) <= 0.08 * MAPs, (maps, MAPs)
+
+
+def test_multi_entry_points_reject_bad_rank_counts_before_sizing_anything():
+    """n_gpus <= 0 or > 64: GEMHIP_E_INVALID from all three entry points (round 4 divided by zero at n_gpus = 0 and threw across the C ABI at -1)."""
+    g = sbm_graph(300, 3000, 2, seed=3)
+    n, src, dst, w, _ = edge_arrays(g)
+    row_ptr, col, _ = to_csr(n, src, dst, None)
+    L = _hip.lib()
+    X = np.zeros((n, 8), np.float32)
+    for bad in (0, -1, -1000, 65):
+        assert L.gemhip_rccl_selftest(bad, None, 4096, None) == _hip.E_INVALID
+        assert L.gemhip_gf_train_multi(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, 8, 0.05, 0.01, 1, bad, None, _hip.ptr(X, C.c_float),
+                                       None) == _hip.E_INVALID
+        assert L.gemhip_n2v_train_multi(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, 8, 20, 1, 5, 1, 1.0, 1.0, 1, 11, bad, None, 2,
+                                        _hip.ptr(X, C.c_float), None) == _hip.E_INVALID
+        assert b'n_gpus' in L.gemhip_last_error()
+
+
+def test_n2v_train_multi_never_swaps_the_unigram_layout_silently(sbm1024):
+    """flags with GEMHIP_N2V_VOCAB_ORDER (27, the plugin default): one device IS gemhip_n2v_train -- same table, and in the deterministic mode the same
+    embedding bit for bit; more than one (virtual) device refuses the flag instead of training with node-id-order partition tables."""
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    row_ptr, col, _ = to_csr(n, src, dst, None)
+    L = _hip.lib()
+    a = np.empty((n, 16), np.float32); b = np.empty((n, 16), np.float32)
+    args = (n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, 16, 30, 2, 5, 1, 1.0, 1.0, 7, _hip.N2V_SNAP_LAYOUT | 4)
+    _hip.check(L.gemhip_n2v_train(*args, _hip.ptr(a, C.c_float), None))
+    st = (C.c_double * 8)()
+    _hip.check(L.gemhip_n2v_train_multi(*args, 1, None, 3, _hip.ptr(b, C.c_float), st))
+    assert np.array_equal(a, b) and st[5] == 1.0 and st[2] > 0
+    assert L.gemhip_n2v_train_multi(*args, 2, _devs(2), 3, _hip.ptr(b, C.c_float), None) == _hip.E_UNSUPPORTED
+    assert b'VOCAB_ORDER' in L.gemhip_last_error()
+
+
+def _real_devices(k):
+    import torch
+    if torch.cuda.device_count() < k:
+        pytest.skip('needs %d GPUs on one node (the test pool has one): the RCCL path across DISTINCT devices stays unvalidated until this runs' % k)
+    return (C.c_int32 * k)(*range(k))
+
+
+@pytest.mark.parametrize('ranks', [2, 4])
+def test_real_devices_gf_train_multi_is_bit_identical_to_one_gpu(ranks):
+    """The assertions of the virtual-rank test on DISTINCT devices: grouped in-place ncclAllGather over RCCL/xGMI after every sweep."""
+    devs = _real_devices(ranks)
+    g = sbm_graph(20011, 200000, 8, seed=3)
+    n, src, dst, w, _ = edge_arrays(g)
+    X0 = (0.05 * np.random.RandomState(0).randn(n, 128)).astype(np.float32)
+    L = _hip.lib()
+    a = X0.copy(); b = X0.copy()
+    _hip.check(L.gemhip_gf_train(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, 128, 0.05, 0.01, 12, _hip.ptr(a, C.c_float), None))
+    st = (C.c_double * 8)()
+    _hip.check(L.gemhip_gf_train_multi(n, len(src), _hip.ptr(src, C.c_int32), _hip.ptr(dst, C.c_int32), None, 128, 0.05, 0.01, 12, ranks, devs, _hip.ptr(b, C.c_float), st))
+    assert np.array_equal(a, b) and st[4] == ranks and st[5] == 0.0
+    _hip.check(L.gemhip_rccl_selftest(ranks, devs, 1 << 22, None))
+
+
+@pytest.mark.parametrize('ranks,episodes', [(2, 3), (4, 4)])
+def test_real_devices_n2v_train_multi_deterministic_equals_the_oracle_schedule(sbm1024, ranks, episodes):
+    """The deterministic schedule test on DISTINCT devices: count all-reduce, corpus all-gather and the ncclSend / ncclRecv ring of SynNeg partitions."""
+    devs = _real_devices(ranks)
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    row_ptr, col, _ = to_csr(n, src, dst, None)
+    d, Lw, r, win, seed, flags = 16, 30, 1, 5, 7, 11
+    X = np.empty((n, d), np.float32)
+    st = (C.c_double * 8)()
+    _hip.check(_hip.lib().gemhip_n2v_train_multi(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, d, Lw, r, win, 1, 1.0, 1.0, seed,
+                                                 flags | 4, ranks, devs, episodes, _hip.ptr(X, C.c_float), st))
+    want, pairs = _oracle_multi_schedule(n, src, dst, d, Lw, r, win, seed, flags, ranks, episodes)
+    assert st[3] == pairs and st[5] == ranks and st[6] == 0.0
+    assert np.abs(X - want).max() <= 2e-4 * np.abs(want).max() + 1e-6
