@@ -342,6 +342,7 @@ class N2VWorkload(object):
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                 'launch_plan': self.launch_plan(),
                 'traffic': traffic, 'traffic_source': tsrc, 'achieved_traffic_GBs': None if traffic is None else traffic / avg_s / 1e9,
+                'achieved_traffic_frac': None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
                 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6,
                 'pairs_per_launch': pairs / launches, 'tokens_per_launch': tokens,
                 'sgns_fraction_of_step': ms / dev_ms_total,
@@ -459,13 +460,17 @@ class N2VWorkload(object):
         assert float(self.P.abs().max()) > 1e-3
 
     @staticmethod
-    def _ref_golden(engine, n):
-        """Committed reference run of `engine` ('snap' | 'oracle') on the n-node benchmark graph: the one scored over the larger node sample."""
+    def _ref_golden(engine, n, vocab_order=False):
+        """Committed reference run of `engine` ('snap' | 'oracle') on the n-node benchmark graph: the one scored over the larger node sample; for the
+        oracle, the run in the unigram-table layout the timed pass used (vocab_order: flags 27, the binary's; else flags 11) when it exists."""
         gdir = os.path.join(ROOT, 'tests', 'golden')
-        for name in ('n2v_ref_%s_%dk_s4096.json' % (engine, n // 1000), 'n2v_ref_%s_%dk.json' % (engine, n // 1000)):
+        names = ['n2v_ref_%s_%dk_s4096.json' % (engine, n // 1000), 'n2v_ref_%s_%dk.json' % (engine, n // 1000)]
+        if engine == 'oracle' and vocab_order:
+            names.insert(0, 'n2v_ref_oracle_%dk_vocab_order_s4096.json' % (n // 1000))
+        for name in names:
             if os.path.exists(os.path.join(gdir, name)):
                 return os.path.join(gdir, name)
-        return os.path.join(gdir, 'n2v_ref_%s_%dk.json' % (engine, n // 1000))
+        return os.path.join(gdir, names[-1])
 
     def quality(self, nsample=1024):
         """Outside the timed region: graph-reconstruction MAP of the learned table over a FIXED node sample, with the reference
@@ -473,8 +478,9 @@ class N2VWorkload(object):
         sample (tests/golden/n2v_ref_snap_<n>k.json, made by scripts/make_golden_n2v_scale.py: gem/c_exe/node2vec race-free)."""
         from gem_amd.evaluation import reconstruction as gr
         a = self.args
+        vo = bool(getattr(self.b, 'vocab_order', False))
         for engine in ('snap', 'oracle'):             # score the sample the committed reference runs were scored on
-            path = self._ref_golden(engine, self.g.n)
+            path = self._ref_golden(engine, self.g.n, vo)
             if a.graph == 'sbm' and os.path.exists(path):
                 nsample = max(nsample, len(json.load(open(path))['ap']))
         rng = np.random.RandomState(0)
@@ -482,11 +488,13 @@ class N2VWorkload(object):
         ap = gr.sampled_ap_gpu(self.g, None, self.P.cpu().numpy(), nodes)
         out = {'sampled_map': float(ap.mean()), 'sampled_map_se': float(ap.std(ddof=1) / np.sqrt(len(ap))), 'nodes_sampled': int(len(nodes)),
                'evaluator': 'metrics.computeMAP semantics on the GPU', 'reference_map': None,
-               'unigram_layout': 'vocabulary order (the binary\'s: GEMHIP_N2V_VOCAB_ORDER)' if getattr(self.b, 'vocab_order', False) else 'node-id order'}
+               'unigram_layout': 'vocabulary order (the binary\'s: GEMHIP_N2V_VOCAB_ORDER)' if vo else 'node-id order'}
         ap_by_engine = {'snap': ap, 'oracle': ap}
-        if getattr(self.b, 'vocab_order', False) and a.graph == 'sbm' and os.path.exists(self._ref_golden('oracle', self.g.n)) and self.world == 1:
-            # the sequential oracle's committed run drew its negatives from the node-id layout: one more pass (outside every timed region) in THAT layout,
-            # same seed, pairs with it draw for draw; the timed pass (the binary's layout) is scored against the reference binary's own run
+        opath = self._ref_golden('oracle', self.g.n, vo)
+        oflags = json.load(open(opath))['params'].get('flags', 11) if (a.graph == 'sbm' and os.path.exists(opath)) else None
+        if vo and oflags is not None and not (oflags & 16) and self.world == 1:
+            # only a node-id-layout oracle run is committed for this size: one more pass (outside every timed region) in THAT layout, same seed, pairs
+            # with it draw for draw.  (At the headline size the oracle's flags-27 run is committed since round 5 and the timed pass itself pairs with it.)
             self.b.vocab_order = False
             P2 = self.job.run(float(a.ret_p), float(a.inout_q))
             self.b.vocab_order = True
@@ -495,7 +503,7 @@ class N2VWorkload(object):
                                   'sampled_map': float(ap_by_engine['oracle'].mean())}
         for engine, key in (('snap', 'reference_map'), ('oracle', 'oracle_map')):
             ap = ap_by_engine[engine]
-            path = self._ref_golden(engine, self.g.n)
+            path = self._ref_golden(engine, self.g.n, vo)
             if a.graph == 'sbm' and os.path.exists(path):
                 ref = json.load(open(path))
                 pr = ref['params']
@@ -583,6 +591,7 @@ class HopeWorkload(object):
         traffic = None if per_col is None else per_col * bavg
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                 'traffic': traffic, 'traffic_source': tsrc, 'achieved_traffic_GBs': None if traffic is None else traffic / avg_s / 1e9,
+                'achieved_traffic_frac': None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
                 'algorithmic_bytes_per_launch': algo, 'avg_launch_us': avg_s * 1e6, 'spmm_launches_per_step': launches / self.calls,
                 'avg_block_columns': bavg, 'device_seconds_per_step': self.dev_s / self.calls, 'spmm_seconds_per_step': self.spmm_s / self.calls,
                 'host_eig_seconds_per_step': self.eig_s / self.calls, 'restarts': self.stats[5], 'katz_terms': self.stats[3],
@@ -841,7 +850,7 @@ def compact_line(full, detail_path=None):
 
     def rnd(o):
         if isinstance(o, float):
-            return float('%.7g' % o)
+            return float('%.10g' % o)
         if isinstance(o, dict):
             return {k: rnd(v) for k, v in o.items()}
         return o

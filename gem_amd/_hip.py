@@ -59,8 +59,8 @@ _SIGS = {
     'gemhip_hope_plan_destroy': (C.c_int, [C.c_void_p]),
     'gemhip_hope': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_float, C.c_uint64, f32p, f32p, f32p, f64p]),
-    'gemhip_hope_svd_error': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, f32p, C.c_int32, C.c_uint64, f64p, f64p]),
-    'gemhip_hope_plan_svd_error': (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int32, C.c_uint64, f64p, f64p]),
+    'gemhip_hope_svd_error': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, f32p, f32p, C.c_int32, C.c_uint64, f64p, f64p]),
+    'gemhip_hope_plan_svd_error': (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int32, C.c_uint64, f64p, f64p]),
     'gemhip_lap_eigmap': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                     C.c_uint64, f32p, f32p, f64p]),
     'gemhip_lle': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,

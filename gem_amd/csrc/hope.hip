@@ -95,43 +95,52 @@ __global__ __launch_bounds__(256) void hope_spmm16_kernel(int64_t n, const int64
     const int64_t i = xcd_contiguous_block(blockIdx.x, gridDim.x) * 16 + (threadIdx.x >> 4);
     if (i >= n) return;
     const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
+    // Round 5: the row's dependent chain is row_ptr -> (column, value) -> gathers -> addends -> store, and at SBM 100k/1M a launch is only ~3 rounds of
+    // resident wavefronts deep, so the chain IS the launch time.  Two links go: (1) the addends of the epilogue (the recurrence's W1 / W2 terms) are
+    // requested here, before the neighbour loop, instead of after it; (2) lane k of the 16-lane group fetches the (column, value) pair of the row's k-th
+    // neighbour -- ONE coalesced request for up to 16 neighbours instead of one round trip per U of them -- and the group reads them back with
+    // ds_bpermute, so that every gather of a row of <= 16 neighbours can be in flight U at a time with nothing but arithmetic between the rounds.
+    // Same products, same order of the additions: bit-identical to the round-4 kernel.
+    float wadd[CPL16], w2v[CPL16];
+#pragma unroll
+    for (int c = 0; c < CPL16; ++c) {
+        const int cc = l16 + c * 16;
+        wadd[c] = (Wadd && cc < b) ? Wadd[i * ldw + cc] : 0.f;
+        w2v[c] = (W2 && cc < b) ? W2[i * ldw2 + cc] : 0.f;
+    }
     float acc[CPL16];
 #pragma unroll
     for (int c = 0; c < CPL16; ++c) acc[c] = 0.f;
-    // the (column, value) pairs of the NEXT U neighbours are requested before the gathers of the current ones: the row's dependent chain
-    // row_ptr -> col/val -> gathers loses one memory round trip per U neighbours (same arithmetic, same order)
-    int32_t cn[U]; float vn[U];
-    auto fetch_edges = [&](int64_t e) {
+    int32_t cl = 0; float vl = 0.f;
+    if (e0 + l16 < e1) { cl = col[e0 + l16]; vl = val[e0 + l16]; }
+    for (int64_t e = e0; e < e1; e += 16) {
+        const int32_t c_cur = cl; const float v_cur = vl;
+        if (e + 16 + l16 < e1) { cl = col[e + 16 + l16]; vl = val[e + 16 + l16]; }          // the next 16 neighbours travel while these are gathered
+        const int cnt = (int)((e1 - e) < 16 ? (e1 - e) : 16);
+        for (int k = 0; k < cnt; k += U) {
+            float xr[U][CPL16], vj[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t ee = (e + u) < e1 ? (e + u) : (e1 - 1);
-            cn[u] = col[ee]; vn[u] = (e + u) < e1 ? val[ee] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const int kk = (k + u) < cnt ? (k + u) : (cnt - 1);
+                const int32_t cj = __shfl(c_cur, kk, 16);
+                const float vv = __shfl(v_cur, kk, 16);
+                vj[u] = (k + u) < cnt ? vv : 0.f;
+                const float *px = X + (int64_t)cj * ldx;
+#pragma unroll
+                for (int c = 0; c < CPL16; ++c) { const int cc = l16 + c * 16; xr[u][c] = cc < b ? px[cc] : 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < CPL16; ++c) acc[c] += vj[u] * xr[u][c];
         }
-    };
-    if (e0 < e1) fetch_edges(e0);
-    for (int64_t e = e0; e < e1; e += U) {
-        int32_t cj[U]; float vj[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { cj[u] = cn[u]; vj[u] = vn[u]; }
-        if (e + U < e1) fetch_edges(e + U);
-        float xr[U][CPL16];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float *px = X + (int64_t)cj[u] * ldx;
-#pragma unroll
-            for (int c = 0; c < CPL16; ++c) { const int cc = l16 + c * 16; xr[u][c] = cc < b ? px[cc] : 0.f; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int c = 0; c < CPL16; ++c) acc[c] += vj[u] * xr[u][c];
     }
 #pragma unroll
     for (int c = 0; c < CPL16; ++c) {
         const int cc = l16 + c * 16;
         if (cc >= b) continue;
-        if (!W2 && wa == 1.0f) Y[i * ldy + cc] = alpha * acc[c] + (Wadd ? Wadd[i * ldw + cc] : 0.f);
-        else Y[i * ldy + cc] = fmaf(alpha, acc[c], fmaf(wa, Wadd ? Wadd[i * ldw + cc] : 0.f, W2 ? wb * W2[i * ldw2 + cc] : 0.f));
+        if (!W2 && wa == 1.0f) Y[i * ldy + cc] = alpha * acc[c] + wadd[c];
+        else Y[i * ldy + cc] = fmaf(alpha, acc[c], fmaf(wa, wadd[c], W2 ? wb * w2v[c] : 0.f));
         // (measured and dropped, round 4: reading W2 -- the oldest term of the three-term recurrence, its last use -- with the non-temporal hint: 12.65 ms per
         // solve either way, profiles/r04_ab_hope_spmm_nt.jsonl; the block and its addends fit the chip's caches)
     }
@@ -1220,7 +1229,10 @@ void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const f
 #define SPMM16(C, U) hipLaunchKernelGGL((hope_spmm16_kernel<C, U>), grid16, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
         // neighbours in flight per row and round.  With the next round's (column, value) pairs prefetched, short rounds win: measured 2 / 4 / 8 / 16 at
         // SBM 100k/1M (about 20 neighbours per row): see the dispatch below; round 2, without the prefetch: 4 / 8 / 16 = 5.5 / 5.2 / 5.8 ms of SpMM per solve
-        static const int uu = getenv("GEMHIP_HOPE_SPMM16_U") ? atoi(getenv("GEMHIP_HOPE_SPMM16_U")) : 4;
+        // gathers in flight per row and round (GEMHIP_HOPE_SPMM16_U overrides): with a row's (column, value) pairs already in the group's registers the
+        // rounds are separated by arithmetic only, and the bound is registers: U x ceil(b / 16) values per lane
+        static const int uenv = getenv("GEMHIP_HOPE_SPMM16_U") ? atoi(getenv("GEMHIP_HOPE_SPMM16_U")) : 0;
+        const int uu = uenv > 0 ? uenv : (c16 <= 3 ? 8 : 4);
 #define SPMM16_BY_U(C) do { if (uu >= 8) SPMM16(C, 8); else if (uu >= 4) SPMM16(C, 4); else SPMM16(C, 2); } while (0)
         if (c16 <= 1) SPMM16_BY_U(1);
         else if (c16 <= 2) SPMM16_BY_U(2);
@@ -2317,49 +2329,71 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
     return rc;
 }
 
-// hope.py:38-40 prints `SVD error (low rank): ||u diag(s) vt - S||_F` from the dense S it formed.  For the exact truncated SVD that norm is
-// sqrt(||S||_F^2 - sum_{i<=k} sigma_i^2), and ||S||_F^2 = trace(S^T S) = E ||S z||^2 over z ~ N(0, I) (Hutchinson): one application of the Katz
-// series to a block of `probes` random columns with the SpMM kernel the solve itself uses.  S = B + B^2 + ... with B = beta A, and ||B||_F^2 =
-// beta^2 sum w^2 is known exactly, so the probes only estimate the remainder: ||S||_F^2 ~ ||B||_F^2 + mean_z (||S z||^2 - ||B z||^2) -- on the
-// reference's graphs (beta x degree << 1) that remainder is a few percent of the total and the estimate is good to ~1e-3 relative with 32 probes.
-extern "C" int gemhip_hope_plan_svd_error(gemhip_hope_plan_t P, int32_t k, const float *sigma, int32_t probes, uint64_t seed, double *err_out, double *frob2_out)
+// hope.py:38-40 prints `SVD error (low rank): ||u diag(s) vt - S||_F` from the dense S it formed.  For the exact truncated SVD that matrix is
+// S (I - V V^T), V = the k right singular vectors, so the number is ||S P||_F with P the projector onto V's complement, and
+// ||S P||_F^2 = E ||S P z||^2 over z ~ N(0, I) (Hutchinson): the Katz series applied to `probes` random columns with the SpMM kernel the solve itself
+// uses.  Two things keep the variance down.  (1) The probes are deflated (z - V V^T z): the dominant singular directions, which carry most of
+// ||S||_F^2 and all of a plain estimate's variance, never enter.  (2) S = B + B^2 + ... with B = beta A, and ||B P||_F^2 = ||B||_F^2 - ||B V||_F^2 is
+// known exactly (beta^2 sum w^2 and one SpMM on V), so the probes only estimate the remainder: err^2 ~ ||B P||_F^2 + mean_z (||S P z||^2 - ||B P z||^2).
+// On the reference's graphs (beta x degree << 1) the result is good to a few 1e-3 relative with 32 probes (tests/test_run_sbm_gpu.py: dense value).
+// sigma / V_sqrtS: what a solve returned (V sqrt(Sigma), n x k row-major, host).  frob2_out (optional): err^2 + sum sigma^2 = ||S||_F^2.
+extern "C" int gemhip_hope_plan_svd_error(gemhip_hope_plan_t P, int32_t k, const float *sigma, const float *V_sqrtS, int32_t probes, uint64_t seed,
+                                          double *err_out, double *frob2_out)
 {
-    GEMHIP_REQUIRE(P != nullptr && sigma != nullptr && err_out != nullptr && k >= 1, "hope_plan_svd_error: bad arguments");
+    GEMHIP_REQUIRE(P != nullptr && sigma != nullptr && V_sqrtS != nullptr && err_out != nullptr && k >= 1 && k <= 512, "hope_plan_svd_error: bad arguments");
     GEMHIP_REQUIRE(probes >= 1 && probes <= 128, "hope_plan_svd_error: probes=%d (1..128)", probes);
     Hope &H = P->H;
     GEMHIP_REQUIRE(H.mode == 0, "hope_plan_svd_error: the plan is not a Katz (HOPE) operator");
     H.err = 0;
     const int64_t n = H.n;
-    const int ld = (probes + 31) / 32 * 32;
-    float *blk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // Z, T0, T1, W0 (= B Z after apply_S), Out (= S Z)
+    const int ld = (probes + 31) / 32 * 32, ldv = (k + 31) / 32 * 32;
+    // unit right singular vectors, padded to the MFMA tile width
+    std::vector<float> Vh((size_t)n * ldv, 0.f);
+    for (int j = 0; j < k; ++j) GEMHIP_REQUIRE(sigma[j] > 0.f, "hope_plan_svd_error: sigma[%d] = %g", j, (double)sigma[j]);
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) Vh[(size_t)i * ldv + j] = V_sqrtS[(size_t)i * k + j] / std::sqrt(sigma[j]);
+    float *dV = nullptr, *dBV = nullptr;
+    float *blk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // Z (deflated in place), T0, T1, W0 (= B Z after apply_S), Out (= S Z)
+    HOPE_TRY(H, hipMalloc((void **)&dV, Vh.size() * sizeof(float)));
+    HOPE_TRY(H, hipMalloc((void **)&dBV, Vh.size() * sizeof(float)));
     for (float *&b : blk) { HOPE_TRY(H, hipMalloc((void **)&b, (size_t)n * ld * sizeof(float))); if (!H.err) HOPE_TRY(H, hipMemsetAsync(b, 0, (size_t)n * ld * sizeof(float), H.s)); }
+    HOPE_TRY(H, hipMemcpyAsync(dV, Vh.data(), Vh.size() * sizeof(float), hipMemcpyHostToDevice, H.s));
+    HOPE_TRY(H, hipMemsetAsync(dBV, 0, Vh.size() * sizeof(float), H.s));
+    std::vector<double> Gbv, C, Gs, Gb;
     if (!H.err) {
+        for (int c0 = 0; c0 < k; c0 += 128) {                                  // B V, at most 128 columns per SpMM launch
+            const int cb = std::min(128, k - c0);
+            spmm(H, false, H.beta, dV + c0, ldv, nullptr, 0, dBV + c0, ldv, cb);
+        }
+        gram(H, dBV, ldv, k, dBV, ldv, k, Gbv);
         hipLaunchKernelGGL(hope_randn_kernel, dim3((unsigned)((n * probes / 4 + 256) / 256)), dim3(256), 0, H.s, blk[0], n, probes, ld, seed ^ 0x5356444572726F72ull);
+        gram(H, dV, ldv, k, blk[0], ld, probes, C);                            // V^T Z  (k x probes)
+        tsgemm(H, dV, ldv, k, C, probes, -1.0f, blk[0], ld, blk[0], ld);       // Z <- Z - V (V^T Z)
         apply_S(H, blk[0], ld, probes, P->terms, blk[1], blk[2], blk[3], ld, blk[4], ld);           // W0 keeps the first term B Z
+        gram(H, blk[4], ld, probes, blk[4], ld, probes, Gs);
+        gram(H, blk[3], ld, probes, blk[3], ld, probes, Gb);
     }
-    std::vector<double> Gs, Gb;
-    gram(H, blk[4], ld, probes, blk[4], ld, probes, Gs);
-    gram(H, blk[3], ld, probes, blk[3], ld, probes, Gb);
+    HOPE_TRY(H, hipStreamSynchronize(H.s));
     for (float *b : blk) hipFree(b);
+    hipFree(dV); hipFree(dBV);
     if (H.err) return H.err;
-    double rem = 0.0;
+    double rem = 0.0, bv2 = 0.0, top = 0.0;
     for (int j = 0; j < probes; ++j) rem += Gs[(size_t)j * probes + j] - Gb[(size_t)j * probes + j];
-    const double frob2 = (double)H.beta * (double)H.beta * P->frob2_A + rem / probes;
-    double top = 0.0;
-    for (int i = 0; i < k; ++i) top += (double)sigma[i] * (double)sigma[i];
-    *err_out = std::sqrt(std::max(0.0, frob2 - top));
-    if (frob2_out) *frob2_out = frob2;
+    for (int j = 0; j < k; ++j) { bv2 += Gbv[(size_t)j * k + j]; top += (double)sigma[j] * (double)sigma[j]; }
+    const double err2 = std::max(0.0, (double)H.beta * (double)H.beta * P->frob2_A - bv2 + rem / probes);
+    *err_out = std::sqrt(err2);
+    if (frob2_out) *frob2_out = err2 + top;
     return GEMHIP_OK;
 }
 
 // One-shot form for the plugin's verbose mode (hope.py:38-40): the plan is rebuilt (transpose + uploads), which costs about as much as the estimate itself.
 extern "C" int gemhip_hope_svd_error(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
-                                     const float *sigma, int32_t probes, uint64_t seed, double *err_out, double *frob2_out)
+                                     const float *sigma, const float *V_sqrtS, int32_t probes, uint64_t seed, double *err_out, double *frob2_out)
 {
     gemhip_hope_plan_t P = nullptr;
     int rc = gemhip_hope_plan_create(n, nnz, row_ptr, col, w, beta, &P);
     if (rc) return rc;
-    rc = gemhip_hope_plan_svd_error(P, k, sigma, probes, seed, err_out, frob2_out);
+    rc = gemhip_hope_plan_svd_error(P, k, sigma, V_sqrtS, probes, seed, err_out, frob2_out);
     gemhip_hope_plan_destroy(P);
     return rc;
 }

@@ -49,21 +49,23 @@ struct VocabStats {
     double n = 0.0, total = 0.0, max = 0.0, active = 0.0;     // table rows, tokens, largest count, nodes that occur at all
     double z = 0.0;                    // sum of count^0.75
     double n_eff = 0.0;                // 1 / sum_v q_v^2, q = unigram^0.75 distribution: the table size a uniform graph with the same collision rate would have
+    double touch2 = 0.0;               // sum_v (p_v + 5 q_v)^2, p = token share: collision rate of the rows a (centre, context) pair TOUCHES (its context row + five negatives)
     mutable std::vector<int32_t> cnt_desc;     // token counts, descending (after sort_once), and ...
     mutable std::vector<double> u2_prefix;     // ... u2_prefix[i] = sum of (count^0.75)^2 over the i largest counts
     void build(const int32_t *cnt, int64_t len)
     {
-        double tot = 0.0, mx = 0.0, zz = 0.0, z2 = 0.0;
+        double tot = 0.0, mx = 0.0, zz = 0.0, z2 = 0.0, c2 = 0.0, cu = 0.0;
         n = (double)len; active = 0.0;
         for (int64_t i = 0; i < len; ++i) {
             const int32_t c = cnt[i];
             if (c <= 0) continue;
             tot += c; mx = std::max(mx, (double)c); active += 1.0;
             const double u = std::pow((double)c, 0.75);
-            zz += u; z2 += u * u;
+            zz += u; z2 += u * u; c2 += (double)c * c; cu += (double)c * u;
         }
         total = tot; max = mx; z = zz;
         n_eff = z2 > 0.0 ? zz * zz / z2 : n;
+        touch2 = (tot > 0.0 && zz > 0.0) ? c2 / (tot * tot) + 10.0 * cu / (tot * zz) + 25.0 * z2 / (zz * zz) : 0.0;
         cnt_desc.assign(cnt, cnt + len);                     // sorted (and the prefix sums formed) only if the rule has to look at the cold rows
         u2_prefix.clear();
     }
@@ -99,6 +101,7 @@ struct SgnsKnobs {
     int32_t window_span = 0;          // positions of a walk whose context rows a wavefront holds at once: 0 = 2R+1 (the sliding window); the whole walk in the bucket kernel's whole-walk mode
     bool part = false;                // a bucket launch of the partitioned schedule (sgns_win_kernel<PART>: as-loaded window copies in global scratch, 3 wavefronts per SIMD)
     double duty = 1.0;                // fraction of a wavefront's time spent in pair steps (negative rows open); < 1 only for the buckets of the partitioned schedule
+    double touch_scale = 1.0;         // factor on VocabStats::touch2 (bucket launches: the pairs of ONE bucket touch the rows of two partitions only: parts x duty)
 };
 // ... and what a launch of TrainModel over `nwalks` walks then looks like (pure host arithmetic: gemhip_sgns_plan_launch exposes it to the CPU tests)
 struct SgnsLaunchPlan {
@@ -961,6 +964,17 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         // gradients cost nothing up to there -- CPU replay at 0.4 %, SBM 100k at 0.8 %, R-MAT scale 17 at 2.0 % of the active rows; R-MAT scale 13 with
         // 26 % of its 5 936 active rows open ended 21 % ABOVE the sequential algorithm's MAP: its hubs under-trained)
         const int64_t w_act = std::max<int64_t>(1, (int64_t)((vs.active > 0.0 ? vs.active : (double)n) / 50.0));
+        // ... and never more than keeps CONCURRENT TOUCHES OF THE SAME ROW rare (round 5).  A pair touches six rows besides the centre's: its context
+        // (a node drawn by token share p) and five negatives (drawn by q = unigram^0.75).  Hot rows take those touches as atomic adds of a gradient that
+        // was computed from a copy one to two pair steps old -- nothing is lost, but with c other wavefronts touching the same row inside that window
+        // the row moves (1 + c) x as far as TrainModel would move it.  For a random touch c = (W - 1) x s x sum_v (p_v + 5 q_v)^2 / 6 (s ~ 2 pair steps).
+        // Measured on R-MAT scale 17 against the sequential oracle, paired over 16 384 nodes that have a ranked neighbour (s.e. 0.3 %; three launches per
+        // width and layout, profiles/r05_rmat17_width_sweep.jsonl): c = 0.16 / 0.25 / 0.33 / 0.5 / 0.66 / 1.0 (128 / 192 / 256 / 384 / 512 / 768
+        // wavefronts) -> -0.1 / -0.5 / -0.9 / -2.3 / -4.2 / -6.3 % of the MAP in the binary's table layout (node-id layout: -0.2 / -0.2 / +0.2 / +0.4 /
+        // -1.7 / -2.4 %), while rho over the cold rows stayed under 1.5 % throughout: round 3's rule (602 wavefronts there) measured -3.7 %, and its
+        // 2 048-node uniform sample, two thirds of it nodes without a ranked neighbour, could not see it.  Bound: c <= 0.2, i.e. (W - 1) x touch2 <= 0.6.
+        // SBM graphs are far from it (touch2 = 38 / n: 15 800 wavefronts at 1M nodes); R-MAT scale 17: 155, scale 22: 1 866 (the device holds 1 536).
+        const int64_t w_touch = vs.touch2 > 0.0 ? std::max<int64_t>(1, 1 + (int64_t)(0.6 / (vs.touch2 * kn.touch_scale))) : INT64_MAX;
         auto width = [&](bool all_cached) -> int64_t {
             // registers: the single-GPU kernels allocate 176-184 VGPRs (2 wavefronts per SIMD = 8 per CU), the bucket kernels 136-145 (3 per SIMD = 12 per CU)
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(kn.part ? 12 : 8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta, all_cached) + 512)));
@@ -970,13 +984,13 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
             int64_t hog_rho = std::max<int64_t>(1, (int64_t)(0.015 * n_eff / (5.0 * w_steps * kn.duty)));
             // hot rows: with W wavefronts the nodes with count >= tokens / ((W-1)(2R+1)) stay out of the LDS windows and take their negative updates
             // by atomic add (sgns_win_kernel), so the rule only has to hold over the remaining (cold) rows: the largest W that satisfies it
-            if (reload_eff && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(w_dev, w_act) && vs.total > 0.0) {
-                for (int64_t wtry = std::min(w_dev, w_act); wtry > hog_rho; wtry = wtry * 7 / 8) {
+            if (reload_eff && kn.hot_count < 0 && n >= 8192 && hog_rho < std::min(std::min(w_dev, w_act), w_touch) && vs.total > 0.0) {
+                for (int64_t wtry = std::min(std::min(w_dev, w_act), w_touch); wtry > hog_rho; wtry = wtry * 7 / 8) {
                     const double thr = std::max(2.0, std::ceil(vs.total / ((double)(wtry - 1) * span)));
                     if (0.015 * vs.n_eff_cold(thr) / (5.0 * w_steps * kn.duty) >= (double)wtry) { hog_rho = wtry; break; }
                 }
             }
-            const int64_t hog_win = kn.max_waves > 0 ? kn.max_waves : n >= 8192 ? hog_rho : std::min(hog_rho, hog_tiny);
+            const int64_t hog_win = kn.max_waves > 0 ? kn.max_waves : n >= 8192 ? std::min(hog_rho, w_touch) : std::min(hog_rho, hog_tiny);
             return std::min<int64_t>(hog_win, w_dev);
         };
         // the launch without the staging row holds one more wavefront per CU at d = 128 -- but only exists when no row is hot AT THAT WIDTH
@@ -1136,7 +1150,7 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     // distribution bounds the Hogwild width: rho = W x 5 x 0.4 / n_eff <= 1.5 %); hot rows are judged on the GLOBAL token counts (a hub sits in
     // W x (2R+1) x count / tokens windows whatever partition it belongs to)
     VocabStats vs = h->vs_part[word_part];
-    vs.total = h->vs.total; vs.max = h->vs.max;
+    vs.total = h->vs.total; vs.max = h->vs.max; vs.touch2 = h->vs.touch2;
     SgnsKnobs kn = h->kn;
     kn.prefetch = 2; kn.reload = 1; kn.part = true;
     // Duty cycle.  The rule bounds the negative rows that are OPEN at any time (W x 5 x w of them).  A wavefront of a bucket launch spends only part of
@@ -1146,6 +1160,10 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     if (h->parts > 1) {
         const double pairs_pp = (double)walk_len * (window + 1) * 0.95 / ((double)h->parts * h->parts), rows_pp = 2.0 * walk_len / h->parts;
         kn.duty = pairs_pp / (pairs_pp + 0.7 * rows_pp);
+        // the pairs a bucket launch trains all have their context in ONE partition and their negatives in ONE partition: a row of those partitions is touched
+        // `parts` times as often per trained pair as in the whole corpus (sum over the partition's rows of (parts x load)^2 = parts x touch2), in the
+        // fraction `duty` of the time
+        kn.touch_scale = (double)h->parts * kn.duty;
         // from ~4 partitions on a walk's contexts of one partition fit the window's slots and stay cached for the WHOLE walk (sgns_win_kernel<PART>,
         // whole-walk mode): a node then sits in W x walk_len x count / tokens windows, which is what decides whether it is hot
         if (walk_len / h->parts <= 2 * std::min(window, 10) + 1) kn.window_span = walk_len;

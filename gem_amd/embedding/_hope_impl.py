@@ -39,11 +39,11 @@ def learn(model, graph):
     _hip.warn_if_unconverged(model._stats, float(getattr(model, '_tol', 1e-5)), int(getattr(model, '_max_restarts', 20)), 'HOPE')
     model._node_num = n
     if getattr(model, '_verbose', False):
-        # hope.py:38-40 prints ||u diag(s) vt - S||_F of the dense S it formed; here sqrt(||S||_F^2 - sum sigma^2) with ||S||_F^2 from 32 probe columns
+        # hope.py:38-40 prints ||u diag(s) vt - S||_F of the dense S it formed; here ||S (I - V V^T)||_F from 32 deflated probe columns
         # pushed through the Katz series (gemhip_hope_svd_error) -- opt-in (HOPE(..., verbose=True)): it rebuilds the plan outside the timed solve
         err = C.c_double(); fro2 = C.c_double()
         _hip.check(_hip.lib().gemhip_hope_svd_error(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), _hip.ptr(ww, C.c_float),
-                                                    float(model._beta), k, _hip.ptr(sig, C.c_float), 32, int(getattr(model, '_seed', 20260923)),
+                                                    float(model._beta), k, _hip.ptr(sig, C.c_float), _hip.ptr(V, C.c_float), 32, int(getattr(model, '_seed', 20260923)),
                                                     C.byref(err), C.byref(fro2)))
         model._svd_error = err.value
         print('SVD error (low rank): %f' % err.value)

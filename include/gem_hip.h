@@ -347,13 +347,14 @@ int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *c
                 float beta, int32_t k, int32_t oversample, int32_t krylov_steps,
                 int32_t max_restarts, float tol, uint64_t seed, float *U_sqrtS, float *V_sqrtS,
                 float *sigma, double *stats);
-/* hope.py:38-40 `print('SVD error (low rank): %f' % norm(u diag(s) vt - S))`: for the truncated SVD that norm is sqrt(||S||_F^2 - sum sigma_i^2);
- * ||S||_F^2 is estimated with `probes` (1..128; 32 is plenty) Gaussian probe columns pushed through the Katz series by the solver's own SpMM
- * kernel, with the exactly known ||beta A||_F^2 as a control variate.  sigma: the k singular values a solve returned.  frob2_out (optional):
- * the estimate of ||S||_F^2. */
-int gemhip_hope_plan_svd_error(gemhip_hope_plan_t plan, int32_t k, const float *sigma, int32_t probes, uint64_t seed, double *err_out, double *frob2_out);
+/* hope.py:38-40 `print('SVD error (low rank): %f' % norm(u diag(s) vt - S))`: for the truncated SVD that matrix is S (I - V V^T), and its
+ * squared Frobenius norm is estimated with `probes` (1..128; 32 is plenty) Gaussian probe columns, deflated by V, pushed through the Katz series by
+ * the solver's own SpMM kernel, with the exactly known ||beta A (I - V V^T)||_F^2 as a control variate.  sigma / V_sqrtS: the k singular values and
+ * the n x k block V sqrt(Sigma) a solve returned (host).  frob2_out (optional): err^2 + sum sigma^2, the estimate of ||S||_F^2. */
+int gemhip_hope_plan_svd_error(gemhip_hope_plan_t plan, int32_t k, const float *sigma, const float *V_sqrtS, int32_t probes, uint64_t seed,
+                               double *err_out, double *frob2_out);
 int gemhip_hope_svd_error(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
-                          const float *sigma, int32_t probes, uint64_t seed, double *err_out, double *frob2_out);
+                          const float *sigma, const float *V_sqrtS, int32_t probes, uint64_t seed, double *err_out, double *frob2_out);
 
 /* ------------------------------------------------ Laplacian Eigenmaps ("next")
  * Replaces gem/embedding/lap.py:21-37: eigs(nx.normalized_laplacian_matrix(graph.to_undirected()), k=d+1, which='SM').

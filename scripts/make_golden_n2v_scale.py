@@ -34,6 +34,9 @@ ap.add_argument('--workdir', default=None)
 ap.add_argument('--rmat-scale', type=int, default=0, help='R-MAT graph (gem_amd.graph.rmat_graph(scale, edges, seed)) instead of the SBM')
 ap.add_argument('--save-emb', default=None, help='write the trained embedding (float32 .npy) here so a later run can re-score a bigger sample')
 ap.add_argument('--load-emb', default=None, help='skip training, score this saved embedding')
+ap.add_argument('--eligible-sample', type=int, default=0, help='score this many nodes drawn (RandomState(1), sorted) from the nodes that HAVE a neighbour j > i '
+                'instead of --sample uniform nodes: the evaluator only ranks candidates j > i, so on a power-law graph two thirds of a uniform sample score 0 by '
+                'construction and the MAP of the rest hangs on a few nodes (gem_amd.evaluation.reconstruction.eligible_sample)')
 ap.add_argument('--flags', type=int, default=11, help='oracle engine: 11 = SNAP quirks, unigram table in node-id layout (rounds 2-3); 27 = + the binary\'s table layout (first-appearance order)')
 a = ap.parse_args()
 PARAMS = dict(n=a.nodes, edges=a.edges, blocks=a.blocks, seed=a.seed, d=128, walk_len=80, num_walks=10, window=10, p=a.p, q=a.q)
@@ -45,7 +48,10 @@ if a.rmat_scale:
 else:
     g = sbm_graph(a.nodes, a.edges, a.blocks, a.seed)
 n = g.n
-nodes = np.random.RandomState(0).choice(n, size=min(a.sample, n), replace=False)
+if a.eligible_sample:
+    nodes = gr.eligible_sample(g, a.eligible_sample)
+else:
+    nodes = np.random.RandomState(0).choice(n, size=min(a.sample, n), replace=False)
 tmp = a.workdir or tempfile.mkdtemp(prefix='n2vgold_')
 os.makedirs(tmp, exist_ok=True)
 print('graph %d nodes %d directed edges, workdir %s' % (n, g.number_of_edges(), tmp), flush=True)
@@ -55,6 +61,7 @@ if a.load_emb:
     X = np.load(a.load_emb)
     prev = json.load(open(a.load_emb + '.json'))
     el, engine = prev['seconds'], prev['engine']
+    PARAMS.update(prev['params'])                      # (flags and the graph of the run that made the embedding)
 elif a.engine == 'snap':
     gf = os.path.join(tmp, 'g.graph')
     import pandas as pd
@@ -86,25 +93,14 @@ if a.save_emb and not a.load_emb:
     np.save(a.save_emb, X)
     json.dump({'seconds': el, 'engine': engine, 'params': PARAMS}, open(a.save_emb + '.json', 'w'))
 
-Xd = X.astype(np.float64)
-aps = []
+sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+import score_oracle_ap                                   # batched fp64 scoring, exact tie rule (== reconstruction.average_precision_rows, tests/test_evaluation.py)
 order = np.argsort(g.src, kind='stable')
-s_sorted, d_sorted = g.src[order], g.dst[order]
-starts = np.searchsorted(s_sorted, np.arange(n + 1))
-for i in nodes:
-    s = Xd @ Xd[i]
-    tr = np.zeros(n, dtype=bool); tr[d_sorted[starts[i]:starts[i + 1]]] = True
-    s, tr = s[i + 1:], tr[i + 1:]
-    pos = s > 0
-    s, tr = s[pos], tr[pos]
-    if s.size == 0 or tr.sum() == 0:
-        aps.append(0.0); continue
-    hit = tr[np.argsort(-s, kind='stable')]
-    prec = np.cumsum(hit) / np.arange(1, hit.size + 1)
-    aps.append(float(prec[hit].sum() / hit.sum()))
+aps = score_oracle_ap.ap_of_nodes(X, g.dst[order].astype(np.int64), np.searchsorted(g.src[order], np.arange(n + 1)), np.asarray(nodes, dtype=np.int64))
 aps = np.asarray(aps)
 out = {'params': PARAMS, 'engine': engine, 'seconds': el, 'edges_per_s': g.number_of_edges() / el,
-       'sample': 'np.random.RandomState(0).choice(n, %d, replace=False)' % len(nodes),
+       'sample': ('gem_amd.evaluation.reconstruction.eligible_sample(g, %d)' % len(nodes)) if a.eligible_sample else
+                 ('np.random.RandomState(0).choice(n, %d, replace=False)' % len(nodes)),
        'MAP': float(aps.mean()), 'MAP_se': float(aps.std(ddof=1) / np.sqrt(len(aps))), 'ap': [round(float(v), 6) for v in aps]}
 tag = a.tag or ('%s_%dk' % (a.engine, n // 1000))
 path = os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_%s.json' % tag)

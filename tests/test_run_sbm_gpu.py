@@ -68,3 +68,43 @@ def test_node2vec_run_sbm_setting_d182(sbm1024):
     Xs, _ = oracle.n2v_train(n, src, dst, w, 182, 80, 10, 10, 1, 1.0, 1.0, 5, SNAP)
     MAPs = gr.evaluateStaticGraphReconstruction(sbm1024, m, Xs.astype(np.float64), None)[0]
     assert abs(MAP - MAPs) <= 0.08 * MAPs, (MAP, MAPs)
+
+
+def test_verbose_prints_what_the_reference_prints(sbm1024, karate, capsys):
+    """hope.py:38-40 prints `SVD error (low rank): ||u diag(s) vt - S||_F` of its dense S; gf.cpp:144-151 (run with its verbose flag by gf.py:62) prints the
+    iteration id and `Objective: f1+f2, f1: .., f2:..` before every print_step-th sweep.  verbose=True brings both back: HOPE's from a 32-probe Hutchinson
+    estimate of ||S||_F^2 through the solver's own SpMM kernel (vs the dense value: well inside 1 %), GF's from gemhip_gf_objective (vs the oracle's
+    f1 / f2 at the same sweeps)."""
+    for G, d in ((sbm1024, 64), (karate, 4)):
+        n, src, dst, w, order = edge_arrays(G)
+        m = HOPE(d=d, beta=0.01, verbose=True)
+        Y = m.learn_embedding(graph=G, is_weighted=True, no_python=True)
+        out = capsys.readouterr().out
+        assert out.startswith('SVD error (low rank): ')
+        got = float(out.split(':')[1])
+        A = hope_oracle.adjacency(n, src, dst, w, order).toarray()
+        S = np.linalg.inv(np.eye(n) - 0.01 * A) @ (0.01 * A)
+        u, s, vt = np.linalg.svd(S)
+        k = d // 2
+        want = float(np.linalg.norm((u[:, :k] * s[:k]) @ vt[:k] - S))
+        assert abs(got - want) <= 0.01 * want, (got, want)
+        assert abs(m._svd_error - got) < 1e-5 and 'verbose' not in HOPE.hyper_params
+    # the default stays silent
+    HOPE(d=4, beta=0.01).learn_embedding(graph=karate)
+    assert capsys.readouterr().out == ''
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    np.random.seed(5)
+    m = GraphFactorization(d=32, max_iter=25, eta=0.02, regu=0.01, print_step=10, verbose=True)
+    Y = m.learn_embedding(graph=sbm1024, is_weighted=True, no_python=True)
+    GraphFactorization.hyper_params['print_step'] = 10000
+    lines = capsys.readouterr().out.splitlines()
+    assert [l for l in lines if l.startswith('\tIter id: ')] == ['\tIter id: 0', '\tIter id: 10', '\tIter id: 20']
+    np.random.seed(5)
+    X0 = (0.01 * np.random.randn(n, 32)).astype(np.float32)
+    for (it, f1, f2), line in zip(m._objective_log, [l for l in lines if l.startswith('\t\tObjective: ')]):
+        Xo = oracle.gf_train_f32(n, src, dst, w, 32, 0.02, 0.01, it, X0) if it else X0
+        o1, o2 = oracle.gf_objective(n, src, dst, w, 32, Xo)
+        assert f1 == pytest.approx(o1, rel=1e-4) and f2 == pytest.approx(o2, rel=1e-4)
+        assert line == '\t\tObjective: %g, f1: %g, f2:%g' % (f1 + f2, f1, f2)
+    assert len(m._objective_log) == 3 and m._objective_log[2][1] < m._objective_log[0][1]           # the fit improves
+    assert float(np.abs(Y - oracle.gf_train_f32(n, src, dst, w, 32, 0.02, 0.01, 25, X0)).max()) <= 2e-5 * float(np.abs(Y).max()) + 1e-7
