@@ -807,7 +807,7 @@ def compact_line(full, detail_path=None):
     Everything else (notes, sources, API walls, launch plans, the full per-workload objects) goes to the detail record (stderr + file)."""
     line = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
                                  'dtype', 'data') if k in full}
-    line['config'] = _pick(full.get('config'), ('workload', 'nodes', 'directed_edges', 'd', 'sharding', 'driver'))
+    line['config'] = _pick(full.get('config'), ('workload', 'nodes', 'directed_edges', 'd', 'sharding', 'driver', 'world_size_seen'))
 
     def roof(r):
         if r is None:

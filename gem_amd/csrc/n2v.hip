@@ -52,6 +52,7 @@ struct VocabStats {
     double touch2 = 0.0;               // sum_v (p_v + 5 q_v)^2, p = token share: collision rate of the rows a (centre, context) pair TOUCHES (its context row + five negatives)
     mutable std::vector<int32_t> cnt_desc;     // token counts, descending (after sort_once), and ...
     mutable std::vector<double> u2_prefix;     // ... u2_prefix[i] = sum of (count^0.75)^2 over the i largest counts
+    mutable std::vector<double> c_prefix, u_prefix;   // ... sums of count and of count^0.75 over the i largest counts
     void build(const int32_t *cnt, int64_t len)
     {
         double tot = 0.0, mx = 0.0, zz = 0.0, z2 = 0.0, c2 = 0.0, cu = 0.0;
@@ -74,10 +75,21 @@ struct VocabStats {
         if (!u2_prefix.empty()) return;
         std::sort(cnt_desc.begin(), cnt_desc.end(), std::greater<int32_t>());
         u2_prefix.assign(cnt_desc.size() + 1, 0.0);
+        c_prefix.assign(cnt_desc.size() + 1, 0.0); u_prefix.assign(cnt_desc.size() + 1, 0.0);
         for (size_t i = 0; i < cnt_desc.size(); ++i) {
             const double u = cnt_desc[i] > 0 ? std::pow((double)cnt_desc[i], 0.75) : 0.0;
             u2_prefix[i + 1] = u2_prefix[i] + u * u;
+            c_prefix[i + 1] = c_prefix[i] + (cnt_desc[i] > 0 ? (double)cnt_desc[i] : 0.0);
+            u_prefix[i + 1] = u_prefix[i] + u;
         }
+    }
+    // hot row-operations per trained (centre, context) pair when the rows with count >= thr are hot: P(the context is hot) + 5 x P(a negative is hot)
+    double hot_ops_per_pair(double thr) const
+    {
+        if (cnt_desc.empty() || z <= 0.0 || total <= 0.0) return 0.0;
+        sort_once();
+        const size_t nhot = (size_t)(std::lower_bound(cnt_desc.begin(), cnt_desc.end(), thr, [](int32_t c, double t) { return (double)c >= t; }) - cnt_desc.begin());
+        return c_prefix[nhot] / total + 5.0 * u_prefix[nhot] / z;
     }
     // effective table size of the negative-sampling distribution over the rows that are NOT hot (count < thr): hot rows take atomic adds and lose nothing
     double n_eff_cold(double thr) const
@@ -991,7 +1003,28 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
                 }
             }
             const int64_t hog_win = kn.max_waves > 0 ? kn.max_waves : n >= 8192 ? std::min(hog_rho, w_touch) : std::min(hog_rho, hog_tiny);
-            return std::min<int64_t>(hog_win, w_dev);
+            int64_t w = std::min<int64_t>(hog_win, w_dev);
+            // Speed only (round 5): hot rows are updated by atomic adds at the memory side, and the device sustains ~255 M of those row operations per
+            // second however many wavefronts issue them -- R-MAT scale 22: 0.51 hot operations per pair x 502 M pairs/s at the fastest width, R-MAT scale
+            // 17: 1.32 x 195 M (profiles/r05_rmat22_width_sweep.jsonl, r05_rmat17_width_sweep.jsonl).  Beyond the width that saturates them more
+            // wavefronts only queue up behind the same rows (scale 22: 33.0 s at 768 wavefronts, 34.3 at 1024, 36.7 at 1536) and touch them more often
+            // at once.  Model: rate(W) = min(W / 1.2 us  [a wavefront's pair step],  255 M / hot operations per pair at W's hot threshold,  850 M
+            // [the cold-row rate of the SBM headline]); the narrowest W within 3 % of the best rate wins.  Widths only ever shrink here.
+            if (kn.max_waves == 0 && !kn.part && reload_eff && kn.hot_count < 0 && n >= 8192 && w > 64 && vs.total > 0.0) {
+                auto rate = [&](int64_t ww) {
+                    const double thr = std::max(2.0, std::ceil(vs.total / ((double)(ww - 1) * span)));
+                    const double hops = vs.max >= thr ? vs.hot_ops_per_pair(thr) : 0.0;
+                    return std::min(std::min((double)ww / 1.2e-6, hops > 0.0 ? 255e6 / hops : 1e300), 850e6);
+                };
+                if (vs.max >= std::max(2.0, std::ceil(vs.total / ((double)(w - 1) * span)))) {        // (only when some row is hot at the rule's width)
+                    double best = 0.0;
+                    for (int64_t ww = w; ww >= std::max<int64_t>(64, w / 4); ww = ww * 15 / 16) best = std::max(best, rate(ww));
+                    int64_t pick = w;
+                    for (int64_t ww = w; ww >= std::max<int64_t>(64, w / 4); ww = ww * 15 / 16) if (rate(ww) >= 0.97 * best) pick = ww;
+                    w = pick;
+                }
+            }
+            return w;
         };
         // the launch without the staging row holds one more wavefront per CU at d = 128 -- but only exists when no row is hot AT THAT WIDTH
         P.waves = width(allc);
