@@ -337,7 +337,9 @@ class N2VWorkload(object):
         algo = (14 * 4 * self.args.d + 24) * pairs / launches       # 14*4d B per (centre,context) pair + ids
         ach = algo / avg_s / 1e9
         tokens = (self.job.hi - self.job.lo) * self.args.walk_len
-        per_pair, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_pair')
+        per_pair, tsrc = pmc_traffic(self.kernel + '_rmat', 'traffic_bytes_per_pair') if self.args.graph == 'rmat' else (None, None)     # (counters taken on R-MAT scale 22)
+        if per_pair is None:
+            per_pair, tsrc = pmc_traffic(self.kernel, 'traffic_bytes_per_pair')
         traffic = None if per_pair is None else per_pair * pairs / launches
         return {'bound': 'hbm', 'kernel': self.kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                 'launch_plan': self.launch_plan(),
@@ -516,6 +518,24 @@ class N2VWorkload(object):
                     d = ap[:m] - np.asarray(ref['ap'])
                     out['map_minus_' + key] = float(d.mean())
                     out['map_minus_' + key + '_se'] = float(d.std(ddof=1) / np.sqrt(len(d)))
+        if a.graph == 'rmat' and self.world == 1:
+            # power-law family (BASELINE configs[4]): the sequential oracle's run on the same R-MAT graph, scored over the nodes that have a ranked neighbour
+            # (reconstruction.eligible_sample: a uniform sample is two thirds dead weight there, tests/test_rmat_gpu.py) -- committed for scale 17 and 20;
+            # the reference binary itself cannot run these graphs (its per-pair alias tables are Sigma deg^2)
+            scale = int(np.ceil(np.log2(a.nodes)))
+            gpath = os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_oracle_rmat%d%s_e16k.json' % (scale, '_vocab_order' if vo else ''))
+            if os.path.exists(gpath):
+                ref = json.load(open(gpath))
+                pr = ref['params']
+                if (pr['rmat_scale'], pr['edges'], pr['seed'], pr['d'], pr['walk_len'], pr['num_walks'], pr['window']) == \
+                        (scale, a.edges, 20260923 + 5, a.d, a.walk_len, a.num_walks, a.window):
+                    en = gr.eligible_sample(self.g, len(ref['ap']))
+                    ape = gr.sampled_ap_gpu(self.g, None, self.P.cpu().numpy(), en)
+                    dd = ape - np.asarray(ref['ap'])
+                    out.update({'oracle_map': ref['MAP'], 'oracle_map_se': ref['MAP_se'], 'eligible_map': float(ape.mean()), 'eligible_nodes_sampled': int(len(en)),
+                                'map_minus_oracle_map': float(dd.mean()), 'map_minus_oracle_map_se': float(dd.std(ddof=1) / np.sqrt(len(dd))),
+                                'oracle_map_source': 'tests/golden/%s: %s, same graph and seed, paired over %d nodes that have a ranked neighbour' %
+                                                     (os.path.basename(gpath), ref['engine'], len(en))})
         if out['reference_map'] is None:
             out['reference_map_note'] = ('no committed reference run for this graph size; the largest one is tests/golden/n2v_ref_snap_100k.json '
                                          '(python bench.py --nodes 100000 --edges 1000000 --blocks 10 reports against it)')
@@ -991,6 +1011,12 @@ def main():
         # No CPU baseline: SNAP's per-(t, v) alias tables are Sigma deg^2 on a graph with 94k-degree hubs -- the reference runs out of host
         # memory there -- and gf.cpp's rate does not depend on the graph (c_port of the workloads above).
         if time.time() - T_START < float(os.environ.get('GEM_BENCH_RMAT_DEADLINE_S', '900')):
+            # the same family at scale 20 (1M nodes / 15.4M edges): the largest power-law graph the sequential oracle has been run on (tests/golden/
+            # n2v_ref_oracle_rmat20*_e16k.json) -- the parity point of this family; scale 22 below is its timing point
+            a8 = copy.copy(args); a8.graph, a8.nodes, a8.edges = 'rmat', 1 << 20, 16000000
+            extra['node2vec_rmat20'], w8 = time_workload('node2vec', a8, rank, world, comm, 1, 0, with_cpu=False)
+            del w8
+            torch.cuda.empty_cache()
             a6 = copy.copy(args); a6.graph, a6.nodes, a6.edges = 'rmat', 1 << 22, 64000000
             extra['node2vec_rmat22'], w6 = time_workload('node2vec', a6, rank, world, comm, 1, 0, with_cpu=False)
             del w6
@@ -998,7 +1024,7 @@ def main():
             a7 = copy.copy(a6)
             extra['gf_rmat22'], w7 = time_workload('gf', a7, rank, world, comm, 20, 2, with_cpu=False)
             del w7
-            for k in ('node2vec_rmat22', 'gf_rmat22'):
+            for k in ('node2vec_rmat20', 'node2vec_rmat22', 'gf_rmat22'):
                 extra[k]['cpu_baseline'] = {'value': None, 'kind': 'reference', 'note': 'not run: gem/c_exe/node2vec builds Sigma deg^2 second-order alias '
                                             'tables (max degree ~94k here) and exhausts host memory; gf.cpp per-edge rate: see gf_sbm1m_10m.cpu_baseline'}
         else:

@@ -49,6 +49,7 @@ _SIGS = {
     'gemhip_gf_plan_init_embedding': (C.c_int, [C.c_void_p, C.c_uint64, C.c_float]),
     'gemhip_gf_plan_sweeps': (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     'gemhip_gf_plan_set_rows_per_wave': (C.c_int, [C.c_void_p, C.c_int32]),
+    'gemhip_gf_plan_set_fused_sweeps': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_gf_plan_get_embedding': (C.c_int, [C.c_void_p, f32p]),
     'gemhip_gf_plan_current': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'gemhip_gf_plan_info': (C.c_int, [C.c_void_p, i64p]),

@@ -25,6 +25,7 @@
 // HBM traffic per sweep (algorithmic, d=128): 512 B read + 512 B write per active
 // row, 512 B gather + 8 B (col,w) per update.
 #include "common.hpp"
+#include <hip/hip_cooperative_groups.h>
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
@@ -47,6 +48,10 @@ struct gemhip_gf_plan {
     bool own_X = false;
     int cur = 0;                      // X[cur] holds the latest table
     int rows_per_wave = 0;            // 0 = auto (gf_rows_per_wave), else forced (gemhip_gf_plan_set_rows_per_wave: tests, A/B)
+    // sweeps per cooperative launch (gf_sweeps_coop_kernel): 0 = off (one launch per sweep and level), k > 1 = up to k sweeps per launch on single-level
+    // plans without hub rows; fused_grid caps the resident grid (0 = all the occupancy allows).  GEMHIP_GF_FUSED_SWEEPS / _GRID, gemhip_gf_plan_set_fused_sweeps
+    int fused_sweeps = getenv("GEMHIP_GF_FUSED_SWEEPS") ? atoi(getenv("GEMHIP_GF_FUSED_SWEEPS")) : 0;
+    int fused_grid = getenv("GEMHIP_GF_FUSED_GRID") ? atoi(getenv("GEMHIP_GF_FUSED_GRID")) : 0;
     // Non-temporal hints of the sweep kernels (GEMHIP_GF_NT_STORE, read per plan; -1 = auto).  bit 1 (value 2): the load of a wave's OWN row -- with rows
     // visited in ascending order it is the row's last use of the sweep (only lower rows gather it, and they ran before), and at SBM 1M/10M an XCD's 4 MB
     // of L2 cannot even hold the 5 MB neighbour set the gathers hit in: marking the own-row stream evict-first took a sweep from 548 to 515 us
@@ -192,6 +197,63 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweep_kernel(const int32_t *__res
         else gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
     }
     store_row<VEC, NV>(Xnew + (int64_t)i * d, d, lane, xi, nt);
+}
+
+// Several sweeps in ONE launch (round 5; experiment behind gemhip_gf_plan_set_fused_sweeps / GEMHIP_GF_FUSED_SWEEPS).  At SBM 10k/100k (BASELINE configs[1])
+// a sweep is a ~5 us kernel and 1000 of them cost 9 us each: the loop is launch-bound.  This kernel keeps the grid resident (cooperative launch: every
+// workgroup co-resident by construction) and separates the sweeps with cooperative_groups' grid barrier, which carries the agent-scope release / acquire
+// that makes the rows one XCD wrote visible to the other seven (L2 write-back + invalidate: what a kernel boundary does).  Same row body as
+// gf_sweep_kernel, same edge order: bit-identical tables.  Single-level plans without hub rows only (every benchmark graph).
+template <int VEC, int NV>
+__global__ __launch_bounds__(GF_BLOCK) void gf_sweeps_coop_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
+                                                                  const uint32_t *__restrict__ col, const float *__restrict__ w, float *X0, float *X1,
+                                                                  int64_t nrows, int d, float eta, float regu, int nsweeps)
+{
+    cooperative_groups::grid_group grid = cooperative_groups::this_grid();
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int64_t nslots = (int64_t)gridDim.x * GF_WAVES;
+    const int64_t first = xcd_contiguous_block(blockIdx.x, gridDim.x) * GF_WAVES + wave;
+    constexpr int DEEP = (GF_PREFETCH_DEEP / NV) >= GF_PREFETCH ? (GF_PREFETCH_DEEP / NV) : GF_PREFETCH;
+    for (int s = 0; s < nsweeps; ++s) {
+        const float *Xold = (s & 1) ? X1 : X0;
+        float *Xnew = (s & 1) ? X0 : X1;
+        for (int64_t r = first; r < nrows; r += nslots) {
+            const int32_t i = rows[r];
+            const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+            float xi[NV][VEC];
+            const float *pi = Xold + (int64_t)i * d;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) load_row<VEC>(pi, d, lane, c, xi[c]);
+            for (int64_t e = e0; e < e1; e += WAVE) {
+                const int cnt = (int)((e1 - e) < (int64_t)WAVE ? (e1 - e) : (int64_t)WAVE);
+                const uint32_t cj = lane < cnt ? col[e + lane] : 0u;
+                const float wj = lane < cnt ? w[e + lane] : 0.f;
+                if (cnt == WAVE) gf_chunk<VEC, NV, DEEP>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
+                else gf_chunk<VEC, NV, GF_PREFETCH>(xi, cj, wj, cnt, Xold, Xnew, d, lane, eta, regu);
+            }
+            store_row<VEC, NV>(Xnew + (int64_t)i * d, d, lane, xi, 0);
+        }
+        grid.sync();
+    }
+}
+
+template <int VEC, int NV>
+int launch_coop(const gemhip_gf_plan *p, float *X0, float *X1, float eta, float regu, int nsweeps, hipStream_t s)
+{
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    GEMHIP_CHECK(hipGetDevice(&dev));
+    GEMHIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    GEMHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gf_sweeps_coop_kernel<VEC, NV>, GF_BLOCK, 0));
+    int64_t grid = std::min<int64_t>((int64_t)per_cu * prop.multiProcessorCount, (p->nrows + GF_WAVES - 1) / GF_WAVES);
+    grid = std::max<int64_t>(NUM_XCD, grid / NUM_XCD * NUM_XCD);              // a multiple of 8: the XCD-contiguous map covers every slot
+    if (p->fused_grid > 0) grid = std::max<int64_t>(NUM_XCD, std::min<int64_t>(grid, (int64_t)p->fused_grid / NUM_XCD * NUM_XCD));
+    const int32_t *rows = p->d_rows; const int64_t *ptr = p->d_ptr; const uint32_t *col = p->d_col; const float *w = p->d_w;
+    int64_t nrows = p->nrows; int d = (int)p->d;
+    void *args[] = {(void *)&rows, (void *)&ptr, (void *)&col, (void *)&w, (void *)&X0, (void *)&X1, (void *)&nrows, (void *)&d, (void *)&eta, (void *)&regu, (void *)&nsweeps};
+    GEMHIP_CHECK(hipLaunchCooperativeKernel((const void *)gf_sweeps_coop_kernel<VEC, NV>, dim3((unsigned)grid), dim3(GF_BLOCK), args, 0, s));
+    return GEMHIP_OK;
 }
 
 // The same sweep with K consecutive rows per wavefront (large levels; round 4).  A wave that owns ONE row spends its life in a chain of dependent
@@ -432,6 +494,16 @@ hub_fn pick_hub(int d)
 }
 
 using sweep_fn = void (*)(const gemhip_gf_plan *, int64_t, int64_t, const float *, float *, float, float, hipStream_t);
+using coop_fn = int (*)(const gemhip_gf_plan *, float *, float *, float, float, int, hipStream_t);
+coop_fn pick_coop(int d)
+{
+    if (d % 2 == 0) {
+        const int nv = (d + 127) / 128;
+        return nv <= 1 ? launch_coop<2, 1> : nv <= 2 ? launch_coop<2, 2> : nv <= 4 ? launch_coop<2, 4> : nv <= 8 ? launch_coop<2, 8> : nullptr;
+    }
+    const int nv = (d + 63) / 64;
+    return nv <= 1 ? launch_coop<1, 1> : nv <= 2 ? launch_coop<1, 2> : nv <= 4 ? launch_coop<1, 4> : nv <= 8 ? launch_coop<1, 8> : nullptr;
+}
 
 sweep_fn pick_sweep(int d)
 {
@@ -695,7 +767,17 @@ extern "C" int gemhip_gf_plan_sweeps(gemhip_gf_plan_t p, int32_t nsweeps, float 
     const sweep_fn fn = pick_sweep((int)p->d);
     hipStream_t s = (hipStream_t)stream;
     const int nlevels = (int)p->level_off.size() - 1;
-    for (int it = 0; it < nsweeps; ++it) {
+    int it0 = 0;
+    if (p->fused_sweeps > 1 && nlevels == 1 && (p->level_hubs.empty() || p->level_hubs[0] == 0) && pick_coop((int)p->d)) {
+        // up to fused_sweeps sweeps per cooperative launch; the table of sweep k is X[cur ^ (k & 1)]
+        while (nsweeps - it0 >= 2) {
+            const int k = std::min(nsweeps - it0, p->fused_sweeps);
+            if (int rc = pick_coop((int)p->d)(p, p->X[p->cur], p->X[p->cur ^ 1], eta, regu, k, s)) return rc;
+            if (k & 1) p->cur ^= 1;
+            it0 += k;
+        }
+    }
+    for (int it = it0; it < nsweeps; ++it) {
         const float *Xold = p->X[p->cur];
         float *Xnew = p->X[p->cur ^ 1];
         for (int l = 0; l < nlevels; ++l) {
@@ -725,6 +807,13 @@ extern "C" int gemhip_gf_plan_set_rows_per_wave(gemhip_gf_plan_t p, int32_t rows
 {
     GEMHIP_REQUIRE(p && rows_per_wave >= 0 && rows_per_wave <= 64, "gf_plan_set_rows_per_wave: 0 (auto) .. 64");
     p->rows_per_wave = rows_per_wave;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_gf_plan_set_fused_sweeps(gemhip_gf_plan_t p, int32_t sweeps_per_launch, int32_t max_grid)
+{
+    GEMHIP_REQUIRE(p && sweeps_per_launch >= 0 && sweeps_per_launch <= 65536 && max_grid >= 0, "gf_plan_set_fused_sweeps: bad arguments");
+    p->fused_sweeps = sweeps_per_launch; p->fused_grid = max_grid;
     return GEMHIP_OK;
 }
 

@@ -1008,13 +1008,13 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
             // second however many wavefronts issue them -- R-MAT scale 22: 0.51 hot operations per pair x 502 M pairs/s at the fastest width, R-MAT scale
             // 17: 1.32 x 195 M (profiles/r05_rmat22_width_sweep.jsonl, r05_rmat17_width_sweep.jsonl).  Beyond the width that saturates them more
             // wavefronts only queue up behind the same rows (scale 22: 33.0 s at 768 wavefronts, 34.3 at 1024, 36.7 at 1536) and touch them more often
-            // at once.  Model: rate(W) = min(W / 1.2 us  [a wavefront's pair step],  255 M / hot operations per pair at W's hot threshold,  850 M
+            // at once.  Model: rate(W) = min(W / 1.5 us  [a wavefront's pair step next to saturated hot rows; 1.2-1.3 us uncontended],  255 M / hot operations per pair at W's hot threshold,  850 M
             // [the cold-row rate of the SBM headline]); the narrowest W within 3 % of the best rate wins.  Widths only ever shrink here.
             if (kn.max_waves == 0 && !kn.part && reload_eff && kn.hot_count < 0 && n >= 8192 && w > 64 && vs.total > 0.0) {
                 auto rate = [&](int64_t ww) {
                     const double thr = std::max(2.0, std::ceil(vs.total / ((double)(ww - 1) * span)));
                     const double hops = vs.max >= thr ? vs.hot_ops_per_pair(thr) : 0.0;
-                    return std::min(std::min((double)ww / 1.2e-6, hops > 0.0 ? 255e6 / hops : 1e300), 850e6);
+                    return std::min(std::min((double)ww / 1.5e-6, hops > 0.0 ? 255e6 / hops : 1e300), 850e6);
                 };
                 if (vs.max >= std::max(2.0, std::ceil(vs.total / ((double)(w - 1) * span)))) {        // (only when some row is hot at the rule's width)
                     double best = 0.0;

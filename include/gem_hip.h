@@ -109,6 +109,10 @@ int gemhip_gf_plan_sweeps(gemhip_gf_plan_t plan, int32_t nsweeps, float eta,
  * gf_sweep_rows_kernel, which has the next row's inputs in flight while a row is trained); 0 = auto (by level size).  Every
  * setting gives bit-identical tables -- rows of a level are independent.  No reference counterpart (gf.cpp is one thread). */
 int gemhip_gf_plan_set_rows_per_wave(gemhip_gf_plan_t plan, int32_t rows_per_wave);
+/* Sweeps per COOPERATIVE launch (gf_sweeps_coop_kernel: a resident grid, sweeps separated by a grid barrier instead of a kernel boundary): 0 = off
+ * (default: one launch per sweep and level), k > 1 = up to k sweeps per launch on single-level plans without hub rows (others keep the launch loop);
+ * max_grid caps the workgroups of that launch (0 = what the occupancy allows).  Bit-identical tables either way.  No reference counterpart. */
+int gemhip_gf_plan_set_fused_sweeps(gemhip_gf_plan_t plan, int32_t sweeps_per_launch, int32_t max_grid);
 int gemhip_gf_plan_get_embedding(gemhip_gf_plan_t plan, float *X_host);
 /* Device pointer of the CURRENT table (the one holding the latest sweep). */
 int gemhip_gf_plan_current(gemhip_gf_plan_t plan, void **dX);

@@ -227,6 +227,34 @@ def test_rows_per_wave_kernel_is_bit_identical(d, k, sbm1024, karate):
             assert_close(out[k], oracle.gf_train_f32(n, src, dst, w, d, 0.02, 0.01, 4, X0))
 
 
+@pytest.mark.parametrize('d', [7, 128, 256])
+@pytest.mark.parametrize('k,grid', [(2, 0), (5, 8), (64, 0)])
+def test_fused_sweeps_in_one_cooperative_launch_are_bit_identical(d, k, grid, sbm1024, karate):
+    """gemhip_gf_plan_set_fused_sweeps: up to k sweeps per COOPERATIVE launch (gf_sweeps_coop_kernel: a resident grid, the sweeps separated by a grid barrier
+    with agent-scope release / acquire instead of a kernel boundary) -- same row body, same edge order: the tables equal the launch loop's bit for bit, for
+    sweep counts that k does not divide (13), odd k (the current table flips), a grid smaller than the level (grid-stride rows), and on a multi-level plan
+    (karate), which keeps the launch loop."""
+    for name, G in (('sbm1024', sbm1024), ('karate', karate)):
+        n, src, dst, w, _ = edge_arrays(G)
+        X0 = (0.01 * np.random.RandomState(3).randn(n, d)).astype(np.float32)
+        L = _hip.lib()
+        out = {}
+        for kk in (0, k):
+            plan = C.c_void_p()
+            _hip.check(L.gemhip_gf_plan_create(n, len(src), _hip.ptr(_hip.as_i32(src), C.c_int32), _hip.ptr(_hip.as_i32(dst), C.c_int32),
+                                               _hip.ptr(_hip.as_f32(w), C.c_float), d, 0, n, C.byref(plan)))
+            _hip.check(L.gemhip_gf_plan_set_embedding(plan, _hip.ptr(X0, C.c_float)))
+            _hip.check(L.gemhip_gf_plan_set_fused_sweeps(plan, kk, grid))
+            _hip.check(L.gemhip_gf_plan_sweeps(plan, 13, 0.02, 0.01, None))
+            _hip.check(L.gemhip_gf_plan_sweeps(plan, 1, 0.02, 0.01, None))
+            X = np.empty_like(X0)
+            _hip.check(L.gemhip_gf_plan_get_embedding(plan, _hip.ptr(X, C.c_float)))
+            _hip.check(L.gemhip_gf_plan_destroy(plan))
+            out[kk] = X
+        assert np.array_equal(out[0], out[k]), name
+        assert_close(out[k], oracle.gf_train_f32(n, src, dst, w, d, 0.02, 0.01, 14, X0))
+
+
 @pytest.mark.parametrize('case', ['karate', 'sbm1024'])
 def test_hip_equals_the_emb_file_the_gf_cpp_binary_wrote(case, request):
     """The reference's NATIVE path end to end: gf.cpp's binary, run deterministically (frozen clock, scripts/make_golden_gf_cpp.py), wrote
