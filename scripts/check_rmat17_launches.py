@@ -32,6 +32,7 @@ ap_.add_argument('--tag', default='')
 ap_.add_argument('--width-layouts', default='27')
 ap_.add_argument('--width-launches', type=int, default=1)
 ap_.add_argument('--hot-counts', default='', help='staged API, default width: explicit hot-row thresholds (token counts) to try')
+ap_.add_argument('--hot-width', type=int, default=0, help='wavefront cap used together with --hot-counts (0 = the width the planner takes for that threshold)')
 ap_.add_argument('--save-counts', action='store_true')
 a = ap_.parse_args()
 os.makedirs(a.out, exist_ok=True)
@@ -50,7 +51,7 @@ g = rmat_graph(a.scale, a.edges, 20260928)
 old, big, n_elig = samples(g)
 np.save(os.path.join(a.out, 'nodes_old.npy'), old); np.save(os.path.join(a.out, 'nodes_big.npy'), big)
 gold = {}
-for fl, name in ((11, 'n2v_ref_oracle_rmat17.json'), (27, 'n2v_ref_oracle_rmat17_vocab_order.json')):
+for fl, name in ((11, 'n2v_ref_oracle_rmat17.json'), (27, 'n2v_ref_oracle_rmat17_vocab_order.json')):        # (the old 2 048-node statistic, scale 17 only)
     p = os.path.join(ROOT, 'tests', 'golden', name)
     if a.scale == 17 and os.path.exists(p):
         gold[fl] = json.load(open(p))
@@ -123,7 +124,7 @@ if widths or hots:
         for kind, vals in (('max_waves', widths), ('hot_count', hots)):
             for v in vals:
                 for rep in range(a.width_launches):
-                    _hip.check(dev.L.gemhip_n2v_set_max_waves(dev.h, v if kind == 'max_waves' else 0))
+                    _hip.check(dev.L.gemhip_n2v_set_max_waves(dev.h, v if kind == 'max_waves' else a.hot_width))
                     _hip.check(dev.L.gemhip_sgns_set_hot_rows(dev.h, v if kind == 'hot_count' else -1))
                     _hip.check(dev.L.gemhip_sgns_init(dev.h, 128, SEED, None, None))
                     _hip.check(dev.L.gemhip_synchronize(None))
@@ -133,6 +134,8 @@ if widths or hots:
                     el = time.time() - t
                     _hip.check(dev.L.gemhip_sgns_get_tables(dev.h, _hip.ptr(P, C.c_float), None))
                     rec = {'mode': 'staged', 'flags': fl, kind: v, 'rep': rep, 'sgns_s': round(el, 3)}
+                    if kind == 'hot_count':
+                        rec['max_waves'] = a.hot_width
                     o, b = score(P, fl, rec)
                     olds.append(o); bigs.append(b); labels.append([fl, 0 if kind == 'max_waves' else 1, v, rep])
                     emit(rec)
