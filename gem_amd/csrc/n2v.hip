@@ -1004,26 +1004,15 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
             }
             const int64_t hog_win = kn.max_waves > 0 ? kn.max_waves : n >= 8192 ? std::min(hog_rho, w_touch) : std::min(hog_rho, hog_tiny);
             int64_t w = std::min<int64_t>(hog_win, w_dev);
-            // Speed only (round 5): hot rows are updated by atomic adds at the memory side, and the device sustains ~255 M of those row operations per
-            // second however many wavefronts issue them -- R-MAT scale 22: 0.51 hot operations per pair x 502 M pairs/s at the fastest width, R-MAT scale
-            // 17: 1.32 x 195 M (profiles/r05_rmat22_width_sweep.jsonl, r05_rmat17_width_sweep.jsonl).  Beyond the width that saturates them more
-            // wavefronts only queue up behind the same rows (scale 22: 33.0 s at 768 wavefronts, 34.3 at 1024, 36.7 at 1536) and touch them more often
-            // at once.  Model: rate(W) = min(W / 1.5 us  [a wavefront's pair step next to saturated hot rows; 1.2-1.3 us uncontended],  255 M / hot operations per pair at W's hot threshold,  850 M
-            // [the cold-row rate of the SBM headline]); the narrowest W within 3 % of the best rate wins.  Widths only ever shrink here.
-            if (kn.max_waves == 0 && !kn.part && reload_eff && kn.hot_count < 0 && n >= 8192 && w > 64 && vs.total > 0.0) {
-                auto rate = [&](int64_t ww) {
-                    const double thr = std::max(2.0, std::ceil(vs.total / ((double)(ww - 1) * span)));
-                    const double hops = vs.max >= thr ? vs.hot_ops_per_pair(thr) : 0.0;
-                    return std::min(std::min((double)ww / 1.5e-6, hops > 0.0 ? 255e6 / hops : 1e300), 850e6);
-                };
-                if (vs.max >= std::max(2.0, std::ceil(vs.total / ((double)(w - 1) * span)))) {        // (only when some row is hot at the rule's width)
-                    double best = 0.0;
-                    for (int64_t ww = w; ww >= std::max<int64_t>(64, w / 4); ww = ww * 15 / 16) best = std::max(best, rate(ww));
-                    int64_t pick = w;
-                    for (int64_t ww = w; ww >= std::max<int64_t>(64, w / 4); ww = ww * 15 / 16) if (rate(ww) >= 0.97 * best) pick = ww;
-                    w = pick;
-                }
-            }
+            // Speed only (round 5): hot rows are updated by atomic adds at the memory side, and those saturate long before the device's wavefront slots do:
+            // past ~three wavefronts per CU more wavefronts only queue up behind the same rows and touch them more often at once.  Measured per SGNS launch,
+            // same box each (profiles/r05_rmat22_width_sweep.jsonl, r05_rmat20_width_sweep.jsonl): R-MAT scale 22 41.3 / 33.0 / 34.3 / 36.7 s and scale 20
+            // 12.5 / 10.3 / 10.7 / 15.0 s at 512 / 768 / 1024 / 1536 wavefronts.  (A rate model -- min(W / wave step, atomic row operations per second / hot
+            // operations per pair) -- fitted scale 22 and 17 and then put scale 20 at 496 wavefronts, 25 % slower than 768: the atomic unit's rate is not a
+            // constant of the device, it grows with the number of distinct hot rows.  Dropped for the plain cap.)  Widths only ever shrink here.
+            if (kn.max_waves == 0 && !kn.part && reload_eff && kn.hot_count < 0 && n >= 8192 && w > 768 && vs.total > 0.0 &&
+                vs.max >= std::max(2.0, std::ceil(vs.total / ((double)(w - 1) * span))))
+                w = 768;
             return w;
         };
         // the launch without the staging row holds one more wavefront per CU at d = 128 -- but only exists when no row is hot AT THAT WIDTH

@@ -71,7 +71,7 @@ def test_power_law_counts_get_hot_rows_and_the_width_is_bounded_by_concurrent_to
     assert p['waves'] <= 0.015 * p['n_eff_cold'] / 2 + 1                    # rho over the cold rows
     assert p['waves'] <= 0.02 * np.count_nonzero(c) + 1                     # never more than 2 % of the rows that occur
     assert (p['waves'] - 1) * touch2(c) <= 0.6 + 1e-9                       # concurrent touches
-    assert p['waves'] >= 0.85 * min(1 + 0.6 / touch2(c), 0.015 * p['n_eff_cold'] / 2, 1536)      # ... and no narrower than the rules ask (the search steps by 7/8)
+    assert p['waves'] >= 0.85 * min(1 + 0.6 / touch2(c), 0.015 * p['n_eff_cold'] / 2, 768)       # ... and no narrower than the rules ask (the search steps by 7/8; hot rows: at most 768)
     # hot = expected to sit in another wavefront's window: count >= tokens / ((W - 1)(2R + 1))
     assert p['hot'] == max(2, int(np.ceil(c.sum() / ((p['waves'] - 1) * 21.0))))
     assert (c >= p['hot']).sum() < 0.02 * n
@@ -79,13 +79,13 @@ def test_power_law_counts_get_hot_rows_and_the_width_is_bounded_by_concurrent_to
 
 def test_the_measured_rmat_corpora():
     """Token-count summaries of the graphs the rule was measured on (scripts/check_rmat17_launches.py --save-counts): R-MAT scale 17 -> 155 wavefronts
-    (round 3's rule: 602, -3.7 % of the sequential MAP; the concurrent-touch bound); scale 22 (BASELINE configs[4]) -> 751: the touch bound would allow
-    the device's 1536, but its hot rows' atomic updates saturate near 768 wavefronts (33.0 s against 36.7 s at 1536: profiles/r05_rmat22_width_sweep.jsonl),
-    and the launch takes the narrowest width within 3 % of the modelled best rate; SBM 1M/10M (no hot rows) keeps 1792."""
+    (round 3's rule: 602, -3.7 % of the sequential MAP) and scale 20 -> 688: the concurrent-touch bound; scale 22 (BASELINE configs[4]) -> 768: the touch
+    bound would allow the device's 1536, but hot rows' atomic updates saturate at about three wavefronts per CU (scale 22: 33.0 s at 768 against 36.7 s
+    at 1536; scale 20: 10.3 against 15.0 s), so a launch with hot rows is capped there; SBM 1M/10M (no hot rows) keeps 1792."""
     import json, os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rmat_token_count_histograms.json')
     H = json.load(open(path))
-    for name, want in (('rmat17', 155), ('rmat22', 751)):
+    for name, want in (('rmat17', 155), ('rmat20', 688), ('rmat22', 768)):
         h = H[name]
         c = np.repeat(np.asarray(h['count'], dtype=np.int64), np.asarray(h['nodes'], dtype=np.int64)).astype(np.int32)
         c = np.concatenate([c, np.zeros(h['n'] - len(c), np.int32)])
