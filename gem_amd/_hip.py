@@ -71,7 +71,6 @@ _SIGS = {
     'gemhip_sym_eig_top': (C.c_int, [C.c_int32, f64p, C.c_int32, f64p, f64p]),
     'gemhip_set_sym_eig_callback': (C.c_int, [C.c_void_p]),
     'gemhip_set_host_threads': (C.c_int, [C.c_int32, C.POINTER(C.c_int32)]),
-    'gemhip_hope_set_spmm_variant': (C.c_int, [C.c_int32]),
     'gemhip_hope_spmm': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, f32p, f32p, f32p]),
     'gemhip_hope_gram': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, f32p, f32p, f64p]),
     'gemhip_hope_tsgemm': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, f32p, f64p, C.c_float, f32p, f32p]),

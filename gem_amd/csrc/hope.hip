@@ -146,82 +146,6 @@ __global__ __launch_bounds__(256) void hope_spmm16_kernel(int64_t n, const int64
     }
 }
 
-// The same kernel with 16-byte accesses (round 5): lane l of a row's 16-lane group owns the FOUR CONSECUTIVE columns q*64 + 4l .. 4l+3 (q < NQ), so a
-// neighbour's row is read as NQ requests of 256 contiguous bytes per group (whole cache lines) instead of ceil(b / 16) requests of 64 bytes (half
-// lines), and a block of 43 columns costs one vector load per neighbour instead of three.  Every column's sum is formed from the same products in
-// the same order as in hope_spmm16_kernel -- which lane forms it does not enter -- so the output is bit-identical.  The launcher takes it when all
-// operands are 16-byte aligned with leading dimensions that are multiples of four floats (every block the solvers allocate; column-offset views fall
-// back to the scalar kernel); the lane that straddles column b handles its tail element by element.
-template <int NQ, int U>
-__global__ __launch_bounds__(256) void hope_spmm16v_kernel(int64_t n, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-                                                           const float *__restrict__ val, float alpha, const float *__restrict__ X, int ldx,
-                                                           const float *__restrict__ Wadd, int ldw, float *__restrict__ Y, int ldy, int b,
-                                                           float wa, const float *__restrict__ W2, int ldw2, float wb)
-{
-    const int l16 = threadIdx.x & 15;
-    const int64_t i = xcd_contiguous_block(blockIdx.x, gridDim.x) * 16 + (threadIdx.x >> 4);
-    if (i >= n) return;
-    const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
-    auto ld4 = [&](const float *row, int q, float (&v)[4]) {                // columns q*64 + 4*l16 + {0..3} of `row`, zeros beyond b
-        const int c0 = q * 64 + 4 * l16;
-        if (c0 + 3 < b) { const float4 t = *reinterpret_cast<const float4 *>(row + c0); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-        else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (c0 + k) < b ? row[c0 + k] : 0.f;
-        }
-    };
-    float wadd[NQ][4], w2v[NQ][4], acc[NQ][4];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { wadd[q][k] = 0.f; w2v[q][k] = 0.f; acc[q][k] = 0.f; }
-        if (Wadd) ld4(Wadd + i * ldw, q, wadd[q]);
-        if (W2) ld4(W2 + i * ldw2, q, w2v[q]);
-    }
-    int32_t cl = 0; float vl = 0.f;
-    if (e0 + l16 < e1) { cl = col[e0 + l16]; vl = val[e0 + l16]; }
-    for (int64_t e = e0; e < e1; e += 16) {
-        const int32_t c_cur = cl; const float v_cur = vl;
-        if (e + 16 + l16 < e1) { cl = col[e + 16 + l16]; vl = val[e + 16 + l16]; }
-        const int cnt = (int)((e1 - e) < 16 ? (e1 - e) : 16);
-        for (int k = 0; k < cnt; k += U) {
-            float xr[U][NQ][4], vj[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int kk = (k + u) < cnt ? (k + u) : (cnt - 1);
-                const int32_t cj = __shfl(c_cur, kk, 16);
-                const float vv = __shfl(v_cur, kk, 16);
-                vj[u] = (k + u) < cnt ? vv : 0.f;
-                const float *px = X + (int64_t)cj * ldx;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) ld4(px, q, xr[u][q]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                    for (int kk2 = 0; kk2 < 4; ++kk2) acc[q][kk2] += vj[u] * xr[u][q][kk2];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int c0 = q * 64 + 4 * l16;
-        if (c0 >= b) continue;
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!W2 && wa == 1.0f) o[k] = alpha * acc[q][k] + wadd[q][k];
-            else o[k] = fmaf(alpha, acc[q][k], fmaf(wa, wadd[q][k], W2 ? wb * w2v[q][k] : 0.f));
-        }
-        if (c0 + 3 < b) *reinterpret_cast<float4 *>(Y + i * ldy + c0) = make_float4(o[0], o[1], o[2], o[3]);
-        else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (c0 + k < b) Y[i * ldy + c0 + k] = o[k];
-        }
-    }
-}
-
 // ------------------------------------------------------- Gram  P[slab] = X^T Y  (MFMA fp32)
 // One wavefront per 32x32 output tile and row slab.  v_mfma_f32_32x32x2_f32 consumes two rows
 // per issue: lane l supplies X[r + (l>>5)][ci + (l&31)] and Y[r + (l>>5)][cj + (l&31)] -- both
@@ -1290,8 +1214,6 @@ struct Hope {
 
 #define HOPE_TRY(h, x) do { if (!(h).err) { hipError_t _e = (x); if (_e != hipSuccess) { (h).err = fail(GEMHIP_E_HIP, "hope: %s: %s", #x, hipGetErrorString(_e)); } } } while (0)
 
-static std::atomic<int> g_spmm16v{-1};         // gemhip_hope_set_spmm_variant: -1 = environment / default, 0 = scalar columns, 1 = 16-byte accesses, 2 = ... at half depth
-
 void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const float *Wadd, int ldw, float *Y, int ldy, int b,
           float wa = 1.0f, const float *W2 = nullptr, int ldw2 = 0, float wb = 0.f)
 {
@@ -1304,23 +1226,6 @@ void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const f
         const int64_t blocks16 = (H.n + 15) / 16;
         const dim3 grid16((unsigned)((blocks16 + NUM_XCD - 1) / NUM_XCD * NUM_XCD));
         const int c16 = (b + 15) / 16;
-        {   // 16-byte accesses when every operand allows them (GEMHIP_HOPE_SPMM16V=0: the scalar-column kernel, for the A/B)
-            static const int usev_env = getenv("GEMHIP_HOPE_SPMM16V") ? atoi(getenv("GEMHIP_HOPE_SPMM16V")) : 1;
-            const int usev = g_spmm16v >= 0 ? (g_spmm16v != 0) : usev_env;
-            auto ok16 = [](const void *p, int ld) { return p == nullptr || (((uintptr_t)p & 15u) == 0 && ld % 4 == 0); };
-            if (usev && b >= 4 && ok16(X, ldx) && ok16(Wadd, ldw) && ok16(W2, ldw2) && ok16(Y, ldy)) {
-#define SPMM16V(Q, U) hipLaunchKernelGGL((hope_spmm16v_kernel<Q, U>), grid16, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
-                // gathers in flight per row and round: 8 x one vector (b <= 64) / 4 x two vectors allocate 82-84 VGPRs (five wavefronts per SIMD), the half-depth
-                // instantiations fit eight (GEMHIP_HOPE_SPMM16V_U=1: half depth; measured: see DESIGN.md 3.4)
-                static const int half_env = getenv("GEMHIP_HOPE_SPMM16V_U") ? atoi(getenv("GEMHIP_HOPE_SPMM16V_U")) : 0;
-                const int half = g_spmm16v >= 0 ? (g_spmm16v == 2) : half_env;
-                if (b <= 64) { if (half) SPMM16V(1, 4); else SPMM16V(1, 8); }
-                else { if (half) SPMM16V(2, 2); else SPMM16V(2, 4); }
-#undef SPMM16V
-                H.spmm_count += 1; H.spmm_cols += b;
-                return;
-            }
-        }
 #define SPMM16(C, U) hipLaunchKernelGGL((hope_spmm16_kernel<C, U>), grid16, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
         // neighbours in flight per row and round.  With the next round's (column, value) pairs prefetched, short rounds win: measured 2 / 4 / 8 / 16 at
         // SBM 100k/1M (about 20 neighbours per row): see the dispatch below; round 2, without the prefetch: 4 / 8 / 16 = 5.5 / 5.2 / 5.8 ms of SpMM per solve
@@ -2705,16 +2610,6 @@ extern "C" int gemhip_hope_spmm(int64_t n, int64_t nnz, const int64_t *row_ptr, 
     HOPE_TRY(H, hipMemcpy(Y_host, dY, (size_t)n * b * 4, hipMemcpyDeviceToHost));
     hipFree(dX); hipFree(dW); hipFree(dY);
     return H.err;
-}
-
-// Which quarter-wave SpMM kernel blocks of <= 128 columns take (every variant gives bit-identical output; tests and A/B runs switch in-process):
-// -1 = the default (GEMHIP_HOPE_SPMM16V / _U), 0 = hope_spmm16_kernel (a lane owns columns l, l+16, ...), 1 = hope_spmm16v_kernel (a lane owns four
-// consecutive columns: 16-byte accesses), 2 = the same with half the gathers in flight.
-extern "C" int gemhip_hope_set_spmm_variant(int32_t variant)
-{
-    GEMHIP_REQUIRE(variant >= -1 && variant <= 2, "hope_set_spmm_variant: -1 .. 2");
-    g_spmm16v = variant;
-    return GEMHIP_OK;
 }
 
 extern "C" int gemhip_hope_gram(int64_t n, int32_t m1, int32_t m2, const float *X_host, const float *Y_host, double *G_host)

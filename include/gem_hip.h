@@ -405,9 +405,6 @@ int gemhip_set_host_threads(int32_t threads, int32_t *in_effect_out);
 int gemhip_set_sym_eig_callback(int (*fn)(int32_t n, double *A_inout, double *w_out));
 int gemhip_hope_spmm(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w,
                      float alpha, int32_t b, const float *X_host, const float *Wadd_host, float *Y_host);
-/* Kernel variant of the quarter-wave SpMM (blocks of <= 128 columns): -1 default, 0 scalar columns (hope_spmm16_kernel), 1 sixteen-byte accesses
- * (hope_spmm16v_kernel), 2 the same at half depth.  All bit-identical; a process-wide switch for tests and A/B runs. */
-int gemhip_hope_set_spmm_variant(int32_t variant);
 int gemhip_hope_gram(int64_t n, int32_t m1, int32_t m2, const float *X_host, const float *Y_host,
                      double *G_host);
 int gemhip_hope_tsgemm(int64_t n, int32_t m, int32_t b2, const float *X_host, const double *C_host,

@@ -24,17 +24,12 @@ stats = (C.c_double * 12)()
 variants = [('block_krylov', {'GEMHIP_HOPE_SYM': '0'}), ('sym', {'GEMHIP_HOPE_SYM': '1'})] + \
            [('sym_' + '_'.join('%s%s' % (a[16:].lower(), b) for a, b in sorted(e.items())), dict(e, GEMHIP_HOPE_SYM='1')) for e in (
                {'GEMHIP_HOPE_SYM_AMP': '1e5'}, {'GEMHIP_HOPE_SYM_MAXDEG': '30'})]
-if os.environ.get('AB_SPMM_VARIANTS'):      # in-process A/B of the SpMM kernel variants (gemhip_hope_set_spmm_variant): AB_SPMM_VARIANTS=0,1,2,0,1,2
-    variants = [('sym_spmm_variant_%s' % v, {'GEMHIP_HOPE_SYM': '1', '_VARIANT': v}) for v in os.environ['AB_SPMM_VARIANTS'].split(',')]
-elif sys.argv[1:]:      # python scripts/ab_hope_sym.py name:ENV=VAL,ENV=VAL ...   (e.g. fused:GEMHIP_HOPE_SYM_FUSED_RR=1 two_pass:GEMHIP_HOPE_SYM_FUSED_RR=0)
+if sys.argv[1:]:      # python scripts/ab_hope_sym.py name:ENV=VAL,ENV=VAL ...   (e.g. fused:GEMHIP_HOPE_SYM_FUSED_RR=1 two_pass:GEMHIP_HOPE_SYM_FUSED_RR=0)
     variants = [(a.split(':', 1)[0], dict(GEMHIP_HOPE_SYM='1', **dict(kv.split('=', 1) for kv in a.split(':', 1)[1].split(',') if kv))) for a in sys.argv[1:]]
 s_ref = np.asarray(ref['sigma_ascending'])
 for name, env in variants:
     for kk in list(os.environ):
         if kk.startswith('GEMHIP_HOPE_') and kk != 'GEMHIP_HOPE_SPMM16': del os.environ[kk]      # SPMM16 (kernel choice) is read once per process
-    if '_VARIANT' in env:
-        _hip.check(L.gemhip_hope_set_spmm_variant(int(env['_VARIANT'])))
-        env = {k: v for k, v in env.items() if k != '_VARIANT'}
     os.environ.update(env)
     if name == 'sym': os.environ['GEMHIP_HOPE_DEBUG'] = '1'
     ts = []

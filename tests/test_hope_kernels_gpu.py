@@ -46,40 +46,3 @@ def test_tsgemm_mfma(n, m, b2):
                                                  _hip.ptr(src, C.c_float), _hip.ptr(O, C.c_float)))
         ref = (0 if src is None else src.astype(np.float64)) - 0.5 * (X.astype(np.float64) @ Cm.astype(np.float32).astype(np.float64))
         assert np.abs(O - ref).max() <= 1e-5 * np.sqrt(m) * max(np.abs(ref).max(), 1.0)
-
-
-def test_spmm_variants_are_bit_identical():
-    """The quarter-wave SpMM exists with scalar columns per lane (hope_spmm16_kernel: a lane owns columns l, l+16, ...) and with 16-byte accesses
-    (hope_spmm16v_kernel: a lane owns four consecutive columns; at full and at half gather depth).  Every column's sum is the same products in the same
-    order whichever lane forms it: bit-identical blocks, and -- through a whole eigen-path solve, whose blocks shrink to widths that are not multiples of
-    four as pairs lock (tail lanes), with and without the recurrence's addends -- bit-identical embeddings."""
-    L = _hip.lib()
-    try:
-        rng = np.random.RandomState(5)
-        n, deg = 3000, 12
-        A = sp.random(n, n, density=deg / n, format='csr', random_state=rng, dtype=np.float64)
-        rp = A.indptr.astype(np.int64); ci = A.indices.astype(np.int32); va = (rng.rand(len(A.data)) + 0.1).astype(np.float32)
-        for b in (4, 44, 64, 80, 128):
-            X = rng.randn(n, b).astype(np.float32); W = rng.randn(n, b).astype(np.float32)
-            for wadd in (None, W):
-                out = []
-                for variant in (0, 1, 2):
-                    _hip.check(L.gemhip_hope_set_spmm_variant(variant))
-                    Y = np.empty((n, b), np.float32)
-                    _hip.check(L.gemhip_hope_spmm(n, len(ci), _hip.ptr(rp, C.c_int64), _hip.ptr(ci, C.c_int32), _hip.ptr(va, C.c_float), 0.37, b,
-                                                  _hip.ptr(X, C.c_float), _hip.ptr(wadd, C.c_float), _hip.ptr(Y, C.c_float)))
-                    out.append(Y)
-                assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2]), b
-        from gem_amd.embedding.hope import HOPE
-        from gem_amd.graph import sbm_graph
-        g = sbm_graph(20000, 200000, 8, seed=11)
-        res = []
-        for variant in (0, 1, 2):
-            _hip.check(L.gemhip_hope_set_spmm_variant(variant))
-            m = HOPE(d=64, beta=0.01)
-            res.append((m.learn_embedding(graph=g, is_weighted=True, no_python=True), m._sigma.copy(), m._stats['solver'], m._stats['spmm_launches']))
-        assert res[0][2] == 'symmetric_chebyshev_filter' and res[0][3] > 50
-        for r in res[1:]:
-            assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and r[3] == res[0][3]
-    finally:
-        L.gemhip_hope_set_spmm_variant(-1)

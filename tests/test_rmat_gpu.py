@@ -70,7 +70,8 @@ def test_node2vec_hogwild_map_on_power_law_graph(rmat):
 
 @pytest.mark.hogwild_stat
 @pytest.mark.parametrize('layout', ['node_id', 'vocab_order'])
-def test_rmat17_default_concurrency_lands_on_the_sequential_oracle(layout):
+@pytest.mark.parametrize('scale', [17, 20])
+def test_rmat_default_concurrency_lands_on_the_sequential_oracle(scale, layout):
     """The Hogwild defaults on a SECOND graph family at >= scale 17: R-MAT scale 17 -- 131 072 nodes, 1.86 M edges, max degree 9 510, the top hub 0.5 % of
     all tokens -- against the sequential oracle's run on the same seed AND the same unigram-table layout: `node_id` = flags 11, `vocab_order` = flags 27,
     the plugin default (the binary's layout).  ONE launch, bar 3 %.
@@ -84,11 +85,16 @@ def test_rmat17_default_concurrency_lands_on_the_sequential_oracle(layout):
     The rule.  With that statistic round 3's launch rule (602 wavefronts here) measured -3.7 % (vocab order) / -3.4 % (node id) over nine launches on
     two boxes, launch to launch anywhere between +0.9 and -6.7 %: the hubs' atomic updates carry gradients computed one to two pair steps earlier, and
     with W wavefronts (W - 1) x s x sum (p_v + 5 q_v)^2 / 6 others touch the same row inside that window.  The planner now bounds that number at 0.2
-    (155 wavefronts here; n2v.hip plan_sgns_launch): -0.1 ... -0.9 % at 128 - 256 wavefronts in the sweep (profiles/r05_rmat17_width_sweep.jsonl)."""
+    (155 wavefronts here; n2v.hip plan_sgns_launch): -0.1 ... -0.9 % at 128 - 256 wavefronts in the sweep (profiles/r05_rmat17_width_sweep.jsonl).
+    Scale 20 (1 048 576 nodes, 15.4 M edges, 432 M tokens; 3.7 h of CPU per oracle run): the same family three doublings up, 688 wavefronts by the same bound
+    -- the largest power-law graph the sequential oracle has been run on (BASELINE configs[4] is scale 22)."""
     import json, os
     from conftest import golden_path
     from gem_amd.evaluation import reconstruction as gr
-    ref = json.load(open(golden_path('n2v_ref_oracle_rmat17_e16k.json' if layout == 'node_id' else 'n2v_ref_oracle_rmat17_vocab_order_e16k.json')))
+    path = golden_path('n2v_ref_oracle_rmat%d%s_e16k.json' % (scale, '' if layout == 'node_id' else '_vocab_order'))
+    if not os.path.exists(path):
+        pytest.skip('%s not generated (scripts/make_golden_n2v_scale.py --rmat-scale %d --engine oracle --eligible-sample 16384)' % (os.path.basename(path), scale))
+    ref = json.load(open(path))
     pr = ref['params']
     flags = _hip.N2V_SNAP_COMPAT if layout == 'node_id' else _hip.N2V_SNAP_LAYOUT
     assert pr['flags'] == flags
@@ -99,5 +105,5 @@ def test_rmat17_default_concurrency_lands_on_the_sequential_oracle(layout):
     ap = gr.sampled_ap_gpu(g, None, m.learn_embedding(graph=g, is_weighted=True, no_python=True), nodes)
     d = ap - np.asarray(ref['ap'])
     gap, se = float(d.mean() / ref['MAP']), float(d.std(ddof=1) / np.sqrt(len(d)) / ref['MAP'])
-    print('R-MAT-17 %s: one launch %+.2f %% of the sequential MAP (paired s.e. %.2f %%)' % (layout, 100 * gap, 100 * se))
+    print('R-MAT-%d %s: one launch %+.2f %% of the sequential MAP (paired s.e. %.2f %%)' % (scale, layout, 100 * gap, 100 * se))
     assert abs(gap) <= 0.03, (gap, se, ap.mean(), ref['MAP'])
