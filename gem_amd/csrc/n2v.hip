@@ -760,6 +760,9 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
 extern "C" int gemhip_n2v_build_unigram_vocab_order(gemhip_n2v_t h, int32_t flags, int64_t *n_vocab_out, int32_t *order_out, float *UT_out, int32_t *KT_out)
 {
     GEMHIP_REQUIRE(h && h->d_walks && h->nwalks > 0, "n2v_build_unigram_vocab_order: no walks");
+    // like its sibling builders: the walks / counts may have been produced on a non-blocking stream of the caller (staged C-ABI use); the launches
+    // below go to the null stream, which does not wait for such a stream
+    GEMHIP_CHECK(hipDeviceSynchronize());
     const int64_t n = h->n, ntok = h->nwalks * h->walk_len;
     if (!h->d_first) GEMHIP_CHECK(hipMalloc((void **)&h->d_first, n * sizeof(unsigned long long)));
     GEMHIP_CHECK(hipMemset(h->d_first, 0xff, n * sizeof(unsigned long long)));
@@ -769,11 +772,11 @@ extern "C" int gemhip_n2v_build_unigram_vocab_order(gemhip_n2v_t h, int32_t flag
     std::vector<int32_t> back(n), cnt(n);              // back: renamed id -> node
     {
         unsigned long long *keys_out = nullptr; int32_t *ids = nullptr, *ids_out = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
-        GEMHIP_CHECK(hipMalloc((void **)&keys_out, n * sizeof(unsigned long long)));
-        GEMHIP_CHECK(hipMalloc((void **)&ids, 2 * n * sizeof(int32_t)));
+        hipError_t e = hipMalloc((void **)&keys_out, n * sizeof(unsigned long long));          // (every exit below frees all three temporaries)
+        if (e == hipSuccess) e = hipMalloc((void **)&ids, 2 * n * sizeof(int32_t));
         ids_out = ids + n;
-        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ids, n);
-        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
+        if (e == hipSuccess) { hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ids, n); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
         if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
         if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
         if (e == hipSuccess) e = hipDeviceSynchronize();
