@@ -55,3 +55,19 @@ def karate():
 @pytest.fixture(scope='session')
 def sbm1024():
     return load_sbm1024()
+
+
+# ---- measured values of the statistical assertions, printed at the end of the run (the tier's log then carries what was measured, not only "passed")
+STAT_REPORT = []
+
+
+def record_stat(what, measured, bar):
+    """Called by the Hogwild-MAP tests: `what` was measured as `measured` against the bar `bar` (strings, printed in pytest's terminal summary)."""
+    STAT_REPORT.append((str(what), str(measured), str(bar)))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if STAT_REPORT:
+        terminalreporter.section('measured values of the statistical (Hogwild) assertions')
+        for what, measured, bar in STAT_REPORT:
+            terminalreporter.write_line('%s: %s  [bar: %s]' % (what, measured, bar))

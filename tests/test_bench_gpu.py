@@ -174,14 +174,18 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
         k = len(ref['ap'])
         apo = np.asarray(ref['ap'])[:k]
         gaps = [float((run(20260923, k, ref['params'].get('flags', 11)) - apo).mean() / apo.mean()) for _ in range(3)]
-        print('1M parity, oracle leg (paired): gaps %s over %d nodes' % (np.round(gaps, 4).tolist(), k))
+        from conftest import record_stat
+        record_stat('SBM 1M/10M, flags %d, three Hogwild launches against the sequential oracle (paired, %d nodes)' % (ref['params'].get('flags', 11), k),
+                    '%s %%, mean %+.2f %%' % ((100 * np.round(gaps, 4)).tolist(), 100 * np.mean(gaps)), 'mean within +-1 %')
         assert abs(np.mean(gaps)) <= 0.01, (gaps, ref['MAP'])
     if 'snap' in refs:
         ref = refs['snap']
         k = len(ref['ap'])                             # the whole 4096-node sample: over its first 2048 nodes alone the same two runs sit at +2.1 % (sampling)
         aps = np.asarray(ref['ap'])[:k]
         gaps = [float((run(seed, k) - aps).mean() / aps.mean()) for seed in (20260923, 1, 2)]
-        print('1M parity, SNAP leg (unpaired seeds): gaps %s over %d nodes' % (np.round(gaps, 4).tolist(), k))
+        from conftest import record_stat
+        record_stat('SBM 1M/10M, three seeds against the reference binary\'s own run (unpaired, %d nodes)' % k,
+                    '%s %%, mean %+.2f %%' % ((100 * np.round(gaps, 4)).tolist(), 100 * np.mean(gaps)), 'mean within +-2 %')
         assert abs(np.mean(gaps)) <= 0.02, (gaps, ref['MAP'])
 
 
@@ -198,6 +202,8 @@ def test_node2vec_map_at_100k_within_one_percent_of_the_reference_binary():
                  seed=20260923)
     X = m.learn_embedding(graph=g, is_weighted=True, no_python=True)
     ap = gr.sampled_ap_gpu(g, None, X, nodes)
+    from conftest import record_stat
+    record_stat('SBM 100k/1M against the reference binary (1024 nodes)', 'MAP %.4f vs %.4f: %+.2f %%' % (ap.mean(), ref['MAP'], 100 * (ap.mean() / ref['MAP'] - 1)), '+-1 %')
     assert abs(ap.mean() - ref['MAP']) <= 0.01 * ref['MAP'], (ap.mean(), ref['MAP'])
     orc = json.load(open(golden_path('n2v_ref_oracle_100k.json')))           # the sequential restatement lands on the binary as well
     assert abs(orc['MAP'] - ref['MAP']) <= 0.01 * ref['MAP']

@@ -105,5 +105,7 @@ def test_rmat_default_concurrency_lands_on_the_sequential_oracle(scale, layout):
     ap = gr.sampled_ap_gpu(g, None, m.learn_embedding(graph=g, is_weighted=True, no_python=True), nodes)
     d = ap - np.asarray(ref['ap'])
     gap, se = float(d.mean() / ref['MAP']), float(d.std(ddof=1) / np.sqrt(len(d)) / ref['MAP'])
-    print('R-MAT-%d %s: one launch %+.2f %% of the sequential MAP (paired s.e. %.2f %%)' % (scale, layout, 100 * gap, 100 * se))
+    from conftest import record_stat
+    record_stat('R-MAT scale %d, %s layout, one Hogwild launch against the sequential oracle (paired, %d nodes)' % (scale, layout, len(d)),
+                '%+.2f %% (s.e. %.2f %%)' % (100 * gap, 100 * se), '+-3 %')
     assert abs(gap) <= 0.03, (gap, se, ap.mean(), ref['MAP'])
