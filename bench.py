@@ -291,7 +291,7 @@ class N2VWorkload(object):
         self.b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, args.d)
         # one GPU: the unigram alias table in the reference binary's own layout (first-appearance order, GEMHIP_N2V_VOCAB_ORDER) -- what
         # node2vec.learn_embedding runs by default; quality() adds a pass in the node-id layout, whose draws pair with the sequential oracle's run
-        self.b.vocab_order = (world == 1)
+        self.b.vocab_order = (world == 1)          # (N > 1 over torch.distributed: node-id-order partition tables, flags 11; the C-ABI driver honours bit 16)
         if world == 1:
             self.job = multi_gpu.Node2VecSharded(self.b, comm, rank, world, n, args.num_walks, args.walk_len, args.window, 1,
                                                  seed=20260923, flags=_hip.N2V_SNAP_COMPAT)

@@ -95,6 +95,7 @@ _SIGS = {
     'gemhip_n2v_bind_counts': (C.c_int, [C.c_void_p, C.c_void_p]),
     'gemhip_sgns_pairs': (C.c_int, [C.c_void_p, i64p, C.c_int32]),
     'gemhip_n2v_build_unigram_parts': (C.c_int, [C.c_void_p, C.c_int32, f32p, i32p]),
+    'gemhip_n2v_build_unigram_parts_vocab_order': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, f32p, i32p, i32p, i64p]),
     'gemhip_sgns_train_part': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_float,
                                          C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p]),

@@ -341,24 +341,6 @@ extern "C" int gemhip_n2v_train_multi(int64_t n, int64_t nnz, const int64_t *row
 {
     GEMHIP_REQUIRE(X_out != nullptr && episodes >= 1 && epochs >= 1 && epochs < 256, "n2v_train_multi: bad arguments (episodes=%d epochs=%d)", episodes, epochs);
     GEMHIP_REQUIRE(n_gpus >= 1 && n_gpus <= 64, "n2v_train_multi: n_gpus=%d (1..64)", n_gpus);         // before anything is sized or divided by it
-    // GEMHIP_N2V_VOCAB_ORDER (the binary's first-appearance layout of the unigram alias table, the plugin default): the per-partition tables of the
-    // N-GPU schedule are built over each partition's nodes in id order (gemhip_n2v_build_unigram_parts) -- under RndUnigramInt's quirk a different
-    // negative-sampling distribution on power-law graphs.  Never silently: one device with the flag IS gemhip_n2v_train (same model, bit for bit in the
-    // deterministic mode); more than one device refuses the flag
-    if (flags & GEMHIP_N2V_VOCAB_ORDER) {
-        if (n_gpus == 1 && (!devices || devices[0] >= 0)) {
-            int prev = 0, rc = GEMHIP_OK;
-            GEMHIP_CHECK(hipGetDevice(&prev));
-            if (devices) GEMHIP_CHECK(hipSetDevice(devices[0]));
-            double st4[4] = {0, 0, 0, 0};
-            rc = gemhip_n2v_train(n, nnz, row_ptr, col, w, d, walk_len, num_walks, window, epochs, p, q, seed, flags, X_out, st4);
-            if (!rc && stats) { stats[0] = st4[0]; stats[1] = st4[1]; stats[2] = st4[2]; stats[3] = 0.0; stats[4] = 0.0; stats[5] = 1.0; stats[6] = 0.0; stats[7] = (double)epochs; }
-            hipSetDevice(prev);
-            return rc;
-        }
-        return fail(GEMHIP_E_UNSUPPORTED, "n2v_train_multi: GEMHIP_N2V_VOCAB_ORDER (flags & 16) with n_gpus = %d: the partitioned tables are laid out in node-id order; "
-                                          "pass flags without bit 16 (e.g. GEMHIP_N2V_SNAP_COMPAT = 11) or n_gpus = 1", n_gpus);
-    }
     Fabric F;
     int rc = F.init(n_gpus, devices);
     const int N = n_gpus;
@@ -382,7 +364,6 @@ extern "C" int gemhip_n2v_train_multi(int64_t n, int64_t nnz, const int64_t *row
     }
     if (!rc) rc = F.all_reduce_sum_i32(cnt, n);
     if (!rc) rc = F.sync_all();
-    for (int r = 0; r < N && !rc; ++r) { rc = F.use(r); if (!rc) rc = gemhip_n2v_build_unigram_parts(h[r], N, nullptr, nullptr); }
     // ---- the walk corpus on every rank: shard r occupies rows [r * shard_rows, ...) (shorter shards padded with -1 tokens)
     int64_t shard_rows = 1;
     for (int r = 0; r < N; ++r) { int64_t lo, hi; shard(r, lo, hi); shard_rows = std::max(shard_rows, hi - lo); }
@@ -397,6 +378,14 @@ extern "C" int gemhip_n2v_train_multi(int64_t n, int64_t nnz, const int64_t *row
         cptr[r] = corpus[r].p;
     }
     if (!rc) rc = F.all_gather_inplace(cptr, shard_bytes);
+    // ---- the per-partition unigram tables, in the layout the flags ask for: node-id order, or (GEMHIP_N2V_VOCAB_ORDER, the plugin default on one GPU)
+    // the binary's -- each partition's nodes in order of first appearance in the WHOLE corpus, which every rank now holds
+    if (!rc) rc = F.sync_all();
+    for (int r = 0; r < N && !rc; ++r) {
+        rc = F.use(r);
+        if (!rc) rc = (flags & GEMHIP_N2V_VOCAB_ORDER) ? gemhip_n2v_build_unigram_parts_vocab_order(h[r], N, flags, corpus[r].p, (int64_t)N * shard_rows * walk_len, nullptr, nullptr, nullptr, nullptr)
+                                                       : gemhip_n2v_build_unigram_parts(h[r], N, nullptr, nullptr);
+    }
     // ---- episode table [episodes][3][N]: first row, walks present, first global walk id of every shard's slice; work items per shard = longest slice
     std::vector<int64_t> tab((size_t)episodes * 3 * N), seg_len(episodes, 1);
     for (int e = 0; e < episodes; ++e)

@@ -173,6 +173,9 @@ struct gemhip_n2v {
     int32_t parts = 0;
     float *d_UTp = nullptr; int32_t *d_KTp = nullptr;
     uint2 *d_UKp = nullptr;                  // {bits of UTp[i], KTp[i]} interleaved (sgns_win_kernel<PART>)
+    // ... in the binary's layout (gemhip_n2v_build_unigram_parts_vocab_order): per partition the slot table of RndUnigramInt in LOCAL indices
+    // (d_KTslotp[part_off[p] + slot]) and its number of slots (the partition's nodes that occur); the alias arrays above are then indexed by local row
+    int32_t *d_KTslotp = nullptr; std::vector<int64_t> part_slots; bool parts_vocab_order = false;
     std::vector<int64_t> part_off;           // table p occupies [part_off[p], part_off[p+1])
     std::vector<VocabStats> vs_part;         // vocabulary statistics of each partition's rows (launch rule of gemhip_sgns_train_part)
     bool own_counts = true;
@@ -522,7 +525,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
     hipFree(h->d_start);
     hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_scratch);
     if (h->own_counts) hipFree(h->d_counts);
-    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_SK); hipFree(h->d_SKp); hipFree(h->d_KTslot); hipFree(h->d_first); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp);
+    hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_SK); hipFree(h->d_SKp); hipFree(h->d_KTslot); hipFree(h->d_first); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp); hipFree(h->d_KTslotp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
     delete h;
     return GEMHIP_OK;
@@ -747,6 +750,36 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
     return GEMHIP_OK;
 }
 
+// Nodes in order of first appearance in a token buffer on the device (-1 tokens are padding): back[r] = node with the r-th smallest first token index
+// (nodes that never occur sort last), cnt = the handle's token counts.  LearnVocab's renaming (ELF @0x40d560) is r -> back[r] over the nodes that occur.
+static int first_appearance_order(gemhip_n2v_t h, const int32_t *d_tokens, int64_t ntok, std::vector<int32_t> &back, std::vector<int32_t> &cnt)
+{
+    // like its sibling builders: the walks / counts may have been produced on a non-blocking stream of the caller (staged C-ABI use); the launches
+    // below go to the null stream, which does not wait for such a stream
+    GEMHIP_CHECK(hipDeviceSynchronize());
+    const int64_t n = h->n;
+    if (!h->d_first) GEMHIP_CHECK(hipMalloc((void **)&h->d_first, n * sizeof(unsigned long long)));
+    GEMHIP_CHECK(hipMemset(h->d_first, 0xff, n * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(n2v_first_token_kernel, dim3((unsigned)std::min<int64_t>((ntok + 255) / 256, 256 * 16)), dim3(256), 0, 0, d_tokens, ntok, h->d_first);
+    GEMHIP_CHECK(hipGetLastError());
+    // nodes sorted by their first token index on the device (radix sort of (first, node) pairs: nodes that never occur sort last)
+    back.assign(n, 0); cnt.assign(n, 0);
+    unsigned long long *keys_out = nullptr; int32_t *ids = nullptr, *ids_out = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
+    hipError_t e = hipMalloc((void **)&keys_out, n * sizeof(unsigned long long));          // (every exit below frees all three temporaries)
+    if (e == hipSuccess) e = hipMalloc((void **)&ids, 2 * n * sizeof(int32_t));
+    ids_out = ids + n;
+    if (e == hipSuccess) { hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ids, n); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
+    if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) { PhaseScope ph(PH_D2H); e = hipMemcpy(back.data(), ids_out, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+                           if (e == hipSuccess) e = hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost); }
+    hipFree(keys_out); hipFree(ids); hipFree(tmp);
+    if (e != hipSuccess) return fail(GEMHIP_E_HIP, "first_appearance_order: device sort failed: %s", hipGetErrorString(e));
+    return GEMHIP_OK;
+}
+
 // InitUnigramTable in the BINARY's layout.  LearnEmbeddings (ELF @0x40ea30) renames the tokens 0..N-1 in order of first appearance in the walk matrix
 // (LearnVocab @0x40d560) and builds the alias table over those N entries in that order; RndUnigramInt (@0x40d5f0) then draws a SLOT floor(u N) of that
 // table.  Vose's stack discipline makes the table depend on the order of its entries, so the node-id layout of gemhip_n2v_build_unigram is the same
@@ -760,31 +793,9 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
 extern "C" int gemhip_n2v_build_unigram_vocab_order(gemhip_n2v_t h, int32_t flags, int64_t *n_vocab_out, int32_t *order_out, float *UT_out, int32_t *KT_out)
 {
     GEMHIP_REQUIRE(h && h->d_walks && h->nwalks > 0, "n2v_build_unigram_vocab_order: no walks");
-    // like its sibling builders: the walks / counts may have been produced on a non-blocking stream of the caller (staged C-ABI use); the launches
-    // below go to the null stream, which does not wait for such a stream
-    GEMHIP_CHECK(hipDeviceSynchronize());
-    const int64_t n = h->n, ntok = h->nwalks * h->walk_len;
-    if (!h->d_first) GEMHIP_CHECK(hipMalloc((void **)&h->d_first, n * sizeof(unsigned long long)));
-    GEMHIP_CHECK(hipMemset(h->d_first, 0xff, n * sizeof(unsigned long long)));
-    hipLaunchKernelGGL(n2v_first_token_kernel, dim3((unsigned)std::min<int64_t>((ntok + 255) / 256, 256 * 16)), dim3(256), 0, 0, h->d_walks, ntok, h->d_first);
-    GEMHIP_CHECK(hipGetLastError());
-    // nodes sorted by their first token index on the device (radix sort of (first, node) pairs: nodes that never occur sort last)
-    std::vector<int32_t> back(n), cnt(n);              // back: renamed id -> node
-    {
-        unsigned long long *keys_out = nullptr; int32_t *ids = nullptr, *ids_out = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
-        hipError_t e = hipMalloc((void **)&keys_out, n * sizeof(unsigned long long));          // (every exit below frees all three temporaries)
-        if (e == hipSuccess) e = hipMalloc((void **)&ids, 2 * n * sizeof(int32_t));
-        ids_out = ids + n;
-        if (e == hipSuccess) { hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ids, n); e = hipGetLastError(); }
-        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
-        if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
-        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, h->d_first, keys_out, ids, ids_out, (int)n);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess) { PhaseScope ph(PH_D2H); e = hipMemcpy(back.data(), ids_out, n * sizeof(int32_t), hipMemcpyDeviceToHost);
-                               if (e == hipSuccess) e = hipMemcpy(cnt.data(), h->d_counts, n * sizeof(int32_t), hipMemcpyDeviceToHost); }
-        hipFree(keys_out); hipFree(ids); hipFree(tmp);
-        if (e != hipSuccess) return fail(GEMHIP_E_HIP, "n2v_build_unigram_vocab_order: device sort failed: %s", hipGetErrorString(e));
-    }
+    const int64_t n = h->n;
+    std::vector<int32_t> back, cnt;              // back: renamed id -> node
+    if (int rc = first_appearance_order(h, h->d_walks, h->nwalks * h->walk_len, back, cnt)) return rc;
     PhaseScope ph_host(PH_HOST);
     int64_t N = 0;
     while (N < n && cnt[back[N]] > 0) ++N;             // the nodes that occur come first (a node occurs iff it has a first token iff its count > 0)
@@ -851,10 +862,77 @@ extern "C" int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, flo
         for (int64_t i = 0; i < n; ++i) { uint32_t ub; memcpy(&ub, &Uall[i], 4); UK[i] = make_uint2(ub, (uint32_t)Kall[i]); }
         GEMHIP_CHECK(hipMemcpy(h->d_UKp, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
     }
-    h->parts = parts; h->skp_state = -1;
+    h->parts = parts; h->skp_state = -1; h->parts_vocab_order = false;
     hipFree(h->d_SKp); h->d_SKp = nullptr;
     if (UT_out) std::copy(Uall.begin(), Uall.end(), UT_out);
     if (KT_out) std::copy(Kall.begin(), Kall.end(), KT_out);
+    return GEMHIP_OK;
+}
+
+// The per-partition tables in the BINARY's layout (flags bit GEMHIP_N2V_VOCAB_ORDER on the N-GPU schedule): partition p = the nodes v % parts == p that
+// occur, in order of first appearance in the whole corpus -- d_corpus: the walks of ALL ranks in walk-id order (rank-major shards, -1 tokens = padding;
+// NULL = this handle's own walks: one rank) -- Vose over their counts (the handle's counts: summed over the ranks) in that order; the slot table and the
+// alias arrays are stored by LOCAL row v / parts like the node-id layout's.  With one partition this IS gemhip_n2v_build_unigram_vocab_order's table.
+// Optional outputs: UT_out / KT_out [n] by local row (concatenated partitions, as d_UTp / d_KTp), slot_out [n] (partition p's slots at part_off[p],
+// -1 beyond its slot count), nslots_out [parts].
+extern "C" int gemhip_n2v_build_unigram_parts_vocab_order(gemhip_n2v_t h, int32_t parts, int32_t flags, const void *d_corpus, int64_t corpus_tokens,
+                                                          float *UT_out, int32_t *KT_out, int32_t *slot_out, int64_t *nslots_out)
+{
+    GEMHIP_REQUIRE(h && parts >= 1 && parts <= h->n, "n2v_build_unigram_parts_vocab_order: bad arguments");
+    GEMHIP_REQUIRE(d_corpus ? corpus_tokens > 0 : (h->d_walks && h->nwalks > 0), "n2v_build_unigram_parts_vocab_order: no walks");
+    const int64_t n = h->n;
+    std::vector<int32_t> back, cnt;
+    if (int rc = first_appearance_order(h, d_corpus ? (const int32_t *)d_corpus : h->d_walks, d_corpus ? corpus_tokens : h->nwalks * h->walk_len, back, cnt)) return rc;
+    int64_t N = 0;
+    while (N < n && cnt[back[N]] > 0) ++N;
+    GEMHIP_REQUIRE(N > 0, "n2v_build_unigram_parts_vocab_order: empty vocabulary");
+    h->vs.build(cnt.data(), n);
+    h->part_off.assign(parts + 1, 0);
+    h->vs_part.assign(parts, VocabStats());
+    h->part_slots.assign(parts, 0);
+    for (int32_t p = 0; p < parts; ++p) h->part_off[p + 1] = h->part_off[p] + (n - p + parts - 1) / parts;
+    std::vector<float> Uall(n, 0.f);
+    std::vector<int32_t> Kall(n, 0), Sall(n, -1), cp;
+    std::vector<std::vector<int32_t>> L(parts);                // partition p's occurring nodes in first-appearance order
+    for (int64_t r = 0; r < N; ++r) L[back[r] % parts].push_back(back[r]);
+    for (int32_t p = 0; p < parts; ++p) {
+        const int64_t off = h->part_off[p], np = h->part_off[p + 1] - off, Np = (int64_t)L[p].size();
+        GEMHIP_REQUIRE(Np > 0, "n2v_build_unigram_parts_vocab_order: partition %d has an empty vocabulary", p);
+        std::vector<int32_t> cr(Np), K; std::vector<float> Uf;
+        for (int64_t r = 0; r < Np; ++r) cr[r] = cnt[L[p][r]];
+        GEMHIP_REQUIRE(vose_unigram(cr.data(), Np, 1, Uf, K), "n2v_build_unigram_parts_vocab_order: partition %d has an empty vocabulary", p);
+        for (int64_t r = 0; r < Np; ++r) {
+            const int32_t loc = L[p][r] / parts, ali = L[p][K[r]] / parts;
+            Uall[off + loc] = Uf[r]; Kall[off + loc] = ali;
+            Sall[off + r] = (flags & 2) ? ali : loc;
+        }
+        h->part_slots[p] = Np;
+        cp.resize(np);
+        for (int64_t i = 0; i < np; ++i) cp[i] = cnt[p + i * parts];
+        h->vs_part[p].build(cp.data(), np);
+    }
+    hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp); hipFree(h->d_KTslotp); h->d_UTp = nullptr; h->d_KTp = nullptr; h->d_UKp = nullptr; h->d_KTslotp = nullptr;
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_UTp, n * sizeof(float)));
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_KTp, n * sizeof(int32_t)));
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_UKp, n * sizeof(uint2)));
+    GEMHIP_CHECK(hipMalloc((void **)&h->d_KTslotp, n * sizeof(int32_t)));
+    {
+        PhaseScope ph(PH_H2D);
+        std::vector<uint2> UK((size_t)n);
+        for (int64_t i = 0; i < n; ++i) { uint32_t ub; memcpy(&ub, &Uall[i], 4); UK[i] = make_uint2(ub, (uint32_t)Kall[i]); }
+        std::vector<int32_t> Sdev(Sall);
+        for (auto &v : Sdev) if (v < 0) v = 0;                 // (never read: a partition's launches draw slots below its slot count)
+        GEMHIP_CHECK(hipMemcpy(h->d_UTp, Uall.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        GEMHIP_CHECK(hipMemcpy(h->d_KTp, Kall.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+        GEMHIP_CHECK(hipMemcpy(h->d_UKp, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+        GEMHIP_CHECK(hipMemcpy(h->d_KTslotp, Sdev.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    h->parts = parts; h->skp_state = -1; h->parts_vocab_order = true;
+    hipFree(h->d_SKp); h->d_SKp = nullptr;
+    if (UT_out) std::copy(Uall.begin(), Uall.end(), UT_out);
+    if (KT_out) std::copy(Kall.begin(), Kall.end(), KT_out);
+    if (slot_out) std::copy(Sall.begin(), Sall.end(), slot_out);
+    if (nslots_out) std::copy(h->part_slots.begin(), h->part_slots.end(), nslots_out);
     return GEMHIP_OK;
 }
 
@@ -1051,9 +1129,11 @@ static int ensure_slot_table_parts(gemhip_n2v_t h, int quirk, hipStream_t stream
     if (h->skp_state == quirk && h->d_SKp) return GEMHIP_OK;
     if (!h->d_SKp) GEMHIP_CHECK(hipMalloc((void **)&h->d_SKp, (size_t)h->n * sizeof(uint4)));
     for (int32_t p = 0; p < h->parts; ++p) {
-        const int64_t off = h->part_off[p], np = h->part_off[p + 1] - off;
+        const int64_t off = h->part_off[p], np = h->parts_vocab_order ? h->part_slots[p] : h->part_off[p + 1] - off;
         if (np <= 0) continue;
-        hipLaunchKernelGGL(n2v_slot_table_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, h->d_KTp + off, h->d_UKp + off, quirk, h->d_SKp + off);
+        // (the binary's layout: the slot table names the entry -- quirk already folded in --, the alias arrays are indexed by local row)
+        hipLaunchKernelGGL(n2v_slot_table_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, (h->parts_vocab_order ? h->d_KTslotp : h->d_KTp) + off,
+                           h->d_UKp + off, h->parts_vocab_order ? 1 : quirk, h->d_SKp + off);
     }
     GEMHIP_CHECK(hipGetLastError());
     h->skp_state = quirk;
@@ -1166,7 +1246,10 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     const int64_t off = h->part_off[word_part];
     A.UT = h->d_UTp + off; A.KT = h->d_KTp + off; A.UK = h->d_UKp + off; A.n = (uint32_t)(h->part_off[word_part + 1] - off);
     A.seed = seed; A.flags = flags; A.d = d;
-    { const int rc = ensure_slot_table_parts(h, (flags & 2) ? 1 : 0, (hipStream_t)stream); if (rc) return rc; }
+    if (h->parts_vocab_order) {        // the binary's layout: slots over the partition's nodes that occur; the slot table is always consulted
+        A.KT = h->d_KTslotp + off; A.n = (uint32_t)h->part_slots[word_part]; A.flags = flags | 2; A.UT = nullptr;
+    }
+    { const int rc = ensure_slot_table_parts(h, (A.flags & 2) ? 1 : 0, (hipStream_t)stream); if (rc) return rc; }
     A.SK = h->d_SKp + off;
     A.SynPos = (float *)dSynPos_part; A.SynNeg = (float *)dSynNeg_part; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.prefetch = 2; A.reload = 1; A.counts = h->d_counts; A.hot_thr = 0;

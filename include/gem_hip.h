@@ -262,6 +262,11 @@ int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, float alpha0,
  * SynNeg partition) of the walk corpus.  build_unigram_parts: one alias table per partition over local indices
  * (the unigram^0.75 distribution restricted to the partition), from the global counts of the handle. */
 int gemhip_n2v_build_unigram_parts(gemhip_n2v_t h, int32_t parts, float *UT_out, int32_t *KT_out);
+/* ... in the binary's layout (GEMHIP_N2V_VOCAB_ORDER): partition p = its nodes that occur, in order of first appearance in d_corpus (device pointer: the
+ * walks of all ranks in walk-id order, -1 tokens = padding, corpus_tokens int32 entries; NULL = the handle's own walks).  Optional host outputs by local
+ * row (UT_out / KT_out [n]), the slot tables (slot_out [n]: partition p's at its offset, -1 beyond its slot count) and the slot counts (nslots_out [parts]). */
+int gemhip_n2v_build_unigram_parts_vocab_order(gemhip_n2v_t h, int32_t parts, int32_t flags, const void *d_corpus, int64_t corpus_tokens,
+                                               float *UT_out, int32_t *KT_out, int32_t *slot_out, int64_t *nslots_out);
 /* One bucket of the partitioned schedule trained in WALK order (round 4; no reference counterpart beyond TrainModel itself): TrainModel
  * (ELF @0x40d6a0) over a walk corpus in device memory, restricted to the pairs whose context is a node of partition ctx_part (rows of
  * dSynPos_part, local index v / parts) and whose centre word is a node of partition word_part (rows of dSynNeg_part; negatives from the
@@ -295,10 +300,10 @@ int gemhip_n2v_copy_walks(gemhip_n2v_t h, int64_t walk_lo, int64_t walk_hi, void
  * shards and the partitioned-table schedule (`episodes` slices of every shard; rank g trains bucket (g, (g+s) % n_gpus) of each with
  * gemhip_sgns_train_part and passes its SynNeg partition around a ring).  stats (optional, 8 doubles): {walk + vocabulary + gather
  * seconds, training seconds, tokens, pairs trained, ring bytes per rank per round, n_gpus, virtual (0/1), bucket launches per rank}.
- * Unigram-table layout: the per-partition alias tables are built over each partition's nodes in NODE-ID order.  flags with
- * GEMHIP_N2V_VOCAB_ORDER (bit 16, the plugin default on one GPU) are therefore honoured only where they can be: n_gpus = 1 IS
- * gemhip_n2v_train with those flags (same table, same model); n_gpus > 1 returns GEMHIP_E_UNSUPPORTED instead of silently training with
- * another negative-sampling table -- pass GEMHIP_N2V_SNAP_COMPAT (11).
+ * Unigram-table layout: flags with GEMHIP_N2V_VOCAB_ORDER (bit 16, the plugin default) lay every partition's alias table out over its nodes in order
+ * of first appearance in the whole corpus (gemhip_n2v_build_unigram_parts_vocab_order: the binary's layout restricted to the partition; with one
+ * device it IS gemhip_n2v_train's table, and the deterministic mode gives the same embedding bit for bit); without the bit, in node-id order
+ * (gemhip_n2v_build_unigram_parts).  Round 4 ignored the bit here.
  * STATUS of n_gpus > 1 on DISTINCT devices: the RCCL path (grouped in-place ncclAllGather, ncclAllReduce, ncclSend/ncclRecv ring, one
  * non-blocking stream per device, all driven from one host thread) has only ever run with ONE rank (a 1-GPU test pool); with n_gpus > 1
  * it has been exercised as virtual ranks only, where the three collectives are copies on one stream.  Treat the multi-device path as

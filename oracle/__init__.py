@@ -68,6 +68,9 @@ def lib():
         L.oracle_sgns_init.argtypes = [C.c_int64, C.c_int32, C.c_uint64, f32p, f32p]
         L.oracle_sgns_pairs.restype = C.c_int64
         L.oracle_sgns_pairs.argtypes = [C.c_int64, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, i32p, i32p]
+        L.oracle_sgns_train_part_slots.restype = C.c_int64
+        L.oracle_sgns_train_part_slots.argtypes = [C.c_int32, C.c_int64, C.c_int32, i32p, i64p, C.c_int64, C.c_int32, C.c_float, C.c_int64, C.c_int64, C.c_int32,
+                                                   C.c_int32, C.c_int32, C.c_int32, C.c_int64, f32p, i32p, C.c_int64, i32p, C.c_uint64, C.c_int32, C.c_int32, f32p, f32p]
         L.oracle_sgns_train_part.restype = C.c_int64
         L.oracle_sgns_train_part.argtypes = [C.c_int32, C.c_int64, C.c_int32, i32p, i64p, C.c_int64, C.c_int32, C.c_float, C.c_int64, C.c_int64, C.c_int32,
                                              C.c_int32, C.c_int32, C.c_int32, C.c_int64, f32p, i32p, C.c_uint64, C.c_int32, C.c_int32, f32p, f32p]
@@ -266,13 +269,45 @@ def unigram_build_parts(counts, parts):
     return np.concatenate(UT), np.concatenate(KT), off
 
 
+def unigram_build_parts_vocab_order(counts, corpus, parts, flags):
+    """The per-partition tables in the binary's layout (GEMHIP_N2V_VOCAB_ORDER on the N-GPU schedule): partition p = the nodes v % parts == p that occur, in
+    order of first appearance in the WHOLE corpus (walks of all ranks in walk-id order; -1 tokens are padding); Vose over their counts in that order.
+    Returns per partition (slot_tab int32[N_p] of LOCAL indices -- the local index of the entry a slot names, under flags & 2 of its alias --,
+    UT float32[n_p], KT int32[n_p] indexed by local index v // parts, alias as a local index)."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n = len(counts)
+    flat = np.asarray(corpus).ravel()
+    ok = flat >= 0
+    first = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first, flat[ok], np.nonzero(ok)[0])
+    back = np.argsort(first, kind='stable')[:int((first < np.iinfo(np.int64).max).sum())].astype(np.int64)
+    out = []
+    for p in range(parts):
+        Lp = back[back % parts == p]
+        n_p = (n - p + parts - 1) // parts
+        UT = np.zeros(n_p, np.float32); KT = np.zeros(n_p, np.int32)
+        if len(Lp) == 0:
+            out.append((np.zeros(0, np.int32), UT, KT)); continue
+        U, K = unigram_build(np.ascontiguousarray(counts[Lp]))
+        loc = (Lp // parts).astype(np.int32)
+        UT[loc] = U; KT[loc] = loc[K]
+        out.append((np.ascontiguousarray(loc[K] if (flags & 2) else loc, dtype=np.int32), UT, KT))
+    return out
+
+
 def sgns_train_part(walks, wids, window, alpha0, alpha_tokens_total, token_offset, epoch, parts, ctx_part, word_part, UTp, KTp, seed, flags,
-                    SynPos, SynNeg, walk_id_offset=0, local_rows=False):
+                    SynPos, SynNeg, walk_id_offset=0, local_rows=False, slot_tab=None):
     """One bucket (contexts of partition ctx_part, centre words of partition word_part) of the partitioned schedule in walk order, in place.
     UTp / KTp: the unigram table restricted to word_part (local indices); wids: global walk id per walk or None.  SynPos / SynNeg: the FULL
     tables, or (local_rows) the partition buffers of ctx_part / word_part.  Returns the number of pairs trained."""
     walks = np.ascontiguousarray(walks, dtype=np.int32)
     wids = None if wids is None else np.ascontiguousarray(wids, dtype=np.int64)
+    if slot_tab is not None:
+        slot_tab = np.ascontiguousarray(slot_tab, dtype=np.int32)
+        return lib().oracle_sgns_train_part_slots(SynPos.shape[1], walks.shape[0], walks.shape[1], _p(walks, C.c_int32), _p(wids, C.c_int64), walk_id_offset,
+                                                  window, alpha0, alpha_tokens_total, token_offset, epoch, parts, ctx_part, word_part, len(UTp),
+                                                  _p(UTp, C.c_float), _p(KTp, C.c_int32), len(slot_tab), _p(slot_tab, C.c_int32), seed, flags,
+                                                  1 if local_rows else 0, _p(SynPos, C.c_float), _p(SynNeg, C.c_float))
     return lib().oracle_sgns_train_part(SynPos.shape[1], walks.shape[0], walks.shape[1], _p(walks, C.c_int32), _p(wids, C.c_int64), walk_id_offset,
                                         window, alpha0, alpha_tokens_total, token_offset, epoch, parts, ctx_part, word_part, len(UTp),
                                         _p(UTp, C.c_float), _p(KTp, C.c_int32), seed, flags, 1 if local_rows else 0, _p(SynPos, C.c_float),

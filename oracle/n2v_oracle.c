@@ -449,11 +449,29 @@ int64_t oracle_sgns_pairs(int64_t nwalks, int32_t walk_len, const int32_t *walks
  * local * parts + word_part).  Same Philox keys per (walk id, position, slot) as the unrestricted function, so parts = 1 reproduces it exactly.
  * wids: global walk id of every walk in the buffer (NULL: walk_id_offset + index).  local_rows == 0: SynPos / SynNeg are the FULL tables (global
  * rows); != 0: they are the partition buffers of ctx_part / word_part (row v / parts).  Returns the number of (centre, context) pairs trained. */
+/* ... with the partition's table in the binary's layout (oracle_sgns_train_part_slots): n_slots / slot_tab as in sgns_train_core -- the slot
+ * floor(u * n_slots) names the LOCAL entry slot_tab[slot], (UTp[X], KTp[X]) over local indices decide the target.  slot_tab == NULL: the node-id layout
+ * (n_slots = n_local, X = KTp[slot] under flags & 2, else the slot itself). */
+int64_t oracle_sgns_train_part_slots(int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, const int64_t *wids, int64_t walk_id_offset,
+                            int32_t window, float alpha0, int64_t alpha_tokens_total, int64_t token_offset, int32_t epoch, int32_t parts,
+                            int32_t ctx_part, int32_t word_part, int64_t n_local, const float *UTp, const int32_t *KTp, int64_t n_slots,
+                            const int32_t *slot_tab, uint64_t seed, int32_t flags, int32_t local_rows, float *SynPos, float *SynNeg);
+
 int64_t oracle_sgns_train_part(int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, const int64_t *wids, int64_t walk_id_offset,
                             int32_t window, float alpha0, int64_t alpha_tokens_total, int64_t token_offset, int32_t epoch, int32_t parts,
                             int32_t ctx_part, int32_t word_part, int64_t n_local, const float *UTp, const int32_t *KTp, uint64_t seed,
                             int32_t flags, int32_t local_rows, float *SynPos, float *SynNeg)
 {
+    return oracle_sgns_train_part_slots(d, nwalks, walk_len, walks, wids, walk_id_offset, window, alpha0, alpha_tokens_total, token_offset, epoch, parts,
+                                        ctx_part, word_part, n_local, UTp, KTp, n_local, NULL, seed, flags, local_rows, SynPos, SynNeg);
+}
+
+int64_t oracle_sgns_train_part_slots(int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks, const int64_t *wids, int64_t walk_id_offset,
+                            int32_t window, float alpha0, int64_t alpha_tokens_total, int64_t token_offset, int32_t epoch, int32_t parts,
+                            int32_t ctx_part, int32_t word_part, int64_t n_local, const float *UTp, const int32_t *KTp, int64_t n_slots,
+                            const int32_t *slot_tab, uint64_t seed, int32_t flags, int32_t local_rows, float *SynPos, float *SynNeg)
+{
+    (void)n_local;
     float *neu1e = (float *)malloc(sizeof(float) * (size_t)d);
     const int64_t denom = alpha_tokens_total + 1;
     int64_t npairs = 0;
@@ -482,8 +500,8 @@ int64_t oracle_sgns_train_part(int32_t d, int64_t nwalks, int32_t walk_len, cons
                     else {
                         const u32x4 rn = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32),
                                                 (uint32_t)pos | ((uint32_t)a << 16), TAG_NEG | ((uint32_t)epoch << 8) | ((uint32_t)j << 16));
-                        const uint32_t slot = mulhi_range(rn.x, (uint32_t)n_local);
-                        const int32_t X = (flags & 2) ? KTp[slot] : (int32_t)slot;
+                        const uint32_t slot = mulhi_range(rn.x, (uint32_t)n_slots);
+                        const int32_t X = slot_tab ? slot_tab[slot] : ((flags & 2) ? KTp[slot] : (int32_t)slot);
                         const int32_t loc = (u01(rn.y) < UTp[X]) ? X : KTp[X];
                         target = loc * parts + word_part;
                         if (target == word) continue;

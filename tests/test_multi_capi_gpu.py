@@ -73,7 +73,11 @@ def _oracle_multi_schedule(n, src, dst, d, L, r, win, seed, flags, N, episodes):
     shard = [(total * k // N, total * (k + 1) // N) for k in range(N)]
     walks = [oracle.n2v_walks(rp, cs, None, None, 1.0, 1.0, r, L, seed, flags, lo, hi) for lo, hi in shard]
     cnt = sum(oracle.n2v_vocab(n, w_) for w_ in walks)
-    UTp, KTp, off = oracle.unigram_build_parts(cnt.astype(np.int32), N)
+    if flags & _hip.N2V_VOCAB_ORDER:      # the binary's layout per partition: first appearance in the corpus of all ranks (walk-id order)
+        tabs = oracle.unigram_build_parts_vocab_order(cnt.astype(np.int32), np.concatenate(walks, axis=0), N, flags)
+    else:
+        UTp, KTp, off = oracle.unigram_build_parts(cnt.astype(np.int32), N)
+        tabs = [(None, UTp[off[k]:off[k + 1]], KTp[off[k]:off[k + 1]]) for k in range(N)]
     P, Nn = oracle.sgns_init(n, d, seed)
     Pl = [np.ascontiguousarray(P[k::N]) for k in range(N)]
     Nl = [np.zeros_like(Pl[k]) for k in range(N)]
@@ -88,8 +92,8 @@ def _oracle_multi_schedule(n, src, dst, d, L, r, win, seed, flags, N, episodes):
                     a, z = (hi - lo) * e // episodes, (hi - lo) * (e + 1) // episodes
                     if z > a:
                         pairs += oracle.sgns_train_part(walks[k][a:z], None, win, 0.025, alpha_total, done + k * seg_len[e] * L, 0, N, g, h,
-                                                        UTp[off[h]:off[h + 1]], KTp[off[h]:off[h + 1]], seed, flags, Pl[g], Nl[h], walk_id_offset=lo + a,
-                                                        local_rows=True)
+                                                        tabs[h][1], tabs[h][2], seed, flags, Pl[g], Nl[h], walk_id_offset=lo + a,
+                                                        local_rows=True, slot_tab=tabs[h][0])
         done += seg_len[e] * N * L
     X = np.zeros((n, d), np.float32)
     for k in range(N):
@@ -151,20 +155,52 @@ def test_multi_entry_points_reject_bad_rank_counts_before_sizing_anything():
         assert b'n_gpus' in L.gemhip_last_error()
 
 
-def test_n2v_train_multi_never_swaps_the_unigram_layout_silently(sbm1024):
-    """flags with GEMHIP_N2V_VOCAB_ORDER (27, the plugin default): one device IS gemhip_n2v_train -- same table, and in the deterministic mode the same
-    embedding bit for bit; more than one (virtual) device refuses the flag instead of training with node-id-order partition tables."""
+@pytest.mark.parametrize('ranks,episodes', [(1, 2), (3, 4)])
+def test_n2v_train_multi_in_the_binarys_table_layout(sbm1024, ranks, episodes):
+    """flags with GEMHIP_N2V_VOCAB_ORDER (27, the plugin default): the partition tables are laid out over each partition's nodes in order of first
+    appearance in the whole corpus (round 4 ignored the bit and trained with node-id-order tables: ADVICE r4).  Deterministic mode: one device equals
+    gemhip_n2v_train bit for bit (one partition IS the binary's table), and 1 / 3 virtual ranks land on the oracle's restatement of the schedule with
+    oracle.unigram_build_parts_vocab_order's tables (2e-4, every pair trained once) -- and NOT on the node-id-order tables' result."""
     n, src, dst, w, _ = edge_arrays(sbm1024)
     row_ptr, col, _ = to_csr(n, src, dst, None)
     L = _hip.lib()
-    a = np.empty((n, 16), np.float32); b = np.empty((n, 16), np.float32)
-    args = (n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, 16, 30, 2, 5, 1, 1.0, 1.0, 7, _hip.N2V_SNAP_LAYOUT | 4)
-    _hip.check(L.gemhip_n2v_train(*args, _hip.ptr(a, C.c_float), None))
+    d, Lw, r, win, seed, flags = 16, 30, 2, 5, 7, _hip.N2V_SNAP_LAYOUT
+    X = np.empty((n, d), np.float32)
     st = (C.c_double * 8)()
-    _hip.check(L.gemhip_n2v_train_multi(*args, 1, None, 3, _hip.ptr(b, C.c_float), st))
-    assert np.array_equal(a, b) and st[5] == 1.0 and st[2] > 0
-    assert L.gemhip_n2v_train_multi(*args, 2, _devs(2), 3, _hip.ptr(b, C.c_float), None) == _hip.E_UNSUPPORTED
-    assert b'VOCAB_ORDER' in L.gemhip_last_error()
+    args = (n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, d, Lw, r, win, 1, 1.0, 1.0, seed)
+    _hip.check(L.gemhip_n2v_train_multi(*args, flags | 4, ranks, _devs(ranks), episodes, _hip.ptr(X, C.c_float), st))
+    want, pairs = _oracle_multi_schedule(n, src, dst, d, Lw, r, win, seed, flags, ranks, episodes)
+    assert st[3] == pairs and st[5] == ranks
+    assert np.abs(X - want).max() <= 2e-4 * np.abs(want).max() + 1e-6
+    other, _ = _oracle_multi_schedule(n, src, dst, d, Lw, r, win, seed, flags & ~_hip.N2V_VOCAB_ORDER, ranks, episodes)
+    assert np.abs(X - other).max() > 1e-2 * np.abs(want).max()                # the layout is not cosmetic: other negative draws
+    if ranks == 1:
+        a = np.empty((n, d), np.float32)
+        _hip.check(L.gemhip_n2v_train(*args, flags | 4, _hip.ptr(a, C.c_float), None))
+        assert np.abs(a - X).max() <= 2e-4 * np.abs(a).max()               # (the same pass cut into episode launches)
+
+
+def test_build_unigram_parts_vocab_order_tables(sbm1024):
+    """gemhip_n2v_build_unigram_parts_vocab_order against oracle.unigram_build_parts_vocab_order on the handle's own walks: slot tables, slot counts and the
+    alias arrays by local row, for 1 and 4 partitions and both settings of RndUnigramInt's quirk bit; one partition == the single-table builder."""
+    from test_n2v_gpu import Dev
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    dev = Dev(n, src, dst, w)
+    walks = dev.walks(1.0, 1.0, 2, 30, 5, 11)
+    cnt, _, _ = dev.unigram()
+    for parts in (1, 4):
+        for flags in (27, 27 & ~2):
+            UT = np.empty(n, np.float32); KT = np.empty(n, np.int32); SL = np.empty(n, np.int32); ns = np.empty(parts, np.int64)
+            _hip.check(dev.L.gemhip_n2v_build_unigram_parts_vocab_order(dev.h, parts, flags, None, 0, _hip.ptr(UT, C.c_float), _hip.ptr(KT, C.c_int32),
+                                                                        _hip.ptr(SL, C.c_int32), _hip.ptr(ns, C.c_int64)))
+            tabs = oracle.unigram_build_parts_vocab_order(cnt, walks, parts, flags)
+            off = 0
+            for p, (slot, U, K) in enumerate(tabs):
+                npart = len(U)
+                assert ns[p] == len(slot) and np.array_equal(SL[off:off + len(slot)], slot) and np.all(SL[off + len(slot):off + npart] == -1)
+                assert np.array_equal(UT[off:off + npart], U) and np.array_equal(KT[off:off + npart], K)
+                off += npart
+    dev.close()
 
 
 def _real_devices(k):
