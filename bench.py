@@ -720,7 +720,7 @@ def capi_multi(args, rank, world):
         secs = []
         for it in range(W + K):
             _hip.check(L.gemhip_n2v_train_multi(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, args.d, args.walk_len, args.num_walks,
-                                                args.window, 1, float(args.ret_p), float(args.inout_q), 20260923, _hip.N2V_SNAP_COMPAT, N, devs, args.episodes,
+                                                args.window, 1, float(args.ret_p), float(args.inout_q), 20260923, _hip.N2V_SNAP_LAYOUT, N, devs, args.episodes,
                                                 _hip.ptr(X, C.c_float), st))
             if it >= W:
                 secs.append(st[0] + st[1])
@@ -735,7 +735,8 @@ def capi_multi(args, rank, world):
                                'driver': 'capi gemhip_n2v_train_multi' + (' (virtual ranks on one GPU)' if virt else '')},
                     'phases': {'walks_vocab_gather_s': st[0], 'train_s': st[1], 'pairs_trained': st[3], 'ring_shift_bytes_per_rank_per_round': st[4],
                                'bucket_launches_per_rank': st[7], 'virtual_ranks': st[6]},
-                    'quality': {'sampled_map': float(ap.mean()), 'nodes_sampled': int(len(nodes))}})
+                    'quality': {'sampled_map': float(ap.mean()), 'nodes_sampled': int(len(nodes)),
+                                'unigram_layout': 'vocabulary order per partition (GEMHIP_N2V_VOCAB_ORDER: the plugin default)'}})
     out['config']['world_size_seen'] = world
     out['call_wall_s_incl_uploads_and_planning'] = time.perf_counter() - t_all
     return out
