@@ -289,15 +289,15 @@ class N2VWorkload(object):
         n, src, dst, w, _ = edge_arrays(g)
         row_ptr, col, ww = to_csr(n, src, dst, w)
         self.b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, args.d)
-        # one GPU: the unigram alias table in the reference binary's own layout (first-appearance order, GEMHIP_N2V_VOCAB_ORDER) -- what
-        # node2vec.learn_embedding runs by default; quality() adds a pass in the node-id layout, whose draws pair with the sequential oracle's run
-        self.b.vocab_order = (world == 1)          # (N > 1 over torch.distributed: node-id-order partition tables, flags 11; the C-ABI driver honours bit 16)
+        # the unigram alias table in the reference binary's own layout (first-appearance order, GEMHIP_N2V_VOCAB_ORDER) -- what node2vec.learn_embedding runs
+        # by default: one table on one GPU, one per partition (each partition's nodes in first-appearance order of the gathered corpus) on N GPUs
+        self.b.vocab_order = True
         if world == 1:
             self.job = multi_gpu.Node2VecSharded(self.b, comm, rank, world, n, args.num_walks, args.walk_len, args.window, 1,
                                                  seed=20260923, flags=_hip.N2V_SNAP_COMPAT)
         else:       # N GPUs: partitioned tables, episode schedule (gem_amd/multi_gpu.py)
             self.job = multi_gpu.Node2VecPartitioned(self.b, comm, rank, world, n, args.num_walks, args.walk_len, args.window, 1,
-                                                     seed=20260923, flags=_hip.N2V_SNAP_COMPAT, episodes=args.episodes)
+                                                     seed=20260923, flags=_hip.N2V_SNAP_LAYOUT, episodes=args.episodes)
         self.sgns_ms, self.sgns_launches, self.pairs = 0.0, 0, 0
         self._orig_train = self.b.train
         self.b.train = self._timed_train

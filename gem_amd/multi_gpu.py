@@ -341,9 +341,11 @@ class Node2VecPartitioned(object):
         b.walks(p, q, self.num_walks, self.walk_len, self.seed, self.flags, self.lo, self.hi)
         counts = b.vocab()
         comm.all_reduce_sum(counts)
-        b.build_unigram_parts(W)
         tab, seg_len = self.episode_table()
         corpus = b.gather_corpus(comm, self.shard_rows, W)                  # [W * shard_rows, walk_len] int32, identical on every rank
+        # per-partition unigram tables: node-id order, or (flags & 16 = GEMHIP_N2V_VOCAB_ORDER, the plugin default on one GPU) the binary's layout --
+        # each partition's nodes in order of first appearance in the gathered corpus
+        b.build_unigram_parts(W, corpus if (self.flags & _hip.N2V_VOCAB_ORDER) else None, self.flags)
         seg_dev = b.upload_table(tab)
         P_part, N_cur, N_tmp = b.init_part_tables(self.seed, g, W)          # partition g of SynPos / SynNeg (+ a receive buffer)
         self.pairs_trained = 0
@@ -379,9 +381,9 @@ class Node2VecPartitioned(object):
         b, W = self.b, int(parts)
         b.walks(p, q, self.num_walks, self.walk_len, self.seed, self.flags, 0, self.total_walks)
         b.vocab()
-        b.build_unigram_parts(W)
         tab, seg_len = self.episode_table()                                 # one shard (this rank's = everything)
         corpus = b.gather_corpus(self.comm, self.shard_rows, 1)
+        b.build_unigram_parts(W, corpus if (self.flags & _hip.N2V_VOCAB_ORDER) else None, self.flags)
         seg_dev = b.upload_table(tab)
         tabs = [b.init_part_tables(self.seed, g, W) for g in range(W)]
         Pp, Np = [t[0] for t in tabs], [t[1] for t in tabs]
@@ -467,9 +469,13 @@ class HipBackendN2V(object):
                                             flags, self._stream()))
 
     # ---- partitioned schedule -------------------------------------------------
-    def build_unigram_parts(self, parts):
+    def build_unigram_parts(self, parts, corpus=None, flags=0):
+        """corpus (the gathered walks of all ranks, a device tensor) given: the binary's table layout per partition (first-appearance order)."""
         self.torch.cuda.current_stream().synchronize()
-        _hip.check(self.L.gemhip_n2v_build_unigram_parts(self.h, parts, None, None))
+        if corpus is not None:
+            _hip.check(self.L.gemhip_n2v_build_unigram_parts_vocab_order(self.h, parts, flags, C.c_void_p(corpus.data_ptr()), corpus.numel(), None, None, None, None))
+        else:
+            _hip.check(self.L.gemhip_n2v_build_unigram_parts(self.h, parts, None, None))
         self.parts = parts
 
     def init_part_tables(self, seed, rank, world):

@@ -164,8 +164,15 @@ def test_world1_is_the_plain_pipeline(sbm1024):
 class OraclePart(OracleN2V):
     """Stand-in backend for Node2VecPartitioned built on the CPU oracle (partition buffers, local row indices)."""
 
-    def build_unigram_parts(self, parts):
+    def build_unigram_parts(self, parts, corpus=None, flags=0):
         self.parts = parts
+        self.slots = None
+        if corpus is not None:           # flags & 16: the binary's layout per partition (first appearance in the gathered corpus)
+            tabs = oracle.unigram_build_parts_vocab_order(self.counts.numpy(), corpus.numpy(), parts, flags)
+            self.slots = [t[0] for t in tabs]
+            self.UTp = np.concatenate([t[1] for t in tabs]); self.KTp = np.concatenate([t[2] for t in tabs])
+            self.off = np.concatenate([[0], np.cumsum([len(t[1]) for t in tabs])]).tolist()
+            return
         self.UTp, self.KTp, self.off = oracle.unigram_build_parts(self.counts.numpy(), parts)
 
     def init_part_tables(self, seed, rank, world):
@@ -199,7 +206,8 @@ class OraclePart(OracleN2V):
             walks = corpus[base[r]:base[r] + cnt[r]].numpy()
             self.npairs = getattr(self, 'npairs', 0) + oracle.sgns_train_part(
                 walks, None, window, alpha0, alpha_total, token_offset + r * seg_len * L, epoch, self.parts, ctx_part, word_part,
-                self.UTp[j0:j1], self.KTp[j0:j1], seed, flags, P_part.numpy(), N_part.numpy(), walk_id_offset=int(wid0[r]), local_rows=True)
+                self.UTp[j0:j1], self.KTp[j0:j1], seed, flags, P_part.numpy(), N_part.numpy(), walk_id_offset=int(wid0[r]), local_rows=True,
+                slot_tab=None if self.slots is None else self.slots[word_part])
 
     def pairs(self, reset=True):
         v = getattr(self, 'npairs', 0)
@@ -208,7 +216,7 @@ class OraclePart(OracleN2V):
         return v
 
 
-def _worker_part(rank, world, port, out):
+def _worker_part(rank, world, port, out, flags=9):
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     comm = multi_gpu.TorchComm(world)
@@ -225,7 +233,7 @@ def _worker_part(rank, world, port, out):
     buf, tmp = comm.ring_shift(buf, tmp)
     ok_ring = bool((buf == float((rank + 1) % world)).all())
     b = OraclePart(n, src, dst, 16)
-    job = multi_gpu.Node2VecPartitioned(b, comm, rank, world, n, 10, 80, 10, 1, seed=5, flags=9, episodes=32)
+    job = multi_gpu.Node2VecPartitioned(b, comm, rank, world, n, 10, 80, 10, 1, seed=5, flags=flags, episodes=32)
     P = job.run(1.0, 1.0)
     tot = torch.tensor([job.pairs_trained]); dist.all_reduce(tot)
     gathered = [torch.zeros_like(P) for _ in range(world)]
@@ -238,19 +246,22 @@ def _worker_part(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_partitioned_world2_gloo(tmp_path, sbm1024):
+@pytest.mark.parametrize('flags', [9, 9 | 16])
+def test_partitioned_world2_gloo(tmp_path, sbm1024, flags):
+    """flags 9: node-id-order partition tables; 9 | 16 (GEMHIP_N2V_VOCAB_ORDER): the binary's layout per partition -- first appearance in the corpus the
+    ranks all-gather -- against the sequential oracle in the same layout."""
     out = str(tmp_path / 'Pp.npy')
-    mp.spawn(_worker_part, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker_part, args=(2, _free_port(), out, flags), nprocs=2, join=True)
     ok_a2a, ok_ring, ok_same, pairs = (int(x) for x in open(out + '.flags').read().split())
     assert ok_a2a and ok_ring and ok_same
     n, src, dst, w, _ = edge_arrays(sbm1024)
     rp, col, _ = oracle.sorted_csr(n, src, dst, None)
-    walks = oracle.n2v_walks(rp, col, None, None, 1.0, 1.0, 10, 80, 5, 9)
+    walks = oracle.n2v_walks(rp, col, None, None, 1.0, 1.0, 10, 80, 5, flags)
     assert pairs == len(oracle.sgns_pairs(walks, 10, 0, 0, 5))             # every pair trained exactly once across ranks/rounds
     from gem_amd.embedding.node2vec import node2vec
     from gem_amd.evaluation import reconstruction as gr
     m = node2vec(d=16, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1)
     MAP = gr.evaluateStaticGraphReconstruction(sbm1024, m, np.load(out).astype(np.float64), None)[0]
-    Xs, _ = oracle.n2v_train(n, src, dst, w, 16, 80, 10, 10, 1, 1.0, 1.0, 5, 9)          # sequential, same flags
+    Xs, _ = oracle.n2v_train(n, src, dst, w, 16, 80, 10, 10, 1, 1.0, 1.0, 5, flags)          # sequential, same flags
     MAPs = gr.evaluateStaticGraphReconstruction(sbm1024, m, Xs.astype(np.float64), None)[0]
     assert abs(MAP - MAPs) <= 0.03 * MAPs, (MAP, MAPs)
