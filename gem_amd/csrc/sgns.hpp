@@ -384,13 +384,10 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
     const int lane = lane_id();
     const int64_t gw = blockIdx.x;
     if (gw >= A.nwaves) return;
-    // (FULL: the row width is the instantiation's own -- a compile-time constant, so that every row address is a shift instead of a 64-bit scalar multiply;
-    // on the power-law launches, three wavefronts per CU, 43 % of a wavefront's cycles are instruction issue: profiles/r05_pmc_sq_sgns_rmat22_vs_sbm.txt)
-#ifdef GEMHIP_SGNS_RUNTIME_D          // (A/B build: the round-4 form, scripts/build_variant.sh rtd -DGEMHIP_SGNS_RUNTIME_D)
+    // (measured and dropped, round 5: d as a compile-time constant in the FULL instantiations -- every row address a shift instead of a 64-bit scalar multiply,
+    // 160 -> 66 s_mul_i32 in the ISA, but 169 -> 196 SGPR spills: 9.81 against 9.78 s per pass at SBM 1M/10M, 10.53 against 10.46 s on R-MAT scale 22 with
+    // three walks per node, libraries alternated: profiles/r05_ab_sgns_const_d_dropped.jsonl)
     const int d = A.d, win = A.window, len = A.walk_len, R = A.cache_radius, S = 2 * R + 1;
-#else
-    const int d = FULL ? NV * VEC * WAVE : A.d, win = A.window, len = A.walk_len, R = A.cache_radius, S = 2 * R + 1;
-#endif
     const int nsamp = 2 * win * SGNS_NEG;
     int32_t *tok = lds;
     constexpr int32_t PT_ROW = (1 << 29) - 1, PT_WORD = 1 << 29, PT_CTX = 1 << 30;
