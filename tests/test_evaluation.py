@@ -84,3 +84,28 @@ def test_stored_snap_embeddings_carry_the_recorded_map(sbm1024):
             cos[(d, thr)] = float(np.linalg.norm(U.mean(axis=0)))                               # 1.0 = all rows parallel
     # race-free rows share a common component (|mean unit vector| ~0.88-0.89); the 8-thread runs are almost parallel (~0.995)
     assert cos[(16, 't8')] > 0.99 > 0.93 > cos[(16, 't1')] and cos[(128, 't8')] > 0.99 > 0.93 > cos[(128, 't1')]
+
+
+def test_eligible_sample_and_the_batched_cpu_scorer_behind_the_rmat_goldens():
+    """The R-MAT parity goldens (n2v_ref_oracle_rmat*_e16k.json) are per-node APs of the oracle's embedding over reconstruction.eligible_sample -- nodes that
+    have a neighbour j > i, the only ones metrics.computeMAP can give a non-zero AP -- computed by scripts/score_oracle_ap.ap_of_nodes (batched, fp64
+    scores, exact tie rule).  Pin both: the sample's definition, and the scorer against average_precision_rows (= metrics.computeMAP node by node) on a
+    graph with hubs, isolated nodes and tied scores."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
+    import score_oracle_ap
+    from gem_amd.graph import rmat_graph
+    g = rmat_graph(10, 12000, 5)
+    nodes = gr.eligible_sample(g, 200)
+    has_upper = np.zeros(g.n, bool); has_upper[g.src[g.dst > g.src]] = True
+    assert len(nodes) == 200 and np.all(np.diff(nodes) > 0) and has_upper[nodes].all()
+    assert np.array_equal(nodes, gr.eligible_sample(g, 200)) and not np.array_equal(nodes, gr.eligible_sample(g, 200, seed=2))
+    assert len(gr.eligible_sample(g, 10 ** 6)) == int(has_upper.sum())                      # capped at the eligible nodes
+    X = np.random.RandomState(0).randn(g.n, 16).astype(np.float32)
+    X[::7] = X[3]                                                                              # ties
+    order = np.argsort(g.src, kind='stable')
+    got = score_oracle_ap.ap_of_nodes(X, g.dst[order].astype(np.int64), np.searchsorted(g.src[order], np.arange(g.n + 1)), np.arange(g.n))
+    X64 = X.astype(np.float64)
+    T = np.zeros((g.n, g.n), bool); T[g.src, g.dst] = True
+    want = gr.average_precision_rows(X64 @ X64.T, T)
+    assert np.abs(got - want).max() < 1e-12 and np.all(got[~has_upper] == 0.0)
