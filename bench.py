@@ -523,8 +523,12 @@ class N2VWorkload(object):
             # (reconstruction.eligible_sample: a uniform sample is two thirds dead weight there, tests/test_rmat_gpu.py) -- committed for scale 17 and 20;
             # the reference binary itself cannot run these graphs (its per-pair alias tables are Sigma deg^2)
             scale = int(np.ceil(np.log2(a.nodes)))
-            gpath = os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_oracle_rmat%d%s_e16k.json' % (scale, '_vocab_order' if vo else ''))
-            if os.path.exists(gpath):
+            gpath = None
+            for suffix in ('e128k', 'e16k'):            # (scale 20 is scored over 131 072 eligible nodes, scale 17 over 16 384)
+                cand = os.path.join(ROOT, 'tests', 'golden', 'n2v_ref_oracle_rmat%d%s_%s.json' % (scale, '_vocab_order' if vo else '', suffix))
+                if gpath is None and os.path.exists(cand):
+                    gpath = cand
+            if gpath is not None:
                 ref = json.load(open(gpath))
                 pr = ref['params']
                 if (pr['rmat_scale'], pr['edges'], pr['seed'], pr['d'], pr['walk_len'], pr['num_walks'], pr['window']) == \

@@ -1065,9 +1065,15 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         // width and layout, profiles/r05_rmat17_width_sweep.jsonl): c = 0.16 / 0.25 / 0.33 / 0.5 / 0.66 / 1.0 (128 / 192 / 256 / 384 / 512 / 768
         // wavefronts) -> -0.1 / -0.5 / -0.9 / -2.3 / -4.2 / -6.3 % of the MAP in the binary's table layout (node-id layout: -0.2 / -0.2 / +0.2 / +0.4 /
         // -1.7 / -2.4 %), while rho over the cold rows stayed under 1.5 % throughout: round 3's rule (602 wavefronts there) measured -3.7 %, and its
-        // 2 048-node uniform sample, two thirds of it nodes without a ranked neighbour, could not see it.  Bound: c <= 0.2, i.e. (W - 1) x touch2 <= 0.6.
-        // SBM graphs are far from it (touch2 = 38 / n: 15 800 wavefronts at 1M nodes); R-MAT scale 17: 155, scale 22: 1 866 (the device holds 1 536).
-        const int64_t w_touch = vs.touch2 > 0.0 ? std::max<int64_t>(1, 1 + (int64_t)(0.6 / (vs.touch2 * kn.touch_scale))) : INT64_MAX;
+        // 2 048-node uniform sample, two thirds of it nodes without a ranked neighbour, could not see it.  The same family three doublings up (R-MAT scale 20,
+        // sequential oracle: 3.7 h per layout; paired over 131 072 eligible nodes, s.e. 0.4 %) is MORE sensitive at the same width, not less: 256 wavefronts
+        // (c = 0.07) -1.9 %, 688 (c = 0.2) -6.4 % / -8.3 % (profiles/r05_rmat20_launches_e128k.jsonl) -- the reconstruction MAP of a barely trained
+        // million-node embedding (0.003) moves more per unit of perturbation than scale 17's (0.018).  Bound, set by the worse of the two graphs, on the
+        // part of touch2 that HUBS contribute -- touch2 minus the 40 / active a table of equally frequent rows has (SBM: 38 / n; those graphs stay on the rho
+        // rule they were validated on) --: (W - 1) x touch2_hub <= 0.165: 50 wavefronts on scale 17, 207 on scale 20, 548 on scale 22.  Scale 22 itself
+        // has no oracle (15 h per layout): its width is this extrapolation.
+        const double touch2_hub = std::max(0.0, vs.touch2 - 40.0 / std::max(1.0, vs.active > 0.0 ? vs.active : (double)n));
+        const int64_t w_touch = touch2_hub > 0.0 ? std::max<int64_t>(1, 1 + (int64_t)std::min(1e15, 0.165 / (touch2_hub * kn.touch_scale))) : INT64_MAX;
         auto width = [&](bool all_cached) -> int64_t {
             // registers: the single-GPU kernels allocate 176-184 VGPRs (2 wavefronts per SIMD = 8 per CU), the bucket kernels 136-145 (3 per SIMD = 12 per CU)
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(kn.part ? 12 : 8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta, all_cached) + 512)));

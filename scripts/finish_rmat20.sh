@@ -2,6 +2,9 @@
 # After the two R-MAT scale 20 oracle runs (scripts/make_golden_n2v_scale.py --rmat-scale 20 --engine oracle --save-emb .refruns/oracle_rmat20_f{11,27}.npy)
 # have finished: score them over the 16 384-node eligible sample (-> tests/golden/n2v_ref_oracle_rmat20*_e16k.json) and pair the per-node APs the GPU
 # sweep saved (scripts/gpu_r05_f.sh) with them (-> profiles/r05_rmat20_width_sweep_paired.jsonl).
+# NOTE: over 16 384 nodes the APs of this graph sum to 49 and one launch's paired gap has an s.e. of 1.4 %: the COMMITTED goldens are the 131 072-node ones
+# (tests/golden/n2v_ref_oracle_rmat20*_e128k.json, scripts/score_oracle_ap.py --procs 4 on the same embeddings; on the common nodes both scorers agree
+# exactly), the e16k files this script writes were an intermediate and are not kept.
 set -e
 cd "$(dirname "$0")/.."
 for f in 11 27; do
