@@ -114,6 +114,7 @@ struct SgnsKnobs {
     bool part = false;                // a bucket launch of the partitioned schedule (sgns_win_kernel<PART>: as-loaded window copies in global scratch, 3 wavefronts per SIMD)
     double duty = 1.0;                // fraction of a wavefront's time spent in pair steps (negative rows open); < 1 only for the buckets of the partitioned schedule
     double touch_scale = 1.0;         // factor on VocabStats::touch2 (bucket launches: the pairs of ONE bucket touch the rows of two partitions only: parts x duty)
+    bool node_id_layout = false;      // the unigram table the launch draws from is in node-id order (gemhip_n2v_build_unigram), not the binary's: half the concurrent-touch bound (plan_sgns_launch)
 };
 // ... and what a launch of TrainModel over `nwalks` walks then looks like (pure host arithmetic: gemhip_sgns_plan_launch exposes it to the CPU tests)
 struct SgnsLaunchPlan {
@@ -1072,8 +1073,16 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         // part of touch2 that HUBS contribute -- touch2 minus the 40 / active a table of equally frequent rows has (SBM: 38 / n; those graphs stay on the rho
         // rule they were validated on) --: (W - 1) x touch2_hub <= 0.165: 50 wavefronts on scale 17, 207 on scale 20, 548 on scale 22.  Scale 22 itself
         // has no oracle (15 h per layout): its width is this extrapolation.
+        // The NODE-ID table layout (flags without GEMHIP_N2V_VOCAB_ORDER; an opt-in since round 4) gets HALF that bound.  Under RndUnigramInt's quirk the
+        // negatives are drawn from the alias TARGETS only, so the distribution actually sampled is a function of Vose's pairing, i.e. of the table order
+        // (the two layouts are different samplers: the sequential oracle's MAP differs by 8.7 % on scale 17 and 18.9 % on scale 20 between them), and
+        // p, q above are the nominal ones.  Measured on scale 20 in that layout: 688 / 207 / 104 wavefronts -> -8.3 / -6.3 / -1.5 % (s.e. 0.9 / 0.9 / 0.6 %),
+        // i.e. it needs half the width the binary's layout does there (207: -1.5 %), while on scale 17 it was the LESS sensitive one; none of the
+        // statistics of the actually sampled distribution that were tried (its touch2, its largest row load, its collision rate over the cold rows:
+        // scripts/study_negative_distribution.py) orders the two layouts on both graphs, so this is a per-layout calibration on the worse graph.
+        const double touch_bound = kn.node_id_layout ? 0.0825 : 0.165;
         const double touch2_hub = std::max(0.0, vs.touch2 - 40.0 / std::max(1.0, vs.active > 0.0 ? vs.active : (double)n));
-        const int64_t w_touch = touch2_hub > 0.0 ? std::max<int64_t>(1, 1 + (int64_t)std::min(1e15, 0.165 / (touch2_hub * kn.touch_scale))) : INT64_MAX;
+        const int64_t w_touch = touch2_hub > 0.0 ? std::max<int64_t>(1, 1 + (int64_t)std::min(1e15, touch_bound / (touch2_hub * kn.touch_scale))) : INT64_MAX;
         auto width = [&](bool all_cached) -> int64_t {
             // registers: the single-GPU kernels allocate 176-184 VGPRs (2 wavefronts per SIMD = 8 per CU), the bucket kernels 136-145 (3 per SIMD = 12 per CU)
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(kn.part ? 12 : 8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta, all_cached) + 512)));
@@ -1171,7 +1180,9 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->kn.prefetch; A.reload = h->kn.reload; A.counts = nullptr; A.hot_thr = 0;
     A.parts = 0; A.ctx_part = 0; A.word_part = 0; A.seg = nullptr; A.nseg = 0; A.seg_len = 0; A.scratch = nullptr;
-    const SgnsLaunchPlan P = plan_sgns_launch(h->vs, h->kn, h->n, h->d, window, h->walk_len, walk_hi - walk_lo, flags);
+    SgnsKnobs kn_launch = h->kn;
+    kn_launch.node_id_layout = !h->vocab_order;
+    const SgnsLaunchPlan P = plan_sgns_launch(h->vs, kn_launch, h->n, h->d, window, h->walk_len, walk_hi - walk_lo, flags);
     GEMHIP_REQUIRE(P.lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for LDS staging (%zu bytes)", P.lds);
     A.nwaves = (int32_t)P.waves; A.cache_radius = P.R;
     if (P.window) {
@@ -1217,7 +1228,9 @@ extern "C" int gemhip_sgns_plan_launch(const int32_t *counts, int64_t n, int32_t
     GEMHIP_REQUIRE(counts && n >= 1 && d >= 1 && window >= 1 && walk_len >= 1 && nwalks >= 1, "sgns_plan_launch: bad arguments");
     VocabStats vs;
     vs.build(counts, n);
-    const SgnsLaunchPlan P = plan_sgns_launch(vs, SgnsKnobs(), n, d, window, walk_len, nwalks, flags);
+    SgnsKnobs kn;
+    kn.node_id_layout = !(flags & GEMHIP_N2V_VOCAB_ORDER);
+    const SgnsLaunchPlan P = plan_sgns_launch(vs, kn, n, d, window, walk_len, nwalks, flags);
     if (kernel) *kernel = !P.window ? 0 : P.delta ? 2 : 1;          // 0 sgns_kernel, 1 sgns_win_kernel (overwrite on leave), 2 sgns_win_kernel (Hogwild: delta write-back)
     if (waves) *waves = (int32_t)P.waves;
     if (hot_threshold) *hot_threshold = P.hot_thr;
@@ -1266,7 +1279,7 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     VocabStats vs = h->vs_part[word_part];
     vs.total = h->vs.total; vs.max = h->vs.max; vs.touch2 = h->vs.touch2;
     SgnsKnobs kn = h->kn;
-    kn.prefetch = 2; kn.reload = 1; kn.part = true;
+    kn.prefetch = 2; kn.reload = 1; kn.part = true; kn.node_id_layout = !h->parts_vocab_order;
     // Duty cycle.  The rule bounds the negative rows that are OPEN at any time (W x 5 x w of them).  A wavefront of a bucket launch spends only part of
     // its time in pair steps: per walk it has walk_len x (window + 1) x 0.95 / parts^2 pairs to train but still 2 x walk_len / parts rows (the contexts and
     // the centre words of its two partitions) to fetch and return, each an exposed round trip of ~0.7 pair steps.  With that fraction f of the time in

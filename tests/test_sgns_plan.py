@@ -14,7 +14,7 @@ import pytest
 from gem_amd import _hip
 
 
-def plan(counts, d=128, window=10, walk_len=80, nwalks=None, flags=11):
+def plan(counts, d=128, window=10, walk_len=80, nwalks=None, flags=27):
     L = _hip.lib()
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     k, w, hot = C.c_int32(), C.c_int32(), C.c_int32()
@@ -64,16 +64,23 @@ def touch2_hub(c):
 
 
 TOUCH_BOUND = 0.165          # (W - 1) x touch2_hub: n2v.hip plan_sgns_launch, calibrated on the R-MAT scale 20 / 17 oracle runs (tests/test_rmat_gpu.py)
+TOUCH_BOUND_NODE_ID = 0.0825  # ... and half of it in the node-id table layout (flags 11): R-MAT scale 20 measured -6.3 % at 207 wavefronts and -1.5 % at 104 there
 
 
+def bound_of(flags):
+    return TOUCH_BOUND if flags & _hip.N2V_VOCAB_ORDER else TOUCH_BOUND_NODE_ID
+
+
+@pytest.mark.parametrize('flags', [27, 11])
 @pytest.mark.parametrize('s', [0.6, 0.8, 1.0])
-def test_power_law_counts_get_hot_rows_and_the_width_is_bounded_by_concurrent_touches(s):
+def test_power_law_counts_get_hot_rows_and_the_width_is_bounded_by_concurrent_touches(s, flags):
     """Zipf counts: hubs stay out of the LDS windows (hot rows: atomic updates), the cold rows carry the rho rule -- and, round 5, the width is bounded by
     the concurrent touches of one hub row, (W - 1) x touch2_hub <= 0.165: the bound that brought R-MAT scale 17 from -3.7 % to within 1 % and scale 20 from
     -6.4 % to within 2 % of the sequential MAP (tests/test_rmat_gpu.py, profiles/r05_rmat17_width_sweep.jsonl, r05_rmat20_launches_e128k.jsonl)."""
     n, tokens = 131072, 131072 * 800
     c = zipf_counts(n, tokens, s)
-    p = plan(c)
+    p = plan(c, flags=flags)
+    TOUCH_BOUND = bound_of(flags)
     assert p['kernel'] == 2 and p['hot'] >= 2
     assert p['n_eff'] < p['n_eff_cold'] and p['n_eff'] < 0.5 * n            # the hubs dominate the collision rate of the negative draws
     assert p['waves'] <= 0.015 * p['n_eff_cold'] / 2 + 1                    # rho over the cold rows
@@ -89,18 +96,20 @@ def test_the_measured_rmat_corpora():
     """Token-count summaries of the graphs the rule was measured on (scripts/check_rmat17_launches.py --save-counts): R-MAT scale 17 -> 50 wavefronts
     (round 3's rule: 602, -3.7 % of the sequential MAP), scale 20 -> 207 (688 by the first calibration on scale 17 alone: -6.4 %; 256: -1.9 %), scale 22
     (BASELINE configs[4]) -> 548 (round 4: 1536) -- all three by the concurrent-touch bound on the hubs' part of touch2; launches with hot rows are
-    capped at 768 wavefronts anyway (their atomic updates saturate: scale 22 33.0 s at 768 against 36.7 s at 1536).  SBM 1M/10M (no hubs) keeps 1792."""
+    capped at 768 wavefronts anyway (their atomic updates saturate: scale 22 33.0 s at 768 against 36.7 s at 1536).  SBM 1M/10M (no hubs) keeps 1792.
+    The node-id table layout (flags 11) gets half the bound -- 25 / 104 / 274: scale 20 measured -6.3 % at 207 wavefronts and -1.5 % at 104 in that layout."""
     import json, os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rmat_token_count_histograms.json')
     H = json.load(open(path))
-    for name, want in (('rmat17', 50), ('rmat20', 207), ('rmat22', 548)):
+    for name, want, want_node_id in (('rmat17', 50, 25), ('rmat20', 207, 104), ('rmat22', 548, 274)):
         h = H[name]
         c = np.repeat(np.asarray(h['count'], dtype=np.int64), np.asarray(h['nodes'], dtype=np.int64)).astype(np.int32)
         c = np.concatenate([c, np.zeros(h['n'] - len(c), np.int32)])
-        p = plan(c, nwalks=h['nwalks'])
-        assert p['waves'] == want and p['hot'] > 0, (name, p)
-        assert (p['waves'] - 1) * touch2_hub(c) <= TOUCH_BOUND + 1e-9
-        assert p['waves'] * 5 * 0.4 / p['n_eff_cold'] <= 0.015
+        for flags, w in ((27, want), (11, want_node_id)):                   # the plugin default (the binary's table layout) / the node-id layout: half the bound
+            p = plan(c, nwalks=h['nwalks'], flags=flags)
+            assert p['waves'] == w and p['hot'] > 0, (name, flags, p)
+            assert (p['waves'] - 1) * touch2_hub(c) <= bound_of(flags) + 1e-9
+            assert p['waves'] * 5 * 0.4 / p['n_eff_cold'] <= 0.015
     assert touch2_hub(np.full(1000000, 800)) == 0.0                         # equally frequent rows: the bound does not apply
 
 
