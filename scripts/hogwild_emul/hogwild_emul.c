@@ -47,6 +47,9 @@ typedef struct {
     int64_t stat_pairs, stat_neg_lost, stat_ctr_lost;
 } Cfg;
 
+static const int32_t *g_slot_tab = NULL; static int64_t g_nslots = 0;
+void hogwild_emul_set_slot_table(const int32_t *slot_tab, int64_t n_slots) { g_slot_tab = slot_tab; g_nslots = n_slots; }
+
 /* generate the pairs of the next non-empty centre of wave w into its ring; returns 0 when the wave has no walks left */
 static int gen_centre(const Cfg *c, Wave *w)
 {
@@ -77,8 +80,9 @@ static int gen_centre(const Cfg *c, Wave *w)
             for (int j = 1; j <= NEG; ++j) {
                 const u32x4 rn = philox(c->seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos | ((uint32_t)a << 16),
                                         TAG_NEG | ((uint32_t)c->epoch << 8) | ((uint32_t)j << 16));
-                const uint32_t slot = mulhi_range(rn.x, (uint32_t)c->n);
-                const int32_t X = (c->flags & 2) ? c->KT[slot] : (int32_t)slot;
+                /* the binary's table layout (round 5; hogwild_emul_set_slot_table): slots over the nodes that occur, UT / KT indexed by node -- as in sgns_train_core */
+                const uint32_t slot = mulhi_range(rn.x, (uint32_t)(g_slot_tab ? g_nslots : c->n));
+                const int32_t X = g_slot_tab ? g_slot_tab[slot] : (c->flags & 2) ? c->KT[slot] : (int32_t)slot;
                 p->tgt[j - 1] = (u01(rn.y) < c->UT[X]) ? X : c->KT[X];
             }
             ++w->qn; ++made;

@@ -86,6 +86,8 @@ def main():
     ap.add_argument('--cfg', nargs='+', default=['seq'])
     ap.add_argument('--selftest', action='store_true')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--flags', type=int, default=11, help='11 = node-id table layout, 27 = the binary\'s (first-appearance order; round 5)')
+    ap.add_argument('--eligible', action='store_true', help='score nodes that have a ranked neighbour (reconstruction.eligible_sample) instead of a uniform sample')
     a = ap.parse_args()
     L = emul_lib()
     if a.selftest:
@@ -97,13 +99,24 @@ def main():
         g = sbm_graph(a.nodes, a.edges, a.blocks, a.seed + 4)
     n, src, dst, w, _ = edge_arrays(g)
     row_ptr, col, ww = oracle.sorted_csr(n, src, dst, w)
-    flags = 11
+    flags = a.flags
     walks = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, a.walks, a.walk_len, a.seed, flags)
     counts = np.ascontiguousarray(oracle.n2v_vocab(n, walks), dtype=np.int32)
-    UT, KT = oracle.unigram_build(counts)
+    slot_tab = None
+    if flags & 16:
+        slot_tab, UT, KT = oracle.unigram_build_vocab_order(counts, walks, flags)[:3]
+        slot_tab = np.ascontiguousarray(slot_tab, dtype=np.int32)
+        L.hogwild_emul_set_slot_table.argtypes = [C.POINTER(C.c_int32), C.c_int64]; L.hogwild_emul_set_slot_table.restype = None
+        L.hogwild_emul_set_slot_table(p(slot_tab, C.c_int32), len(slot_tab))
+    else:
+        UT, KT = oracle.unigram_build(counts)
     UT = np.ascontiguousarray(UT, dtype=np.float32); KT = np.ascontiguousarray(KT, dtype=np.int32)
     walks = np.ascontiguousarray(walks, dtype=np.int32)
-    nodes = np.random.RandomState(0).choice(n, size=min(a.sample, n), replace=False)
+    if a.eligible:
+        from gem_amd.evaluation.reconstruction import eligible_sample
+        nodes = eligible_sample(g, a.sample)
+    else:
+        nodes = np.random.RandomState(0).choice(n, size=min(a.sample, n), replace=False)
     base = None
     ref_X = None
     for cs in a.cfg:
@@ -112,7 +125,10 @@ def main():
         t = time.time()
         st = (C.c_int64 * 4)()
         if cfg is None:
-            oracle.sgns_train(walks, a.window, 0.025, 1, 0, walks.size, 0, 0, UT, KT, a.seed, flags, P, N)
+            if slot_tab is not None:
+                oracle.sgns_train_vocab_order(walks, a.window, 0.025, 1, 0, walks.size, 0, 0, slot_tab, UT, KT, a.seed, flags, P, N)
+            else:
+                oracle.sgns_train(walks, a.window, 0.025, 1, 0, walks.size, 0, 0, UT, KT, a.seed, flags, P, N)
         else:
             L.hogwild_emul_train(n, a.d, walks.shape[0], walks.shape[1], p(walks, C.c_int32), a.window, 0.025, 1, 0, walks.size, 0, 0,
                                  p(UT, C.c_float), p(KT, C.c_int32), a.seed, flags, p(P, C.c_float), p(N, C.c_float),
@@ -123,7 +139,7 @@ def main():
         if base is None:
             base = aps; ref_X = P.copy()
         dlt = aps - base
-        rec = dict(cfg=cs, n=n, walks=a.walks, d=a.d, MAP=float(aps.mean()), MAP_se=float(aps.std(ddof=1) / np.sqrt(len(aps))),
+        rec = dict(cfg=cs, flags=flags, n=n, walks=a.walks, d=a.d, MAP=float(aps.mean()), MAP_se=float(aps.std(ddof=1) / np.sqrt(len(aps))),
                    rel_vs_first_pct=float(100 * dlt.mean() / base.mean()), rel_se_pct=float(100 * dlt.std(ddof=1) / np.sqrt(len(aps)) / base.mean()),
                    max_abs_diff_vs_first=float(np.abs(P - ref_X).max()), seconds=round(el, 1), pairs=int(st[0]),
                    neg_overwrote_foreign=float(st[1]) / max(1, 5 * st[0]), centre_overwrote_foreign=int(st[2]))
