@@ -1073,9 +1073,10 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         // part of touch2 that HUBS contribute -- touch2 minus the 40 / active a table of equally frequent rows has (SBM: 38 / n; those graphs stay on the rho
         // rule they were validated on) --: (W - 1) x touch2_hub <= 0.165: 50 wavefronts on scale 17, 207 on scale 20, 548 on scale 22.  Scale 22 itself
         // has no oracle (15 h per layout): its width is this extrapolation.
-        // (The picture above is the rule's motivation, not an established mechanism: the CPU replay of exactly that picture -- lossless additive updates from
-        // copies two pairs old, round-robin wavefronts, scripts/hogwild_emul -- shows no bias on R-MAT scale 15 up to 384 virtual wavefronts in either table
-        // layout; the bound is a fit through the oracle-pinned points.  DESIGN.md 3.3 (4), section 7.)
+        // (How far the picture above carries: the CPU replay of exactly that picture -- lossless additive updates from copies two pairs old, round-robin
+        // wavefronts, scripts/hogwild_emul -- gives +0.6 / -3.4 % at 512 / 768 virtual wavefronts on scale 17 in the binary's layout and -1.6 % at 768 in the
+        // node-id layout, where the device measures -4.2 / -6.3 and -2.4 %: the right sign and layout order, half the size, a later onset; nothing on scale
+        // 15 up to 384.  The bound is a fit through the oracle-pinned points.  DESIGN.md 3.3 (4), section 7.)
         // The NODE-ID table layout (flags without GEMHIP_N2V_VOCAB_ORDER; an opt-in since round 4) gets HALF that bound.  Under RndUnigramInt's quirk the
         // negatives are drawn from the alias TARGETS only, so the distribution actually sampled is a function of Vose's pairing, i.e. of the table order
         // (the two layouts are different samplers: the sequential oracle's MAP differs by 8.7 % on scale 17 and 18.9 % on scale 20 between them), and

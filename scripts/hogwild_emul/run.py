@@ -86,6 +86,8 @@ def main():
     ap.add_argument('--cfg', nargs='+', default=['seq'])
     ap.add_argument('--selftest', action='store_true')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--train-seed', type=int, default=None, help='seed of walks / init / draws when it differs from the graph seed (--seed)')
+    ap.add_argument('--baseline-emb', default=None, help='.npy embedding of the sequential pass (oracle.n2v_train with the same seeds and flags): `seq` is then not trained again')
     ap.add_argument('--flags', type=int, default=11, help='11 = node-id table layout, 27 = the binary\'s (first-appearance order; round 5)')
     ap.add_argument('--eligible', action='store_true', help='score nodes that have a ranked neighbour (reconstruction.eligible_sample) instead of a uniform sample')
     a = ap.parse_args()
@@ -100,7 +102,8 @@ def main():
     n, src, dst, w, _ = edge_arrays(g)
     row_ptr, col, ww = oracle.sorted_csr(n, src, dst, w)
     flags = a.flags
-    walks = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, a.walks, a.walk_len, a.seed, flags)
+    tseed = a.seed if a.train_seed is None else a.train_seed
+    walks = oracle.n2v_walks(row_ptr, col, None, None, 1.0, 1.0, a.walks, a.walk_len, tseed, flags)
     counts = np.ascontiguousarray(oracle.n2v_vocab(n, walks), dtype=np.int32)
     slot_tab = None
     if flags & 16:
@@ -121,17 +124,19 @@ def main():
     ref_X = None
     for cs in a.cfg:
         cfg = parse_cfg(cs, a.window)
-        P, N = oracle.sgns_init(n, a.d, a.seed)
+        P, N = oracle.sgns_init(n, a.d, tseed)
         t = time.time()
         st = (C.c_int64 * 4)()
-        if cfg is None:
+        if cfg is None and a.baseline_emb:
+            P = np.ascontiguousarray(np.load(a.baseline_emb), dtype=np.float32)
+        elif cfg is None:
             if slot_tab is not None:
-                oracle.sgns_train_vocab_order(walks, a.window, 0.025, 1, 0, walks.size, 0, 0, slot_tab, UT, KT, a.seed, flags, P, N)
+                oracle.sgns_train_vocab_order(walks, a.window, 0.025, 1, 0, walks.size, 0, 0, slot_tab, UT, KT, tseed, flags, P, N)
             else:
-                oracle.sgns_train(walks, a.window, 0.025, 1, 0, walks.size, 0, 0, UT, KT, a.seed, flags, P, N)
+                oracle.sgns_train(walks, a.window, 0.025, 1, 0, walks.size, 0, 0, UT, KT, tseed, flags, P, N)
         else:
             L.hogwild_emul_train(n, a.d, walks.shape[0], walks.shape[1], p(walks, C.c_int32), a.window, 0.025, 1, 0, walks.size, 0, 0,
-                                 p(UT, C.c_float), p(KT, C.c_int32), a.seed, flags, p(P, C.c_float), p(N, C.c_float),
+                                 p(UT, C.c_float), p(KT, C.c_int32), tseed, flags, p(P, C.c_float), p(N, C.c_float),
                                  cfg['W'], cfg['L'], cfg['R'], cfg['ctr'], cfg['ctx'], cfg['neg'], st, p(counts, C.c_int32),
                                  0 if not cfg['hot'] else max(2, int(np.ceil(walks.size / ((cfg['W'] - 1) * (2 * cfg['R'] + 1) * cfg['hot'])))))
         el = time.time() - t
