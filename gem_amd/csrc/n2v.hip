@@ -114,6 +114,7 @@ struct SgnsKnobs {
     bool part = false;                // a bucket launch of the partitioned schedule (sgns_win_kernel<PART>: as-loaded window copies in global scratch, 3 wavefronts per SIMD)
     double duty = 1.0;                // fraction of a wavefront's time spent in pair steps (negative rows open); < 1 only for the buckets of the partitioned schedule
     double touch_scale = 1.0;         // factor on VocabStats::touch2 (bucket launches: the pairs of ONE bucket touch the rows of two partitions only: parts x duty)
+    int32_t fresh = 0;                // FRESH HOT ROWS (sgns.hpp, SgnsArgs::fresh): bit 0 hot centre words by returning atomics, bit 1 hot negatives re-read before the dot products
     bool node_id_layout = false;      // the unigram table the launch draws from is in node-id order (gemhip_n2v_build_unigram), not the binary's: half the concurrent-touch bound (plan_sgns_launch)
 };
 // ... and what a launch of TrainModel over `nwalks` walks then looks like (pure host arithmetic: gemhip_sgns_plan_launch exposes it to the CPU tests)
@@ -499,6 +500,7 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     if (const char *e = getenv("GEMHIP_SGNS_PREFETCH")) h->kn.prefetch = std::min(2, std::max(1, atoi(e)));
     if (const char *e = getenv("GEMHIP_SGNS_RELOAD")) h->kn.reload = atoi(e) != 0;
     if (const char *e = getenv("GEMHIP_SGNS_HOT_COUNT")) h->kn.hot_count = std::max(-1, atoi(e));
+    if (const char *e = getenv("GEMHIP_SGNS_FRESH")) h->kn.fresh = atoi(e) & 3;
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
     phase_acc()[PH_HOST] += phase_now() - t_host0;
     PhaseScope ph_up(PH_H2D);
@@ -1184,6 +1186,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->kn.prefetch; A.reload = h->kn.reload; A.counts = nullptr; A.hot_thr = 0;
     A.parts = 0; A.ctx_part = 0; A.word_part = 0; A.seg = nullptr; A.nseg = 0; A.seg_len = 0; A.scratch = nullptr;
+    A.fresh = h->kn.fresh; A.stale_ver = nullptr; A.stale_hist = nullptr; A.n_nodes = h->n;
     SgnsKnobs kn_launch = h->kn;
     kn_launch.node_id_layout = !h->vocab_order;
     const SgnsLaunchPlan P = plan_sgns_launch(h->vs, kn_launch, h->n, h->d, window, h->walk_len, walk_hi - walk_lo, flags);
@@ -1202,6 +1205,14 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
             h->dummy_bytes = need;
         }
         A.dummy = h->d_dummy;
+#ifdef GEMHIP_SGNS_STALENESS
+        static unsigned int *d_sver = nullptr; static unsigned long long *d_shist = nullptr; static int64_t sver_n = 0;
+        if (sver_n < h->n) { if (d_sver) hipFree(d_sver); GEMHIP_CHECK(hipMalloc(&d_sver, (size_t)h->n * 2 * sizeof(unsigned int))); sver_n = h->n; }
+        if (!d_shist) GEMHIP_CHECK(hipMalloc(&d_shist, 3 * 32 * 16 * sizeof(unsigned long long)));
+        GEMHIP_CHECK(hipMemset(d_sver, 0, (size_t)h->n * 2 * sizeof(unsigned int)));
+        GEMHIP_CHECK(hipMemset(d_shist, 0, 3 * 32 * 16 * sizeof(unsigned long long)));
+        A.stale_ver = d_sver; A.stale_hist = d_shist;
+#endif
 #ifdef GEMHIP_SGNS_PROFILE
         static unsigned long long *d_prof = nullptr;
         if (!d_prof) GEMHIP_CHECK(hipMalloc(&d_prof, 64));
@@ -1213,6 +1224,32 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
     fn(A, P.blocks, P.threads, P.lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());
+#ifdef GEMHIP_SGNS_STALENESS
+    if (P.window) {      // one JSON line per launch: {"waves", "hot_thr", "fresh", "hist": {class: {log2 count: [launches by bit length of the foreign-update count]}}}
+        std::vector<unsigned long long> hh(3 * 32 * 16);
+        GEMHIP_CHECK(hipDeviceSynchronize());
+        GEMHIP_CHECK(hipMemcpy(hh.data(), A.stale_hist, hh.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        FILE *fo = getenv("GEMHIP_SGNS_STALENESS_OUT") ? fopen(getenv("GEMHIP_SGNS_STALENESS_OUT"), "a") : stderr;
+        if (fo) {
+            fprintf(fo, "{\"waves\": %lld, \"hot_thr\": %d, \"fresh\": %d, \"vocab_order\": %d, \"hist\": {", (long long)P.waves, (int)P.hot_thr, (int)A.fresh, (int)h->vocab_order);
+            const char *cls[3] = {"negative", "centre", "context"};
+            for (int c = 0; c < 3; ++c) {
+                fprintf(fo, "%s\"%s\": {", c ? ", " : "", cls[c]);
+                bool first = true;
+                for (int hb = 0; hb < 32; ++hb) {
+                    unsigned long long tot = 0; for (int sb = 0; sb < 16; ++sb) tot += hh[(c * 32 + hb) * 16 + sb];
+                    if (!tot) continue;
+                    fprintf(fo, "%s\"%d\": [", first ? "" : ", ", hb); first = false;
+                    for (int sb = 0; sb < 16; ++sb) fprintf(fo, "%s%llu", sb ? ", " : "", hh[(c * 32 + hb) * 16 + sb]);
+                    fprintf(fo, "]");
+                }
+                fprintf(fo, "}");
+            }
+            fprintf(fo, "}}\n");
+            if (fo != stderr) fclose(fo);
+        }
+    }
+#endif
 #ifdef GEMHIP_SGNS_PROFILE
     if (P.window) {
         unsigned long long hp[8];
@@ -1277,6 +1314,7 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     A.SynPos = (float *)dSynPos_part; A.SynNeg = (float *)dSynNeg_part; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.prefetch = 2; A.reload = 1; A.counts = h->d_counts; A.hot_thr = 0;
     A.parts = h->parts; A.ctx_part = ctx_part; A.word_part = word_part; A.seg = (const int64_t *)d_seg; A.nseg = nseg; A.seg_len = seg_len;
+    A.fresh = h->kn.fresh; A.stale_ver = nullptr; A.stale_hist = nullptr; A.n_nodes = h->n;
     // the launch rule of gemhip_sgns_train on the rows in play: the negative rows are those of partition word_part (n_eff of ITS restricted unigram
     // distribution bounds the Hogwild width: rho = W x 5 x 0.4 / n_eff <= 1.5 %); hot rows are judged on the GLOBAL token counts (a hub sits in
     // W x (2R+1) x count / tokens windows whatever partition it belongs to)

@@ -39,6 +39,12 @@ struct SgnsArgs {
     // walk id = walk_id_offset + wl
     const int64_t *seg; int32_t nseg; int64_t seg_len;
     float *scratch;             // sgns_win_kernel<PART, DELTA>: nwaves x (2R+1) rows -- the window rows as loaded (delta write-back), kept out of LDS
+    // FRESH HOT ROWS (round 6; Hogwild launches that have hot rows).  bit 0: a hot centre word's positive row SynNeg[word] takes every pair's update as a
+    // RETURNING atomic add -- the next pair computes with the row as memory held it one pair step ago (what came back + this pair's own change), not with
+    // the copy loaded at the centre's start, ~10 pair steps old by the centre's end.  bit 1: hot negative rows are fetched AGAIN right before the dot
+    // products, so the gradient is computed from the row as it is now and not from the copy requested two pairs ahead.
+    int32_t fresh;
+    unsigned int *stale_ver; unsigned long long *stale_hist; int64_t n_nodes;   // GEMHIP_SGNS_STALENESS builds only (see STALE below)
 };
 
 using sgns_fn = void (*)(const SgnsArgs &, int blocks, int threads, size_t lds, hipStream_t);
@@ -291,6 +297,23 @@ __global__ __launch_bounds__(256) void sgns_kernel(SgnsArgs A)
 #define PROF_WAIT_VM(n)
 #endif
 
+// GEMHIP_SGNS_STALENESS builds (scripts/build_variant.sh stale -DGEMHIP_SGNS_STALENESS): HOW STALE is the copy a gradient is computed from?  Every row
+// carries an update counter (stale_ver[t] for SynNeg[t], stale_ver[n + v] for SynPos[v], bumped by whoever applies an update); a wavefront notes the
+// counter when it loads a row and again when it applies its update -- the difference is the number of FOREIGN updates the row took in between, i.e. the
+// number of gradients that were computed concurrently from the same base.  Histogram stale_hist[class][floor(log2 count)][bit length of the difference]:
+// class 0 a negative target, 1 the centre word's positive row (per pair), 2 an uncached (hot) context row.
+#ifdef GEMHIP_SGNS_STALENESS
+#define STALE(...) __VA_ARGS__
+__device__ __forceinline__ void stale_rec(unsigned long long *hist, int cls, int cnt, unsigned int diff)
+{
+    const int hb = 31 - __clz(cnt > 1 ? cnt : 1), sb = diff == 0u ? 0 : (32 - __clz(diff) > 15 ? 15 : 32 - __clz(diff));
+    atomicAdd(hist + (cls * 32 + hb) * 16 + sb, 1ull);
+}
+__device__ __forceinline__ unsigned int stale_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+#define STALE(...)
+#endif
+
 // ---- window-cached TrainModel (default since round 2) ------------------------------------------------------------
 // Same arithmetic, same order and same Philox draws as sgns_kernel; what changes is WHERE the context rows live.
 // A token is a context of every centre within `window` positions, so sgns_kernel moves its SynPos row 2 x ~11 times.
@@ -346,6 +369,7 @@ template <int VEC, int NV>
 struct NegSet {
     int32_t tv;                 // lanes 0..4: the five targets (lane form, for the any-match test)
     int32_t cnt;                // lanes 0..4: their token counts (instantiations that handle hot rows: fetched with the rows)
+    STALE(unsigned int ver;)    // lanes 0..4: the targets' update counters when their rows were requested
     int32_t tgt[SGNS_NEG];
     float y[SGNS_NEG][NV][VEC]; // their SynNeg rows (in flight, then updated in place)
 };
@@ -679,6 +703,11 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 
             float yp[NV][VEC], yp0[NV][VEC];                         // the centre's positive row SynNeg[word] (and, RELOAD, as it was loaded)
             float *pp = A.SynNeg + (int64_t)(word >= 0 ? word : 0) * d;
+            // FRESH HOT ROWS, bit 0: the centre word is a hot row -> its positive row is refreshed by every pair's returning atomic add (pos_update)
+            bool word_hot = false;
+            if constexpr (!ALLC && RELOAD)
+                word_hot = (A.fresh & 1) && word >= 0 && A.hot_thr > 0 && A.counts[PART ? (int64_t)word * A.parts + A.word_part : (int64_t)word] >= A.hot_thr;
+            STALE(unsigned int ver_c = 0u; int cnt_c = 1;)
             if (word >= 0) {
                 const int64_t t = A.token_offset + wl * len + pos;
                 const int64_t tq = t - (t % 10000);
@@ -689,6 +718,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 const int32_t *ncur = negs + ((PART && whole) ? par : (pos & 1)) * nsamp;
 
                 g_ld(pp, yp);
+                STALE(if constexpr (!PART) { ver_c = stale_load(A.stale_ver + word); cnt_c = A.counts[word]; })
                 if constexpr (RELOAD) {
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
@@ -745,6 +775,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     Q.tv = ncur[ai * SGNS_NEG + (lane < SGNS_NEG ? lane : 0)];
                     if (lane >= SGNS_NEG || !live) Q.tv = -1;
                     if constexpr (!ALLC && RELOAD) Q.cnt = A.counts[Q.tv >= 0 ? (PART ? (int64_t)Q.tv * A.parts + A.word_part : (int64_t)Q.tv) : 0];      // one 4-byte gather per pair, in flight with the rows
+                    STALE(if constexpr (!PART) { if constexpr (ALLC || !RELOAD) Q.cnt = A.counts[Q.tv >= 0 ? Q.tv : 0]; Q.ver = stale_load(A.stale_ver + (Q.tv >= 0 ? Q.tv : 0)); })
 #pragma unroll
                     for (int j = 0; j < SGNS_NEG; ++j) {
                         Q.tgt[j] = __builtin_amdgcn_readlane(Q.tv, j);
@@ -766,6 +797,42 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     for (int k = 0; k < VEC; ++k) asm volatile("" ::"v"(yp[c][k]));
                 PROF_LAP(6);                                         // centre set-up: alpha, window draw, masks, centre row request, first prefetches, entering row -> LDS
 
+                // the positive target's update, gradient scale g0, context row xc: neu1e += g0 * yp (the copy the gradient was computed from), then
+                // yp += g0 * xc -- in registers, or (hot centre word, FRESH bit 0) as a returning atomic add whose result is the row as memory holds it now
+                auto pos_update = [&](float g0, const float (&xc)[NV][VEC], float (&neu)[NV][VEC]) __attribute__((always_inline)) {
+                    bool atomic_path = false;
+                    if constexpr (!ALLC && RELOAD) atomic_path = word_hot;
+                    if (atomic_path) {
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) {
+                                neu[c][k] = fmaf(g0, yp[c][k], neu[c][k]);
+                                const float dl = g0 * xc[c][k];
+                                float old = 0.f;
+                                if ((c * WAVE + lane) * VEC + k < dg)
+                                    old = __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pp + (c * WAVE + lane) * VEC + k), dl);
+                                yp[c][k] = (c * WAVE + lane) * VEC + k < dg ? old + dl : 0.f;
+                                yp0[c][k] = yp[c][k];
+                            }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NV; ++c)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) {
+                                neu[c][k] = fmaf(g0, yp[c][k], neu[c][k]);
+                                yp[c][k] = fmaf(g0, xc[c][k], yp[c][k]);
+                            }
+                    }
+#ifdef GEMHIP_SGNS_STALENESS
+                    if constexpr (!PART) {
+                        if (lane == 0) {
+                            if (atomic_path) { const unsigned int v = atomicAdd(A.stale_ver + word, 1u); stale_rec(A.stale_hist, 1, cnt_c, v - ver_c); ver_c = v + 1u; }
+                            else stale_rec(A.stale_hist, 1, cnt_c, stale_load(A.stale_ver + word) - ver_c);
+                        }
+                    }
+#endif
+                };
                 // one (centre, context) pair: C holds its negative rows, the sets in between are in flight, P2 is free
                 auto step = [&](NegSet<VEC, NV> &C, NegSet<VEC, NV> &P2) __attribute__((always_inline)) {
                     PROF_LAP(0);                                     // outside the pair steps (per-centre work, loop control)
@@ -779,10 +846,12 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     float *lrow = rowsL + (size_t)((ALLC || chit) ? (int)__builtin_ctzll(chit) : S) * RW;
                     float *pc = A.SynPos + (int64_t)ctx * d;
                     float xc[NV][VEC], neu[NV][VEC];
+                    STALE(unsigned int ver_x = 0u;)
                     if constexpr (!ALLC)
                         if (!chit) {        // beyond the cached radius: stage through LDS so that the wait for this row stays inside the branch
                             float t[NV][VEC];
                             g_ld(pc, t);
+                            STALE(if constexpr (!PART) ver_x = stale_load(A.stale_ver + A.n_nodes + ctx);)
                             lds_st(lrow, t);
                         }
                     lds_ld(lrow, xc);
@@ -804,6 +873,18 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                     }
                     if (!((spec_cur >> ai_c) & 1u)) {
                         // fast path: the six targets are distinct rows and none is the centre word -> six independent updates
+                        // hot negative rows (hubs drawn as negatives by many wavefronts at once): their update is an atomic add of g * xc -- no
+                        // window at all -- and the row-sized store goes to the scratch row instead (the number of loads / stores per pair stays static)
+                        unsigned hotm = 0u;
+                        if constexpr (!ALLC && RELOAD) {
+                            hotm = A.hot_thr > 0 ? (unsigned)__builtin_amdgcn_ballot_w64(lane < SGNS_NEG && C.cnt >= A.hot_thr) : 0u;
+                            if ((A.fresh & 2) && hotm) {         // FRESH bit 1: the gradient of a hot row is computed from the row as it is NOW
+#pragma unroll
+                                for (int j = 0; j < SGNS_NEG; ++j)
+                                    if ((hotm >> j) & 1u) g_ld(A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                                STALE(if constexpr (!PART) { if (lane < SGNS_NEG && ((hotm >> lane) & 1u)) C.ver = stale_load(A.stale_ver + C.tv); })
+                            }
+                        }
                         float part[6];
 #pragma unroll
                         for (int j = 0; j < 6; ++j) part[j] = 0.f;
@@ -825,13 +906,12 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                         float g[6];
 #pragma unroll
                         for (int j = 0; j < 6; ++j) g[j] = bcast_lane(gl, j);
-#pragma unroll
-                        for (int c = 0; c < NV; ++c)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) {
-                                neu[c][k] = fmaf(g[0], yp[c][k], neu[c][k]);
-                                yp[c][k] = fmaf(g[0], xc[c][k], yp[c][k]);
-                            }
+                        pos_update(g[0], xc, neu);
+#ifdef GEMHIP_SGNS_STALENESS
+                        if constexpr (!PART) {
+                            if (lane < SGNS_NEG && C.tv >= 0) { const unsigned int v = atomicAdd(A.stale_ver + C.tv, 1u); stale_rec(A.stale_hist, 0, C.cnt, v - C.ver); }
+                        }
+#endif
                         if constexpr (RELOAD) {
 #pragma unroll
                             for (int j = 0; j < SGNS_NEG; ++j)
@@ -839,10 +919,6 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                                 for (int c = 0; c < NV; ++c)
 #pragma unroll
                                     for (int k = 0; k < VEC; ++k) neu[c][k] = fmaf(g[j + 1], C.y[j][c][k], neu[c][k]);
-                            // hot negative rows (hubs drawn as negatives by many wavefronts at once): their update is an atomic add of g * xc -- no
-                            // window at all -- and the row-sized store goes to the scratch row instead (the number of loads / stores per pair stays static)
-                            unsigned hotm = 0u;
-                            if constexpr (!ALLC) hotm = A.hot_thr > 0 ? (unsigned)__builtin_amdgcn_ballot_w64(lane < SGNS_NEG && C.cnt >= A.hot_thr) : 0u;
 #pragma unroll
                             for (int j = 0; j < SGNS_NEG; ++j) {
                                 const bool hotj = (hotm >> j) & 1u;
@@ -886,10 +962,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
 #pragma unroll
                                 for (int k = 0; k < VEC; ++k) part = fmaf(xc[c][k], yp[c][k], part);
                             const float g = sgns_grad(wave_sum(part), 1.0f, alpha);
-#pragma unroll
-                            for (int c = 0; c < NV; ++c)
-#pragma unroll
-                                for (int k = 0; k < VEC; ++k) { neu[c][k] = fmaf(g, yp[c][k], neu[c][k]); yp[c][k] = fmaf(g, xc[c][k], yp[c][k]); }
+                            pos_update(g, xc, neu);
                         }
 #pragma unroll
                         for (int j = 0; j < SGNS_NEG; ++j) {
@@ -928,6 +1001,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                             for (int k = 0; k < VEC; ++k)
                                 if ((c * WAVE + lane) * VEC + k < dg)
                                     __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pc + (c * WAVE + lane) * VEC + k), neu[c][k]);
+                        STALE(if constexpr (!PART) { if (lane == 0) { const unsigned int v = atomicAdd(A.stale_ver + A.n_nodes + ctx, 1u); stale_rec(A.stale_hist, 2, A.counts[ctx], v - ver_x); } })
                     } else g_st(pc, xc);
                     PROF_LAP(4);                                     // arithmetic + stores
                 };
@@ -991,7 +1065,8 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                 }
             }
             // ---- stores only from here on
-            if (word >= 0) {
+            STALE(if constexpr (!PART) { if (word >= 0 && !word_hot && lane == 0) atomicAdd(A.stale_ver + word, 1u); })
+            if (word >= 0 && !word_hot) {           // (a hot centre word under FRESH bit 0 has already added every pair's change)
 #pragma unroll
                 for (int c = 0; c < NV; ++c) {
                     if ((c * WAVE + lane) * VEC < dg) {

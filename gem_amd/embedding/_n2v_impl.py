@@ -22,6 +22,21 @@ def learn(model, graph):
         seed = int(np.random.randint(0, 2 ** 31 - 1))
     flags = int(getattr(model, '_flags', _hip.N2V_SNAP_LAYOUT))       # the binary's quirks AND its unigram-table layout (include/gem_hip.h)
     _hip.require_device()
+    # n_gpus / devices / virtual_ranks / episodes kwargs (gem_amd/embedding/_multi.py): walks by start-node shard, SGNS over partitioned tables
+    from gem_amd.embedding import _multi
+    mode, n_gpus, devices = _multi.resolve(model)
+    if mode != 'single':
+        if mode == 'spmd':                        # every rank must train with the same seed: rank 0's draw is everyone's
+            seed = int(_multi.broadcast_from_rank0(np.array([seed], dtype=np.int64))[0])
+            X, st = _multi.n2v_spmd(model, n, row_ptr, col, ww, seed, flags)
+        else:
+            X, st = _multi.n2v_capi(model, n, row_ptr, col, ww, seed, flags, n_gpus, devices)
+        t2 = time.perf_counter()
+        model._stats = st
+        model._node_num = n
+        X64 = X.astype(np.float64)
+        model._api_wall = _hip.api_wall(t0, t1, t2, time.perf_counter())
+        return X64
     X = np.empty((n, d), dtype=np.float32)
     stats = (C.c_double * 4)()
     _hip.check(_hip.lib().gemhip_n2v_train(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32),

@@ -20,6 +20,10 @@ its verbose flag, as gf.py:62 does): before every `print_step`-th sweep the iter
 id and the objective f1 + f2 of gf.cpp:94-113 (f1 over all edges, f2 = ||X||_F^2),
 also kept in `self._objective_log`.
 
+`n_gpus=N` (with `devices=[...]` or `virtual_ranks=True`; gem_amd/embedding/_multi.py) shards the source rows over N GPUs -- one process driving N
+devices through gemhip_gf_train_multi, or one process per GPU under torch.distributed -- with an all-gather of the owned row blocks after every sweep:
+the same table as one GPU, bit for bit.
+
 Edge order.  The sweep kernel reproduces the reference's Gauss-Seidel order exactly with two table copies, which needs every
 row a firing edge READS to have had all or none of its own updates of that sweep at that point of the edge list.  That holds for
 graph.edges() of any networkx graph and for saveGraphToEdgeListTxt files (edges grouped by source) -- every call site of the
@@ -61,6 +65,23 @@ class GraphFactorization(StaticGraphEmbedding):
         _hip.require_device()
         L = _hip.lib()
         verbose = bool(getattr(self, '_verbose', False))
+        # n_gpus / devices / virtual_ranks kwargs (gem_amd/embedding/_multi.py): source rows sharded over N GPUs, all-gather of the owned blocks per sweep --
+        # bit-identical to one GPU.  The initial table is gf.py:92's numpy draw (RandomState(seed), or numpy's global stream), identical on every rank
+        from gem_amd.embedding import _multi
+        mode, n_gpus, devices = _multi.resolve(self)
+        if mode != 'single':
+            if verbose:
+                raise ValueError('verbose=True (the objective print of gf.cpp:144-151) is a single-GPU option; n_gpus=%d' % n_gpus)
+            rng = np.random if seed is None else np.random.RandomState(seed)
+            X0 = (0.01 * rng.randn(n, d)).astype(np.float32)          # gf.py:92
+            if mode == 'spmd' and seed is None:                       # numpy's global stream differs between processes: rank 0's draw is everyone's
+                X0 = _multi.broadcast_from_rank0(X0)
+            t_init = time.perf_counter()
+            self._stats = _multi.gf_capi(self, n, src, dst, w, X0, n_gpus, devices) if mode == 'capi' else _multi.gf_spmd(self, n, src, dst, w, X0)
+            t_called = time.perf_counter()
+            self._X = X0.astype(np.float64)
+            self._api_wall = _hip.api_wall(t_begin, t_init, t_called, time.perf_counter())
+            return self._X
         # device_init: explicit, else ON when `seed` is given (a seeded run does not need numpy's stream, and at 1M x 128 numpy's randn is 80 % of the
         # call: bench.py api_wall, round 4) -- np.random.seed()-controlled runs (no `seed` kwarg: the reference's own convention) keep gf.py:92's draw
         device_init = getattr(self, '_device_init', None)

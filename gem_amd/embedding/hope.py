@@ -22,6 +22,9 @@ class HOPE(StaticGraphEmbedding):
     def learn_embedding(self, graph=None, edge_f=None, is_weighted=False, no_python=False, **_ignored):
         if not graph:
             raise ValueError('graph needed')
+        if getattr(self, '_n_gpus', 1) not in (1, None):
+            # HOPE is "replicas only" -- cfg3 fits one GPU and north_star shards GF and node2vec; there is no N-GPU HOPE to fall back from silently
+            raise ValueError('HOPE does not shard (n_gpus=%r): run one replica per GPU' % (self._n_gpus,))
         from gem_amd.embedding import _hope_impl
         self._X = _hope_impl.learn(self, graph)
         return self._X

@@ -5,6 +5,10 @@ gem/c_exe/node2vec with `-i -o -d -l -r -k -e -p -q -v -dr -w`.
 Here the same three phases (transition tables, biased walks, skip-gram with negative
 sampling) run in libgem_hip.so: gem_amd/csrc/n2v.hip (n2v_alias_rows_kernel, n2v_walk_kernel, n2v_vocab_kernel) and
 gem_amd/csrc/sgns.hpp (sgns_win_kernel) through gemhip_n2v_train (include/gem_hip.h).
+
+Backend kwargs (kept on the instance like every GEM hyper-parameter): `seed`, `flags` (the binary's quirks and table layout, include/gem_hip.h),
+and `n_gpus=N` with `devices=[...]` / `virtual_ranks=True` / `episodes=64` (gem_amd/embedding/_multi.py): walks sharded by start node, skip-gram over
+partitioned tables -- gemhip_n2v_train_multi in one process, or gem_amd.multi_gpu.Node2VecPartitioned with one process per GPU under torch.distributed.
 """
 import numpy as np
 

@@ -21,7 +21,8 @@ import numpy as np
 
 class StaticGraphEmbedding(object):
     hyper_params = {}
-    backend_params = ('seed', 'device_init', 'flags', 'tol', 'oversample', 'krylov_steps', 'max_restarts', 'regroup_edges', 'verbose')
+    backend_params = ('seed', 'device_init', 'flags', 'tol', 'oversample', 'krylov_steps', 'max_restarts', 'regroup_edges', 'verbose',
+                      'n_gpus', 'devices', 'virtual_ranks', 'episodes')
 
     def __init__(self, *args, **kwargs):
         self._method_name = None

@@ -399,6 +399,87 @@ void oracle_sgns_train_vocab_order(int64_t n_slots, const int32_t *slot_tab, int
                     UT, KT, seed, flags, SynPos, SynNeg);
 }
 
+/* The SAME TrainModel restatement with the dot product X_ctx . Y_target accumulated in 32 interleaved partial sums (k mod 32) instead of one
+ * running sum -- the only arithmetic difference from sgns_train_core (the device sums it across 64 lanes, a reordering of the same class); the row
+ * updates, the sigmoid, every draw and the order of the pairs are those of sgns_train_core.  It exists because the strict loop's 128 dependent
+ * additions per target make an R-MAT scale 22 pass (3.2e9 tokens) a 15-hour run; this one also computes a pair's six targets before it touches them
+ * and prefetches their rows.  tests/test_oracle_n2v.py ties it to the strict function (max |difference| after a small pass at fp32 rounding level);
+ * goldens made with it say so in their `engine`.  d must be a multiple of 32.  slot_tab as in sgns_train_core (NULL: slot == entry). */
+typedef float v8f __attribute__((vector_size(32), aligned(4)));
+__attribute__((target("avx2")))
+int32_t oracle_sgns_train_wide(int64_t n_slots, const int32_t *slot_tab, int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks,
+                               int32_t window, int32_t neg, float alpha0, int32_t epochs, int32_t epoch, int64_t tokens_total,
+                               int64_t token_offset, int64_t walk_id_offset, const float *UT, const int32_t *KT, uint64_t seed,
+                               int32_t flags, float *SynPos, float *SynNeg)
+{
+    (void)flags;
+    if (d % 32 != 0 || neg > 15) return -1;
+    float *neu1e = (float *)aligned_alloc(64, sizeof(float) * (size_t)d);
+    const int64_t denom = (int64_t)epochs * tokens_total + 1;
+    for (int64_t wl = 0; wl < nwalks; ++wl) {
+        const int32_t *walk = walks + wl * walk_len;
+        const int64_t wid = walk_id_offset + wl;
+        for (int32_t pos = 0; pos < walk_len; ++pos) {
+            const int64_t t = token_offset + wl * walk_len + pos;
+            const float alpha = sgns_alpha(alpha0, t, denom);
+            const int32_t word = walk[pos];
+            if (word < 0) continue;
+            const u32x4 rw = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos, TAG_WIN | ((uint32_t)epoch << 8));
+            const int32_t b = (int32_t)(rw.x % (uint32_t)window);
+            for (int32_t a = b; a < window * 2 + 1 - b; ++a) {
+                if (a == window) continue;
+                const int32_t cp = pos - window + a;
+                if (cp < 0 || cp >= walk_len) continue;
+                const int32_t ctx = walk[cp];
+                if (ctx < 0) continue;
+                float *xc = SynPos + (size_t)ctx * d;
+                int32_t tg[16];
+                tg[0] = word;
+                for (int32_t j = 1; j < neg + 1; ++j) {
+                    const u32x4 rn = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32),
+                                            (uint32_t)pos | ((uint32_t)a << 16), TAG_NEG | ((uint32_t)epoch << 8) | ((uint32_t)j << 16));
+                    const uint32_t slot = mulhi_range(rn.x, (uint32_t)n_slots);
+                    const int32_t X = slot_tab ? slot_tab[slot] : (int32_t)slot;
+                    const int32_t target = (u01(rn.y) < UT[X]) ? X : KT[X];
+                    tg[j] = (target == word) ? -1 : target;
+                    if (tg[j] >= 0) {
+                        const char *q = (const char *)(SynNeg + (size_t)target * d);
+                        for (int32_t c = 0; c < d * 4; c += 64) __builtin_prefetch(q + c, 1, 1);
+                    }
+                }
+                for (int32_t k = 0; k < d; k += 8) *(v8f *)(neu1e + k) = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
+                for (int32_t j = 0; j < neg + 1; ++j) {
+                    if (tg[j] < 0) continue;
+                    const float label = j == 0 ? 1.0f : 0.0f;
+                    float *yt = SynNeg + (size_t)tg[j] * d;
+                    v8f a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+                    for (int32_t k = 0; k < d; k += 32) {
+                        a0 += *(const v8f *)(xc + k) * *(const v8f *)(yt + k);
+                        a1 += *(const v8f *)(xc + k + 8) * *(const v8f *)(yt + k + 8);
+                        a2 += *(const v8f *)(xc + k + 16) * *(const v8f *)(yt + k + 16);
+                        a3 += *(const v8f *)(xc + k + 24) * *(const v8f *)(yt + k + 24);
+                    }
+                    const v8f s = (a0 + a1) + (a2 + a3);
+                    const float f = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+                    float g;
+                    if (f > 6.0f) g = (label - 1.0f) * alpha;
+                    else if (f < -6.0f) g = label * alpha;
+                    else g = (label - 1.0f + 1.0f / (1.0f + expf(f))) * alpha;
+                    const v8f gv = {g, g, g, g, g, g, g, g};
+                    for (int32_t k = 0; k < d; k += 8) {
+                        const v8f y = *(const v8f *)(yt + k);
+                        *(v8f *)(neu1e + k) += gv * y;
+                        *(v8f *)(yt + k) = y + gv * *(const v8f *)(xc + k);
+                    }
+                }
+                for (int32_t k = 0; k < d; k += 8) *(v8f *)(xc + k) += *(const v8f *)(neu1e + k);
+            }
+        }
+    }
+    free(neu1e);
+    return 0;
+}
+
 void oracle_sgns_init(int64_t n, int32_t d, uint64_t seed, float *SynPos, float *SynNeg)
 {
     const int64_t total = n * (int64_t)d;

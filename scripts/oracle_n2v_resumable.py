@@ -21,13 +21,21 @@ ap.add_argument('--flags', type=int, default=27)
 ap.add_argument('--out', default=None)
 ap.add_argument('--chunk-walks', type=int, default=150000)
 ap.add_argument('--selftest', action='store_true')
+ap.add_argument('--wide', action='store_true', help='oracle_sgns_train_wide: the dot product in 32 partial sums (about 4x the speed; the engine string says so)')
+ap.add_argument('--walks-cache', default=None, help='.npy the walk matrix is written to / memory-mapped from (the two layouts train on the same walks: one copy in the page cache)')
 a = ap.parse_args()
 D, L, R, WIN, SEED = 128, 80, 10, 10, 20260923
 
 
-def run(n, src, dst, flags, out, chunk, d=D, l=L, r=R):
-    rp, cs, _ = oracle.sorted_csr(n, src, dst, None)
-    walks = oracle.n2v_walks(rp, cs, None, None, 1.0, 1.0, r, l, SEED, flags)
+def run(n, src, dst, flags, out, chunk, d=D, l=L, r=R, wide=False, walks_cache=None):
+    if walks_cache and os.path.exists(walks_cache):
+        walks = np.load(walks_cache, mmap_mode='r')
+    else:
+        rp, cs, _ = oracle.sorted_csr(n, src, dst, None)
+        walks = oracle.n2v_walks(rp, cs, None, None, 1.0, 1.0, r, l, SEED, flags & ~16)     # (bit 16 is the unigram layout: the walks do not see it)
+        if walks_cache:
+            np.save(walks_cache + '.tmp.npy', walks); os.replace(walks_cache + '.tmp.npy', walks_cache)
+            walks = np.load(walks_cache, mmap_mode='r')
     tot = walks.size
     cnt = oracle.n2v_vocab(n, walks)
     if flags & 16:
@@ -47,7 +55,10 @@ def run(n, src, dst, flags, out, chunk, d=D, l=L, r=R):
         z = min(len(walks), done + chunk)
         t = time.time()
         w = np.ascontiguousarray(walks[done:z])
-        if flags & 16:
+        if wide:
+            if flags & 16: oracle.sgns_train_wide(w, WIN, 0.025, 1, 0, tot, done * l, done, slot_tab, UTn, KTn, SEED, flags, P, N)
+            else: oracle.sgns_train_wide(w, WIN, 0.025, 1, 0, tot, done * l, done, None, UT, KT, SEED, flags, P, N)
+        elif flags & 16:
             oracle.sgns_train_vocab_order(w, WIN, 0.025, 1, 0, tot, done * l, done, slot_tab, UTn, KTn, SEED, flags, P, N)
         else:
             oracle.sgns_train(w, WIN, 0.025, 1, 0, tot, done * l, done, UT, KT, SEED, flags, P, N)
@@ -69,15 +80,19 @@ if a.selftest:
         P, _ = run(n, src, dst, flags, tmp, 777, d=16, l=30, r=2)
         X, _ = oracle.n2v_train(n, src, dst, None, 16, 30, 2, WIN, 1, 1.0, 1.0, SEED, flags)
         assert np.array_equal(P, X), flags
+        Pw, _ = run(n, src, dst, flags, tmp + '.w.npy', 777, d=32, l=30, r=2, wide=True, walks_cache=tmp + '.walks.npy')
+        Pw1, _ = run(n, src, dst, flags, tmp + '.w1.npy', 10 ** 9, d=32, l=30, r=2, wide=True, walks_cache=tmp + '.walks.npy')
+        assert np.array_equal(Pw, Pw1), flags
     print('selftest ok: chunked == one call, bit for bit, both layouts')
     sys.exit(0)
 
 g = rmat_graph(a.rmat_scale, a.edges, a.seed)
 n, src, dst, _, _ = edge_arrays(g)
-P, secs = run(n, src, dst, a.flags, a.out, a.chunk_walks)
+P, secs = run(n, src, dst, a.flags, a.out, a.chunk_walks, wide=a.wide, walks_cache=a.walks_cache)
 np.save(a.out, np.asarray(P, dtype=np.float32))
 PARAMS = dict(n=g.n, edges=a.edges, blocks=1, seed=a.seed, d=D, walk_len=L, num_walks=R, window=WIN, p=1.0, q=1.0, rmat_scale=a.rmat_scale, flags=a.flags)
 engine = 'oracle/n2v_oracle.c (sequential restatement of SNAP)' + (', unigram table in the binary\'s vocabulary-order layout' if a.flags & 16 else '') + \
+         (', oracle_sgns_train_wide (dot product in 32 interleaved partial sums)' if a.wide else '') + \
          '; run in resumable chunks (scripts/oracle_n2v_resumable.py)'
 json.dump({'seconds': secs, 'engine': engine, 'params': PARAMS}, open(a.out + '.json', 'w'))
 for f in ('.ckpt.P.npy', '.ckpt.N.npy', '.ckpt.json'):

@@ -55,6 +55,26 @@ def test_backend_only_kwargs_stay_on_the_instance():
     assert (n._seed, n._flags) == (9, 8) and not hasattr(node2vec(d=2), '_seed')
 
 
+def test_n_gpus_kwargs_resolve_to_a_driver_without_touching_a_device():
+    """n_gpus / devices / virtual_ranks / episodes are backend kwargs (knobs travel through the kwargs -> _attr mechanism of
+    static_graph_embedding.py:14-19); gem_amd.embedding._multi.resolve decides single GPU / one process with N devices / one process per GPU on the host."""
+    from gem_amd.embedding import _multi
+    assert _multi.resolve(GraphFactorization(d=4)) == ('single', 1, None)
+    assert _multi.resolve(GraphFactorization(d=4, n_gpus=1)) == ('single', 1, None)
+    assert _multi.resolve(GraphFactorization(d=4, n_gpus='world')) == ('single', 1, None)         # no process group: the world is one rank
+    assert _multi.resolve(node2vec(d=4, n_gpus=8)) == ('capi', 8, None)
+    assert _multi.resolve(node2vec(d=4, n_gpus=2, devices=[3, 5])) == ('capi', 2, [3, 5])
+    assert _multi.resolve(node2vec(d=4, n_gpus=4, virtual_ranks=True, episodes=16)) == ('capi', 4, [0, 0, 0, 0])
+    assert _multi.resolve(node2vec(d=4, n_gpus=1, virtual_ranks=True)) == ('capi', 1, [0])
+    for bad in (dict(n_gpus=0), dict(n_gpus=2.5), dict(n_gpus=True), dict(n_gpus=2, devices=[0]), dict(n_gpus=2, virtual_ranks=True, devices=[0, 1])):
+        with pytest.raises(ValueError):
+            _multi.resolve(node2vec(d=4, **bad))
+    assert 'n_gpus' not in node2vec.hyper_params and not hasattr(node2vec(d=4), '_n_gpus')
+    with pytest.raises(ValueError, match='does not shard'):
+        import networkx as nx
+        HOPE(d=4, beta=0.01, n_gpus=2).learn_embedding(graph=nx.path_graph(4).to_directed())
+
+
 def test_reconstructed_adj_sets_embedding_and_zero_diagonal():
     m = HOPE(d=4, beta=0.01)
     X = np.arange(12.0).reshape(3, 4)

@@ -240,3 +240,46 @@ def test_real_devices_n2v_train_multi_deterministic_equals_the_oracle_schedule(s
     want, pairs = _oracle_multi_schedule(n, src, dst, d, Lw, r, win, seed, flags, ranks, episodes)
     assert st[3] == pairs and st[5] == ranks and st[6] == 0.0
     assert np.abs(X - want).max() <= 2e-4 * np.abs(want).max() + 1e-6
+
+
+# ----------------------------------------------------------------------------------------------- n_gpus through the plugin API (round 6)
+@pytest.mark.parametrize('ranks', [2, 4])
+def test_plugin_gf_n_gpus_is_the_one_gpu_table(ranks):
+    """GraphFactorization(n_gpus=N, virtual_ranks=True).learn_embedding() -> gemhip_gf_train_multi: the same table as the one-GPU plugin call with the
+    same numpy draw (device_init=False), bit for bit; the stats say which driver ran."""
+    from gem_amd.embedding.gf import GraphFactorization
+    g = sbm_graph(1001, 10000, 4, seed=3)
+    kw = dict(d=32, eta=0.05, regu=0.01, max_iter=6, seed=5)
+    one = GraphFactorization(device_init=False, **kw)
+    X1 = one.learn_embedding(graph=g, is_weighted=True, no_python=True)
+    many = GraphFactorization(n_gpus=ranks, virtual_ranks=True, **kw)
+    XN = many.learn_embedding(graph=g, is_weighted=True, no_python=True)
+    assert XN.dtype == np.float64 and np.array_equal(X1, XN)
+    assert many._stats['driver'] == 'gemhip_gf_train_multi' and many._stats['n_gpus'] == ranks and many._stats['virtual_ranks']
+    assert 'n_gpus' not in GraphFactorization.hyper_params
+
+
+def test_plugin_node2vec_n_gpus_deterministic_is_the_capi_call(sbm1024):
+    """node2vec(n_gpus=3, virtual_ranks=True, episodes=4, flags=... | 4): the plugin hands exactly its hyper-parameters to gemhip_n2v_train_multi
+    (same embedding as the direct C-ABI call, which tests above tie to the oracle's schedule)."""
+    n, src, dst, w, _ = edge_arrays(sbm1024)
+    row_ptr, col, _ = to_csr(n, src, dst, None)
+    d, L, r, win, seed, flags = 16, 30, 1, 5, 7, 11 | 4
+    m = node2vec(d=d, max_iter=1, walk_len=L, num_walks=r, con_size=win, ret_p=1, inout_p=1, seed=seed, flags=flags, n_gpus=3, virtual_ranks=True, episodes=4)
+    X = m.learn_embedding(graph=sbm1024, is_weighted=True, no_python=True)
+    want = np.empty((n, d), np.float32)
+    _hip.check(_hip.lib().gemhip_n2v_train_multi(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), None, d, L, r, win, 1, 1.0, 1.0, seed,
+                                                 flags, 3, _devs(3), 4, _hip.ptr(want, C.c_float), None))
+    assert np.array_equal(X, want.astype(np.float64))
+    assert m._stats['driver'] == 'gemhip_n2v_train_multi' and m._stats['n_gpus'] == 3 and m._stats['pairs'] > 0
+
+
+def test_plugin_n_gpus_never_falls_back_to_one_gpu():
+    """Two REAL ranks on the one-GPU box: the library's error comes through as GemHipError -- not a silent single-GPU run."""
+    from gem_amd.embedding.gf import GraphFactorization
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a box with ONE GPU')
+    g = sbm_graph(512, 4000, 2, seed=1)
+    with pytest.raises(_hip.GemHipError):
+        GraphFactorization(d=8, eta=0.05, regu=0.01, max_iter=2, seed=1, n_gpus=2).learn_embedding(graph=g)
