@@ -365,20 +365,27 @@ class N2VWorkload(object):
         return out
 
     def launch_plan(self):
-        """What gemhip_sgns_train chose for this corpus (the rule of DESIGN.md 3.3, recomputed from the token counts by gemhip_sgns_plan_launch;
-        environment overrides of the knobs are not reflected)."""
+        """What gemhip_sgns_train actually launched in the last pass: read back from the handle (gemhip_sgns_last_launch -- the planner's choice after
+        every knob and environment override, for the handle's own table layout), with the rule's inputs (n_eff over all / the cold rows)
+        recomputed from the token counts for the SAME layout flags.  (Round 5 replayed the planner with the node-id layout's flags while the timed pass
+        ran the vocabulary-order table: the line said 104 wavefronts for a pass that ran at 207.)"""
         try:
             if self.world != 1:
                 return None
+            L = _hip.lib()
+            k, w, hot, fresh = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            _hip.check(L.gemhip_sgns_last_launch(self.b.h, C.byref(k), C.byref(w), C.byref(hot), C.byref(fresh)))
             cnt = np.ascontiguousarray(self.b.counts.cpu().numpy(), dtype=np.int32)
-            k, w, hot, ne, nec = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double(), C.c_double()
+            flags = _hip.N2V_SNAP_LAYOUT if getattr(self.b, 'vocab_order', False) else _hip.N2V_SNAP_COMPAT
+            pk, pw, ph, ne, nec = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double(), C.c_double()
             a = self.args
-            _hip.check(_hip.lib().gemhip_sgns_plan_launch(_hip.ptr(cnt, C.c_int32), cnt.size, a.d, a.window, a.walk_len, self.job.hi - self.job.lo,
-                                                          _hip.N2V_SNAP_COMPAT, C.byref(k), C.byref(w), C.byref(hot), C.byref(ne), C.byref(nec)))
+            _hip.check(L.gemhip_sgns_plan_launch(_hip.ptr(cnt, C.c_int32), cnt.size, a.d, a.window, a.walk_len, self.job.hi - self.job.lo,
+                                                 flags, C.byref(pk), C.byref(pw), C.byref(ph), C.byref(ne), C.byref(nec)))
             return {'kernel': ['sgns_kernel', 'sgns_win_kernel (overwrite on leave)', 'sgns_win_kernel (Hogwild: delta write-back, reload-on-update)'][k.value],
                     'concurrent_wavefronts': w.value, 'hot_row_min_count': hot.value, 'hot_rows': int((cnt >= hot.value).sum()) if hot.value > 0 else 0,
-                    'n_eff': ne.value, 'n_eff_cold': nec.value,
-                    'rho': w.value * 5 * 0.4 / nec.value}
+                    'fresh_hot_rows_bits': fresh.value, 'unigram_layout_flags': flags,
+                    'source': 'gemhip_sgns_last_launch (the launch as it ran)', 'planner_without_overrides': {'concurrent_wavefronts': pw.value, 'hot_row_min_count': ph.value},
+                    'n_eff': ne.value, 'n_eff_cold': nec.value, 'rho': w.value * 5 * 0.4 / nec.value}
         except Exception as e:           # (an A/B library without the entry point)
             return {'error': str(e)[:200]}
 
@@ -430,6 +437,7 @@ class N2VWorkload(object):
             Xh = mh.learn_embedding(graph=gs, is_weighted=True, no_python=True)
             return {'value': runs[cores]['edges_per_s'], 'unit': self.unit, 'cores': cores, 'kind': 'reference',
                     'all_cores': runs[cores], 'single_thread_race_free': runs[1], 'committed_full_size_runs': self._full_size_runs(),
+                    'full_size_reference': self._full_size_reference(a.nodes),
                     'hip_map_same_sample': gr.evaluateStaticGraphReconstruction(gs, mh, Xh, None)[0],
                     'sample': 'gem/c_exe/node2vec (SNAP ELF) end to end incl. its text IO on an SBM with %d nodes / %d edges (same '
                               'density, block size, d, r, l, k): %d threads %.1fs, 1 thread %.1fs; MAP = graph reconstruction over all nodes of '
@@ -440,6 +448,18 @@ class N2VWorkload(object):
         el = (time.time() - t) * a.num_walks
         return {'value': gs.number_of_edges() / el, 'unit': self.unit, 'cores': 1, 'kind': 'port',
                 'sample': 'oracle/n2v_oracle.c, r=1 timed and scaled x%d (linear in tokens), SBM %d nodes' % (a.num_walks, n_s)}
+
+    @staticmethod
+    def _full_size_reference(nodes):
+        """The reference binary's OWN runs on the benchmark graph itself (committed records of hours-long CPU runs, tests/golden/n2v_ref_snap_<n>k*.json):
+        {threads: {edges_per_s, seconds, MAP}} -- carried in the compact line next to the 2048-node sample's rate."""
+        out = {}
+        for thr, f in ((1, 'n2v_ref_snap_%dk.json' % (nodes // 1000)), (4, 'n2v_ref_snap_%dk_t4.json' % (nodes // 1000))):
+            p = os.path.join(ROOT, 'tests', 'golden', f)
+            if os.path.exists(p):
+                j = json.load(open(p))
+                out['threads_%d' % thr] = {'edges_per_s': round(j['edges_per_s'], 1), 'seconds': round(j['seconds']), 'MAP': round(j['MAP'], 4)}
+        return out or None
 
     @staticmethod
     def _full_size_runs():
@@ -811,7 +831,7 @@ def time_workload(name, args, rank, world, comm, K=None, W=None, with_cpu=True):
 
 ROOFLINE_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'achieved_traffic_GBs', 'achieved_traffic_frac', 'avg_launch_us',
                  'algorithmic_bytes_per_launch', 'regime_short')
-CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample', 'full_size_reference', 'full_size')
 QUALITY_KEYS = ('sampled_map', 'nodes_sampled', 'unigram_layout_short', 'reference_map', 'map_minus_reference_map', 'map_minus_reference_map_se', 'oracle_map',
                 'map_minus_oracle_map', 'map_minus_oracle_map_se', 'bit_identical_to_one_gpu', 'deviation_relative_to_largest_change')
 MAX_LINE_BYTES = 4000        # the driver parses the LAST stdout line from a bounded tail: round 4's 23 KB line came back as parsed = null
@@ -1029,6 +1049,12 @@ def main():
             a7 = copy.copy(a6)
             extra['gf_rmat22'], w7 = time_workload('gf', a7, rank, world, comm, 20, 2, with_cpu=False)
             del w7
+            torch.cuda.empty_cache()
+            if time.time() - T_START < float(os.environ.get('GEM_BENCH_RMAT_PQ_DEADLINE_S', '780')):
+                # general (p, q) second-order walks at R-MAT scale (rejection sampling against the hubs' rows), (p, q) = (0.25, 4)
+                a9 = copy.copy(a6); a9.ret_p, a9.inout_q = 0.25, 4.0
+                extra['node2vec_rmat22_p0.25_q4'], w9 = time_workload('node2vec', a9, rank, world, comm, 1, 0, with_cpu=False)
+                del w9
             for k in ('node2vec_rmat20', 'node2vec_rmat22', 'gf_rmat22'):
                 extra[k]['cpu_baseline'] = {'value': None, 'kind': 'reference', 'note': 'not run: gem/c_exe/node2vec builds Sigma deg^2 second-order alias '
                                             'tables (max degree ~94k here) and exhausts host memory; gf.cpp per-edge rate: see gf_sbm1m_10m.cpu_baseline'}

@@ -61,6 +61,8 @@ _SIGS = {
     'gemhip_hope': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_float, C.c_uint64, f32p, f32p, f32p, f64p]),
     'gemhip_hope_svd_error': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, f32p, f32p, C.c_int32, C.c_uint64, f64p, f64p]),
+    'gemhip_hope_svd_error_uv': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_float, C.c_int32, f32p, f32p, f32p, C.c_int32, C.c_uint64, f64p, f64p, f64p]),
+    'gemhip_hope_plan_svd_error_uv': (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, f32p, C.c_int32, C.c_uint64, f64p, f64p, f64p]),
     'gemhip_hope_plan_svd_error': (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int32, C.c_uint64, f64p, f64p]),
     'gemhip_lap_eigmap': (C.c_int, [C.c_int64, C.c_int64, i64p, i32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                     C.c_uint64, f32p, f32p, f64p]),
@@ -104,6 +106,8 @@ _SIGS = {
     'gemhip_sgns_set_window_cache': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_sgns_set_hogwild': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'gemhip_sgns_set_hot_rows': (C.c_int, [C.c_void_p, C.c_int32]),
+    'gemhip_sgns_last_launch': (C.c_int, [C.c_void_p, i32p, i32p, i32p, i32p]),
+    'gemhip_sgns_set_fresh': (C.c_int, [C.c_void_p, C.c_int32]),
     'gemhip_sgns_plan_launch': (C.c_int, [i32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, i32p, i32p, i32p, f64p, f64p]),
     'gemhip_test_wave_sum6': (C.c_int, [f32p, f32p]),
     'gemhip_sgns_set_tables': (C.c_int, [C.c_void_p, f32p, f32p]),

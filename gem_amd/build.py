@@ -54,10 +54,11 @@ def build(force=False, verbose=True):
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']     # (multi.hip loads RCCL with dlopen)
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB + '.tmp'] + objs + ['-ldl']     # (multi.hip loads RCCL with dlopen)
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(LIB + '.tmp', LIB)          # (rename, never truncate: a gpurun snapshot or a process that has the old file mapped sees a whole library)
     return LIB
 
 

@@ -241,12 +241,19 @@ __global__ __launch_bounds__(GF_BLOCK) void gf_sweeps_coop_kernel(const int32_t 
 template <int VEC, int NV>
 int launch_coop(const gemhip_gf_plan *p, float *X0, float *X1, float eta, float regu, int nsweeps, hipStream_t s)
 {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    GEMHIP_CHECK(hipGetDevice(&dev));
-    GEMHIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    GEMHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gf_sweeps_coop_kernel<VEC, NV>, GF_BLOCK, 0));
-    int64_t grid = std::min<int64_t>((int64_t)per_cu * prop.multiProcessorCount, (p->nrows + GF_WAVES - 1) / GF_WAVES);
+    // resident workgroups of this instantiation on this device: queried once (both calls are millisecond-scale host work, and the fused path launches
+    // once per `fused_sweeps` sweeps -- ADVICE r5).  The kernel reads Xold only: the caller takes this path for single-level plans alone (nlevels == 1 at
+    // the launch site), and those never set the "read Xnew" column bit (bit 31).
+    static int64_t resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        GEMHIP_CHECK(hipGetDevice(&dev));
+        GEMHIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        GEMHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gf_sweeps_coop_kernel<VEC, NV>, GF_BLOCK, 0));
+        resident = (int64_t)per_cu * prop.multiProcessorCount;
+    }
+    int64_t grid = std::min<int64_t>(resident, (p->nrows + GF_WAVES - 1) / GF_WAVES);
     grid = std::max<int64_t>(NUM_XCD, grid / NUM_XCD * NUM_XCD);              // a multiple of 8: the XCD-contiguous map covers every slot
     if (p->fused_grid > 0) grid = std::max<int64_t>(NUM_XCD, std::min<int64_t>(grid, (int64_t)p->fused_grid / NUM_XCD * NUM_XCD));
     const int32_t *rows = p->d_rows; const int64_t *ptr = p->d_ptr; const uint32_t *col = p->d_col; const float *w = p->d_w;

@@ -2337,10 +2337,16 @@ extern "C" int gemhip_hope(int64_t n, int64_t nnz, const int64_t *row_ptr, const
 // known exactly (beta^2 sum w^2 and one SpMM on V), so the probes only estimate the remainder: err^2 ~ ||B P||_F^2 + mean_z (||S P z||^2 - ||B P z||^2).
 // On the reference's graphs (beta x degree << 1) the result is good to a few 1e-3 relative with 32 probes (tests/test_run_sbm_gpu.py: dense value).
 // sigma / V_sqrtS: what a solve returned (V sqrt(Sigma), n x k row-major, host).  frob2_out (optional): err^2 + sum sigma^2 = ||S||_F^2.
-extern "C" int gemhip_hope_plan_svd_error(gemhip_hope_plan_t P, int32_t k, const float *sigma, const float *V_sqrtS, int32_t probes, uint64_t seed,
-                                          double *err_out, double *frob2_out)
+// U_sqrtS (optional, round 6 -- ADVICE r5): with it the U side of the factorisation enters.  For orthonormal V,
+//   u diag(s) vt - S = (U Sigma - S V) V^T - S (I - V V^T),  the two terms orthogonal in the Frobenius inner product ((I - V V^T) V = 0),
+// so ||u diag(s) vt - S||_F^2 = ||S (I - V V^T)||_F^2 + ||S V - U Sigma||_F^2: the second term is computed EXACTLY (the Katz series applied to V's k
+// columns, U Sigma subtracted on the device, one Gram trace) and is ~0 for a converged solve -- a wrong or unconverged U now shows in the print, as it does in
+// the reference's.  Without U the result is the truncation error of an exact SVD with this V.  Columns with sigma[j] <= 0 (k above the rank of S) carry no
+// direction: they are skipped on both sides instead of failing.
+static int svd_error_impl(gemhip_hope_plan_t P, int32_t k, const float *sigma, const float *U_sqrtS, const float *V_sqrtS, int32_t probes, uint64_t seed,
+                          double *err_out, double *frob2_out, double *uside_out)
 {
-    GEMHIP_REQUIRE(P != nullptr && sigma != nullptr && V_sqrtS != nullptr && err_out != nullptr && k >= 1 && k <= 512, "hope_plan_svd_error: bad arguments");
+    GEMHIP_REQUIRE(P != nullptr && sigma != nullptr && V_sqrtS != nullptr && err_out != nullptr && k >= 1 && k <= 512, "hope_plan_svd_error: bad arguments (1 <= k <= 512)");
     GEMHIP_REQUIRE(probes >= 1 && probes <= 128, "hope_plan_svd_error: probes=%d (1..128)", probes);
     Hope &H = P->H;
     GEMHIP_REQUIRE(H.mode == 0, "hope_plan_svd_error: the plan is not a Katz (HOPE) operator");
@@ -2349,9 +2355,9 @@ extern "C" int gemhip_hope_plan_svd_error(gemhip_hope_plan_t P, int32_t k, const
     const int ld = (probes + 31) / 32 * 32, ldv = (k + 31) / 32 * 32;
     // unit right singular vectors, padded to the MFMA tile width
     std::vector<float> Vh((size_t)n * ldv, 0.f);
-    for (int j = 0; j < k; ++j) GEMHIP_REQUIRE(sigma[j] > 0.f, "hope_plan_svd_error: sigma[%d] = %g", j, (double)sigma[j]);
+    for (int j = 0; j < k; ++j) GEMHIP_REQUIRE(std::isfinite(sigma[j]), "hope_plan_svd_error: sigma[%d] = %g", j, (double)sigma[j]);
     for (int64_t i = 0; i < n; ++i)
-        for (int j = 0; j < k; ++j) Vh[(size_t)i * ldv + j] = V_sqrtS[(size_t)i * k + j] / std::sqrt(sigma[j]);
+        for (int j = 0; j < k; ++j) Vh[(size_t)i * ldv + j] = sigma[j] > 0.f ? V_sqrtS[(size_t)i * k + j] / std::sqrt(sigma[j]) : 0.f;      // (a zero column deflates nothing)
     float *dV = nullptr, *dBV = nullptr;
     float *blk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // Z (deflated in place), T0, T1, W0 (= B Z after apply_S), Out (= S Z)
     HOPE_TRY(H, hipMalloc((void **)&dV, Vh.size() * sizeof(float)));
@@ -2373,6 +2379,32 @@ extern "C" int gemhip_hope_plan_svd_error(gemhip_hope_plan_t P, int32_t k, const
         gram(H, blk[4], ld, probes, blk[4], ld, probes, Gs);
         gram(H, blk[3], ld, probes, blk[3], ld, probes, Gb);
     }
+    // the U side: ||S V - U Sigma||_F^2, at most 128 columns of V per pass of the Katz series
+    double uside = 0.0;
+    if (U_sqrtS && !H.err) {
+        const int ldc = 128;
+        float *cb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // T0, T1, W0, Out (= S V chunk), U Sigma chunk / residual
+        for (float *&b : cb) HOPE_TRY(H, hipMalloc((void **)&b, (size_t)n * ldc * sizeof(float)));
+        std::vector<float> Uh((size_t)n * ldc);
+        for (int c0 = 0; c0 < k && !H.err; c0 += ldc) {
+            const int cbn = std::min(ldc, k - c0);
+            std::fill(Uh.begin(), Uh.end(), 0.f);
+            for (int64_t i = 0; i < n; ++i)
+                for (int j = 0; j < cbn; ++j) Uh[(size_t)i * ldc + j] = sigma[c0 + j] > 0.f ? U_sqrtS[(size_t)i * k + c0 + j] * std::sqrt(sigma[c0 + j]) : 0.f;
+            HOPE_TRY(H, hipMemcpyAsync(cb[4], Uh.data(), Uh.size() * sizeof(float), hipMemcpyHostToDevice, H.s));
+            HOPE_TRY(H, hipMemsetAsync(cb[3], 0, (size_t)n * ldc * sizeof(float), H.s));
+            apply_S(H, dV + c0, ldv, cbn, P->terms, cb[0], cb[1], cb[2], ldc, cb[3], ldc);
+            if (!H.err)
+                hipLaunchKernelGGL(hope_lincomb_kernel, dim3((unsigned)((n * ldc + 255) / 256)), dim3(256), 0, H.s, n, ldc, 1.0f, cb[3], ldc, -1.0f, cb[4], ldc, 0.0f,
+                                   cb[4], ldc, cb[4], ldc);                 // residual in place (padding columns: 0 - 0)
+            std::vector<double> Gr;
+            const int cpad = (cbn + 31) / 32 * 32;
+            gram(H, cb[4], ldc, cpad, cb[4], ldc, cpad, Gr);
+            HOPE_TRY(H, hipStreamSynchronize(H.s));
+            if (!H.err) for (int j = 0; j < cbn; ++j) uside += Gr[(size_t)j * cpad + j];
+        }
+        for (float *b : cb) hipFree(b);
+    }
     HOPE_TRY(H, hipStreamSynchronize(H.s));
     for (float *b : blk) hipFree(b);
     hipFree(dV); hipFree(dBV);
@@ -2380,10 +2412,37 @@ extern "C" int gemhip_hope_plan_svd_error(gemhip_hope_plan_t P, int32_t k, const
     double rem = 0.0, bv2 = 0.0, top = 0.0;
     for (int j = 0; j < probes; ++j) rem += Gs[(size_t)j * probes + j] - Gb[(size_t)j * probes + j];
     for (int j = 0; j < k; ++j) { bv2 += Gbv[(size_t)j * k + j]; top += (double)sigma[j] * (double)sigma[j]; }
-    const double err2 = std::max(0.0, (double)H.beta * (double)H.beta * P->frob2_A - bv2 + rem / probes);
+    const double trunc2 = std::max(0.0, (double)H.beta * (double)H.beta * P->frob2_A - bv2 + rem / probes);
+    const double err2 = trunc2 + std::max(0.0, uside);
     *err_out = std::sqrt(err2);
-    if (frob2_out) *frob2_out = err2 + top;
+    if (frob2_out) *frob2_out = trunc2 + top;
+    if (uside_out) *uside_out = std::sqrt(std::max(0.0, uside));
     return GEMHIP_OK;
+}
+
+extern "C" int gemhip_hope_plan_svd_error(gemhip_hope_plan_t P, int32_t k, const float *sigma, const float *V_sqrtS, int32_t probes, uint64_t seed,
+                                          double *err_out, double *frob2_out)
+{
+    return svd_error_impl(P, k, sigma, nullptr, V_sqrtS, probes, seed, err_out, frob2_out, nullptr);
+}
+
+extern "C" int gemhip_hope_plan_svd_error_uv(gemhip_hope_plan_t P, int32_t k, const float *sigma, const float *U_sqrtS, const float *V_sqrtS, int32_t probes,
+                                             uint64_t seed, double *err_out, double *frob2_out, double *uside_out)
+{
+    GEMHIP_REQUIRE(U_sqrtS != nullptr, "hope_plan_svd_error_uv: U_sqrtS is NULL (gemhip_hope_plan_svd_error is the V-only form)");
+    return svd_error_impl(P, k, sigma, U_sqrtS, V_sqrtS, probes, seed, err_out, frob2_out, uside_out);
+}
+
+extern "C" int gemhip_hope_svd_error_uv(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
+                                        const float *sigma, const float *U_sqrtS, const float *V_sqrtS, int32_t probes, uint64_t seed, double *err_out,
+                                        double *frob2_out, double *uside_out)
+{
+    gemhip_hope_plan_t P = nullptr;
+    int rc = gemhip_hope_plan_create(n, nnz, row_ptr, col, w, beta, &P);
+    if (rc) return rc;
+    rc = gemhip_hope_plan_svd_error_uv(P, k, sigma, U_sqrtS, V_sqrtS, probes, seed, err_out, frob2_out, uside_out);
+    gemhip_hope_plan_destroy(P);
+    return rc;
 }
 
 // One-shot form for the plugin's verbose mode (hope.py:38-40): the plan is rebuilt (transpose + uploads), which costs about as much as the estimate itself.

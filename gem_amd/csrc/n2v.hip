@@ -114,6 +114,9 @@ struct SgnsKnobs {
     bool part = false;                // a bucket launch of the partitioned schedule (sgns_win_kernel<PART>: as-loaded window copies in global scratch, 3 wavefronts per SIMD)
     double duty = 1.0;                // fraction of a wavefront's time spent in pair steps (negative rows open); < 1 only for the buckets of the partitioned schedule
     double touch_scale = 1.0;         // factor on VocabStats::touch2 (bucket launches: the pairs of ONE bucket touch the rows of two partitions only: parts x duty)
+    bool has_local_hot = false;       // this corpus HAS locally hot nodes (ensure_hotkey): the launch carries the staging row and a hot threshold even without count-hot rows
+    int32_t local_hot = 8;            // LOCALLY HOT ROWS: a node with at least this many tokens per walk that contains it is treated as a hot row (0: off)
+    int32_t neg_count = 0;            // fresh bit 2: token count from which a negative row is updated by atomic add (0: every row)
     int32_t fresh = 0;                // FRESH HOT ROWS (sgns.hpp, SgnsArgs::fresh): bit 0 hot centre words by returning atomics, bit 1 hot negatives re-read before the dot products
     bool node_id_layout = false;      // the unigram table the launch draws from is in node-id order (gemhip_n2v_build_unigram), not the binary's: half the concurrent-touch bound (plan_sgns_launch)
 };
@@ -167,6 +170,9 @@ struct gemhip_n2v {
     float *SynPos = nullptr, *SynNeg = nullptr;
     bool own_syn = false;
     SgnsKnobs kn;                     // launch knobs (setters below; environment overrides read once in gemhip_n2v_create)
+    int32_t *d_hotkey = nullptr; int32_t *d_wcount = nullptr; unsigned int *d_nlocal = nullptr; int hotkey_state = 0; int64_t n_local_hot = 0;   // LOCALLY HOT ROWS (ensure_hotkey)
+    SgnsLaunchPlan last_plan;         // what the last gemhip_sgns_train / _train_part on this handle actually launched (gemhip_sgns_last_launch)
+    int32_t last_fresh = 0;
     VocabStats vs;                    // vocabulary statistics (gemhip_n2v_build_unigram*): how concentrated the row traffic is -> plan_sgns_launch
     float *d_dummy = nullptr; size_t dummy_bytes = 0;   // sgns_win_kernel: one scratch row per wavefront
     float *d_scratch = nullptr; size_t scratch_bytes = 0;   // sgns_win_kernel<PART>: the window rows as loaded, 2R+1 rows per wavefront
@@ -393,6 +399,43 @@ __global__ void n2v_vocab_kernel(const int32_t *__restrict__ walks, int64_t ntok
     }
 }
 
+// LOCALLY HOT ROWS (round 6).  wcount[v] = number of walks that CONTAIN v (one wavefront per walk: a token counts at its first occurrence in the walk).
+// A node whose tokens are packed into few walks -- count[v] / wcount[v] occurrences per walk that touches it -- sits in that walk's LDS window for the
+// whole walk, not for 2R+1 centres: the two nodes of an isolated edge make up ALL 80 tokens of each of their 20 walks.  Two wavefronts that train two of
+// those walks at the same time each apply a whole walk's worth of updates (~800 pair steps per row) to the same base and both deltas are added: the pair
+// ends with a norm 14 % above its peers' (measured, R-MAT scale 17 at 1 536 wavefronts: profiles/r06_canaries_rmat17.jsonl) and, because the nodes of
+// such components are nearly collinear (cosine 0.93; they are only ever pushed away from the same hub rows), outranks the true neighbour of dozens of
+// them -- the heavy tail of the power-law "Hogwild bias" (each event costs 2-5 % of the graph's MAP; its probability grows with the width).
+__global__ __launch_bounds__(64) void n2v_walk_presence_kernel(const int32_t *__restrict__ walks, int64_t nwalks, int32_t walk_len, int32_t *__restrict__ wcount)
+{
+    extern __shared__ int32_t tokp[];
+    const int lane = threadIdx.x;
+    for (int64_t wl = blockIdx.x; wl < nwalks; wl += gridDim.x) {
+        const int32_t *walk = walks + wl * walk_len;
+        for (int k = lane; k < walk_len; k += WAVE) tokp[k] = walk[k];
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < walk_len; k += WAVE) {
+            const int32_t v = tokp[k];
+            bool first = v >= 0;
+            for (int q = 0; q < k && first; ++q) first = tokp[q] != v;
+            if (first) atomicAdd(&wcount[v], 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// hotkey[v] = INT32_MAX for a locally hot node (count >= per_walk x walks containing it), else its token count: what the SGNS kernels compare with hot_thr
+__global__ void n2v_hotkey_kernel(int64_t n, const int32_t *__restrict__ counts, const int32_t *__restrict__ wcount, int32_t per_walk, int32_t *__restrict__ hotkey,
+                                  unsigned int *__restrict__ nlocal)
+{
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int32_t c = counts[v], w = wcount[v];
+    const bool loc = w > 0 && (int64_t)c >= (int64_t)per_walk * w;
+    hotkey[v] = loc ? INT32_MAX : c;
+    if (loc) atomicAdd(nlocal, 1u);
+}
+
 // -------------------------------------------------------------------------- SGNS
 // InitPosEmb (ELF @0x40e270): (U(0,1)-0.5)/d ; InitNegEmb: zeros.
 // first[v] = index of the first token equal to v (LearnVocab @0x40d560 renames the tokens 0..N-1 in that order)
@@ -500,7 +543,9 @@ extern "C" int gemhip_n2v_create(int64_t n, int64_t nnz, const int64_t *row_ptr,
     if (const char *e = getenv("GEMHIP_SGNS_PREFETCH")) h->kn.prefetch = std::min(2, std::max(1, atoi(e)));
     if (const char *e = getenv("GEMHIP_SGNS_RELOAD")) h->kn.reload = atoi(e) != 0;
     if (const char *e = getenv("GEMHIP_SGNS_HOT_COUNT")) h->kn.hot_count = std::max(-1, atoi(e));
-    if (const char *e = getenv("GEMHIP_SGNS_FRESH")) h->kn.fresh = atoi(e) & 3;
+    if (const char *e = getenv("GEMHIP_SGNS_LOCAL_HOT")) h->kn.local_hot = std::max(0, atoi(e));
+    if (const char *e = getenv("GEMHIP_SGNS_FRESH")) h->kn.fresh = atoi(e) & 7;
+    if (const char *e = getenv("GEMHIP_SGNS_NEG_COUNT")) h->kn.neg_count = std::max(0, atoi(e));
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(GEMHIP_E_HIP, "n2v_create: no HIP device"); }
     phase_acc()[PH_HOST] += phase_now() - t_host0;
     PhaseScope ph_up(PH_H2D);
@@ -528,6 +573,7 @@ extern "C" int gemhip_n2v_destroy(gemhip_n2v_t h)
     hipFree(h->d_start);
     hipFree(h->d_row_ptr); hipFree(h->d_col); hipFree(h->d_w); hipFree(h->d_U); hipFree(h->d_K); hipFree(h->d_walks); hipFree(h->d_dummy); hipFree(h->d_scratch);
     if (h->own_counts) hipFree(h->d_counts);
+    hipFree(h->d_hotkey); hipFree(h->d_wcount); hipFree(h->d_nlocal);
     hipFree(h->d_UT); hipFree(h->d_KT); hipFree(h->d_UK); hipFree(h->d_SK); hipFree(h->d_SKp); hipFree(h->d_KTslot); hipFree(h->d_first); hipFree(h->d_pairs); hipFree(h->d_UTp); hipFree(h->d_KTp); hipFree(h->d_UKp); hipFree(h->d_KTslotp);
     if (h->own_syn) { hipFree(h->SynPos); hipFree(h->SynNeg); }
     delete h;
@@ -600,7 +646,7 @@ extern "C" int gemhip_n2v_walks(gemhip_n2v_t h, float p, float q, int32_t num_wa
     const int64_t count = walk_end - walk_begin;
     if (int rc = ensure_walk_buffer(h, count, walk_len)) return rc;
     h->walk_id_offset = walk_begin;
-    h->unigram_ready = false;
+    h->unigram_ready = false; h->hotkey_state = 0;
     if (count == 0) return GEMHIP_OK;
     const bool second = !(p == 1.0f && q == 1.0f);
     const float ip = 1.0f / p, iq = 1.0f / q;
@@ -629,7 +675,7 @@ extern "C" int gemhip_n2v_set_walks(gemhip_n2v_t h, const int32_t *walks_host, i
     GEMHIP_REQUIRE(h && walks_host && nwalks >= 0 && walk_len >= 1 && walk_len < 65536, "n2v_set_walks: bad arguments");
     if (int rc = ensure_walk_buffer(h, nwalks, walk_len)) return rc;
     h->walk_id_offset = walk_id_offset;
-    h->unigram_ready = false;
+    h->unigram_ready = false; h->hotkey_state = 0;
     if (nwalks) GEMHIP_CHECK(hipMemcpy(h->d_walks, walks_host, nwalks * walk_len * sizeof(int32_t), hipMemcpyHostToDevice));
     return GEMHIP_OK;
 }
@@ -662,7 +708,7 @@ extern "C" int gemhip_n2v_vocab(gemhip_n2v_t h, void *stream)
         hipLaunchKernelGGL(n2v_vocab_kernel, dim3((unsigned)blocks), dim3(256), 0, s, h->d_walks, ntok, h->d_counts);
         GEMHIP_CHECK(hipGetLastError());
     }
-    h->unigram_ready = false;
+    h->unigram_ready = false; h->hotkey_state = 0;
     return GEMHIP_OK;
 }
 
@@ -670,7 +716,7 @@ extern "C" int gemhip_n2v_bind_counts(gemhip_n2v_t h, void *d_counts)
 {
     GEMHIP_REQUIRE(h && d_counts, "n2v_bind_counts: NULL argument");
     if (h->own_counts) hipFree(h->d_counts);
-    h->d_counts = (int32_t *)d_counts; h->own_counts = false; h->unigram_ready = false;
+    h->d_counts = (int32_t *)d_counts; h->own_counts = false; h->unigram_ready = false; h->hotkey_state = 0;
     return GEMHIP_OK;
 }
 
@@ -746,7 +792,7 @@ extern "C" int gemhip_n2v_build_unigram(gemhip_n2v_t h, int32_t *counts_out, flo
         if (!h->d_UK) GEMHIP_CHECK(hipMalloc((void **)&h->d_UK, n * sizeof(uint2)));
         GEMHIP_CHECK(hipMemcpy(h->d_UK, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
     }
-    h->unigram_ready = true; h->vocab_order = false; h->sk_state = -1;
+    h->unigram_ready = true; h->vocab_order = false; h->sk_state = -1; h->hotkey_state = 0;
     if (counts_out) std::copy(cnt.begin(), cnt.end(), counts_out);
     if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
     if (KT_out) std::copy(K.begin(), K.end(), KT_out);
@@ -821,7 +867,7 @@ extern "C" int gemhip_n2v_build_unigram_vocab_order(gemhip_n2v_t h, int32_t flag
     { PhaseScope ph(PH_H2D);
       GEMHIP_CHECK(hipMemcpy(h->d_KTslot, slot.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
       GEMHIP_CHECK(hipMemcpy(h->d_UK, UK.data(), n * sizeof(uint2), hipMemcpyHostToDevice)); }
-    h->n_vocab = N; h->vocab_order = true; h->unigram_ready = true; h->sk_state = -1;
+    h->n_vocab = N; h->vocab_order = true; h->unigram_ready = true; h->sk_state = -1; h->hotkey_state = 0;
     if (n_vocab_out) *n_vocab_out = N;
     if (order_out) std::copy(back.begin(), back.end(), order_out);
     if (UT_out) std::copy(Uf.begin(), Uf.end(), UT_out);
@@ -1041,7 +1087,7 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         }
         return 0;
     };
-    bool allc = R >= window;
+    bool allc = R >= window && !kn.has_local_hot;
     if (!deterministic) {
         P.delta = mode != 0;
         // the (reload, prefetch) pair the launcher will actually run: launches WITHOUT reload-on-update and with prefetch distance 1 exist for the
@@ -1123,10 +1169,38 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         if (P.waves == 1 && mode < 0) P.delta = false;
     }
     P.hot_thr = hot_threshold(P.waves);
+    if (P.hot_thr == 0 && kn.has_local_hot && P.delta && P.waves > 1) P.hot_thr = INT32_MAX;       // only the locally hot nodes (hotkey INT32_MAX) qualify
     // (the launcher takes an ALLC instantiation iff R >= window && hot_thr == 0: `allc` false with hot_thr 0 only gives that kernel a row it does not use)
     P.lds = lds_bytes(P.delta, allc && P.hot_thr == 0);
     P.blocks = (int)P.waves; P.threads = 64;
     return P;
+}
+
+// LOCALLY HOT ROWS: the array the Hogwild kernels compare with hot_thr -- the token count, or INT32_MAX for a node whose tokens are packed into few walks
+// (kernels above).  Built on `stream` from the walks this handle holds and its (possibly externally reduced) counts; rebuilt after walks / vocabulary
+// change.  n_local_hot is read back (one 4-byte copy): a launch without any such node and without count-hot rows keeps the all-cached instantiation.
+static int ensure_hotkey(gemhip_n2v_t h, hipStream_t stream)
+{
+    if (h->hotkey_state == 1) return GEMHIP_OK;
+    if (!h->d_hotkey) {
+        GEMHIP_CHECK(hipMalloc((void **)&h->d_hotkey, (size_t)h->n * sizeof(int32_t)));
+        GEMHIP_CHECK(hipMalloc((void **)&h->d_wcount, (size_t)h->n * sizeof(int32_t)));
+        GEMHIP_CHECK(hipMalloc((void **)&h->d_nlocal, sizeof(unsigned int)));
+    }
+    GEMHIP_CHECK(hipMemsetAsync(h->d_wcount, 0, (size_t)h->n * sizeof(int32_t), stream));
+    GEMHIP_CHECK(hipMemsetAsync(h->d_nlocal, 0, sizeof(unsigned int), stream));
+    if (h->nwalks > 0) {
+        const int64_t blocks = std::min<int64_t>(h->nwalks, 256 * 32);
+        hipLaunchKernelGGL(n2v_walk_presence_kernel, dim3((unsigned)blocks), dim3(64), (size_t)h->walk_len * sizeof(int32_t), stream, h->d_walks, h->nwalks, h->walk_len, h->d_wcount);
+    }
+    hipLaunchKernelGGL(n2v_hotkey_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, stream, h->n, h->d_counts, h->d_wcount, h->kn.local_hot, h->d_hotkey, h->d_nlocal);
+    GEMHIP_CHECK(hipGetLastError());
+    unsigned int nl = 0;
+    GEMHIP_CHECK(hipMemcpyAsync(&nl, h->d_nlocal, sizeof nl, hipMemcpyDeviceToHost, stream));
+    GEMHIP_CHECK(hipStreamSynchronize(stream));
+    h->n_local_hot = nl;
+    h->hotkey_state = 1;
+    return GEMHIP_OK;
 }
 
 // The slot table the window kernels draw negatives from (SgnsArgs::SK), for the table currently held and the given quirk bit.  Built on `stream`,
@@ -1186,9 +1260,15 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     A.SynPos = h->SynPos; A.SynNeg = h->SynNeg; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.cache_radius = 0; A.nwaves = 1; A.prefetch = h->kn.prefetch; A.reload = h->kn.reload; A.counts = nullptr; A.hot_thr = 0;
     A.parts = 0; A.ctx_part = 0; A.word_part = 0; A.seg = nullptr; A.nseg = 0; A.seg_len = 0; A.scratch = nullptr;
-    A.fresh = h->kn.fresh; A.stale_ver = nullptr; A.stale_hist = nullptr; A.n_nodes = h->n;
+    A.fresh = h->kn.fresh; A.neg_thr = h->kn.neg_count; A.stale_ver = nullptr; A.stale_hist = nullptr; A.n_nodes = h->n;
     SgnsKnobs kn_launch = h->kn;
     kn_launch.node_id_layout = !h->vocab_order;
+    // LOCALLY HOT ROWS need the WHOLE corpus on this handle (walks-per-node is a property of the corpus: a rank's shard against all-reduced counts would
+    // flag everything); Hogwild launches only
+    if (!(flags & 4) && h->kn.local_hot > 0 && h->walk_id_offset == 0 && h->vs.total <= (double)h->nwalks * h->walk_len + 0.5) {
+        { const int rc = ensure_hotkey(h, (hipStream_t)stream); if (rc) return rc; }
+        kn_launch.has_local_hot = h->n_local_hot > 0;
+    }
     const SgnsLaunchPlan P = plan_sgns_launch(h->vs, kn_launch, h->n, h->d, window, h->walk_len, walk_hi - walk_lo, flags);
     GEMHIP_REQUIRE(P.lds <= 64 * 1024, "sgns_train: walk_len/window/d too large for LDS staging (%zu bytes)", P.lds);
     A.nwaves = (int32_t)P.waves; A.cache_radius = P.R;
@@ -1197,6 +1277,8 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
         A.SK = h->d_SK;
         // hot rows (sgns_win_kernel): never cached; the launch then takes the instantiation that handles uncached contexts
         A.counts = h->d_counts; A.hot_thr = P.hot_thr;
+        // LOCALLY HOT ROWS: the kernel compares `hotkey` (INT32_MAX for a node whose tokens are packed into few walks, else its token count) with the threshold
+        if (P.delta && P.waves > 1 && kn_launch.has_local_hot) A.counts = h->d_hotkey;
         const size_t need = (size_t)P.waves * sgns_win_row_floats(h->d) * sizeof(float);
         if (need > h->dummy_bytes) {
             if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
@@ -1222,6 +1304,7 @@ extern "C" int gemhip_sgns_train(gemhip_n2v_t h, int32_t window, int32_t neg, fl
     }
     sgns_fn fn = !P.window ? pick_sgns(h->d) : P.delta ? pick_sgns_win_hogwild(h->d) : pick_sgns_win_det(h->d);
     GEMHIP_REQUIRE(fn != nullptr, "sgns_train: d=%d unsupported", h->d);
+    h->last_plan = P; h->last_fresh = (P.window && P.delta && P.hot_thr > 0) ? A.fresh : 0;
     fn(A, P.blocks, P.threads, P.lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());
 #ifdef GEMHIP_SGNS_STALENESS
@@ -1314,7 +1397,7 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     A.SynPos = (float *)dSynPos_part; A.SynNeg = (float *)dSynNeg_part; A.pairs = h->d_pairs;
     A.dummy = nullptr; A.prof = nullptr; A.prefetch = 2; A.reload = 1; A.counts = h->d_counts; A.hot_thr = 0;
     A.parts = h->parts; A.ctx_part = ctx_part; A.word_part = word_part; A.seg = (const int64_t *)d_seg; A.nseg = nseg; A.seg_len = seg_len;
-    A.fresh = h->kn.fresh; A.stale_ver = nullptr; A.stale_hist = nullptr; A.n_nodes = h->n;
+    A.fresh = h->kn.fresh; A.neg_thr = h->kn.neg_count; A.stale_ver = nullptr; A.stale_hist = nullptr; A.n_nodes = h->n;
     // the launch rule of gemhip_sgns_train on the rows in play: the negative rows are those of partition word_part (n_eff of ITS restricted unigram
     // distribution bounds the Hogwild width: rho = W x 5 x 0.4 / n_eff <= 1.5 %); hot rows are judged on the GLOBAL token counts (a hub sits in
     // W x (2R+1) x count / tokens windows whatever partition it belongs to)
@@ -1360,6 +1443,7 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
     }
     sgns_fn fn = pick_sgns_win_part(d, P.delta);
     GEMHIP_REQUIRE(fn != nullptr, "sgns_train_part: d=%d unsupported", d);
+    h->last_plan = P; h->last_fresh = (P.delta && P.hot_thr > 0) ? A.fresh : 0;
     fn(A, P.blocks, P.threads, P.lds, (hipStream_t)stream);
     GEMHIP_CHECK(hipGetLastError());
     return GEMHIP_OK;
@@ -1412,6 +1496,24 @@ extern "C" int gemhip_sgns_set_hot_rows(gemhip_n2v_t h, int32_t min_count)
 {
     GEMHIP_REQUIRE(h && min_count >= -1, "sgns_set_hot_rows: bad arguments");
     h->kn.hot_count = min_count;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_set_fresh(gemhip_n2v_t h, int32_t bits)
+{
+    GEMHIP_REQUIRE(h && bits >= 0 && bits <= 7, "sgns_set_fresh: bits=%d (0..7)", bits);
+    h->kn.fresh = bits;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_sgns_last_launch(gemhip_n2v_t h, int32_t *kernel, int32_t *waves, int32_t *hot_threshold, int32_t *fresh)
+{
+    GEMHIP_REQUIRE(h, "sgns_last_launch: null handle");
+    const SgnsLaunchPlan &P = h->last_plan;
+    if (kernel) *kernel = !P.window ? 0 : P.delta ? 2 : 1;
+    if (waves) *waves = (int32_t)P.waves;
+    if (hot_threshold) *hot_threshold = P.hot_thr;
+    if (fresh) *fresh = h->last_fresh;
     return GEMHIP_OK;
 }
 

@@ -29,7 +29,8 @@ struct SgnsArgs {
     int32_t cache_radius;       // sgns_win_kernel: tokens within this many positions of the centre keep their SynPos row in LDS
     int32_t prefetch;           // sgns_win_kernel: pairs whose negative rows are requested ahead (2, or 1)
     int32_t reload;             // sgns_win_kernel<RELOAD>: negative rows updated as they are at store time, centre row by atomic add
-    const int32_t *counts; int32_t hot_thr;   // sgns_win_kernel<!ALLC>: nodes with counts[v] >= hot_thr > 0 never enter the LDS window (HOT ROWS below)
+    const int32_t *counts; int32_t hot_thr;   // sgns_win_kernel<!ALLC>: nodes with counts[v] >= hot_thr > 0 never enter the LDS window (HOT ROWS below); `counts` is the
+                                              // token count, or -- single-GPU Hogwild launches -- n2v.hip's hotkey: INT32_MAX for a LOCALLY hot node (tokens packed into few walks)
     // sgns_win_kernel<PART> (partitioned tables, N-GPU schedule): node v belongs to partition v % parts, local row v / parts.  SynPos / SynNeg point
     // at partition ctx_part of SynPos and partition word_part of SynNeg; UT / KT / UK / n describe the unigram table RESTRICTED to word_part (local
     // indices); `counts` stays global.  Only pairs (context in ctx_part, centre word in word_part) are trained: TrainModel filtered to one bucket.
@@ -43,7 +44,11 @@ struct SgnsArgs {
     // RETURNING atomic add -- the next pair computes with the row as memory held it one pair step ago (what came back + this pair's own change), not with
     // the copy loaded at the centre's start, ~10 pair steps old by the centre's end.  bit 1: hot negative rows are fetched AGAIN right before the dot
     // products, so the gradient is computed from the row as it is now and not from the copy requested two pairs ahead.
-    int32_t fresh;
+    // bit 2 (value 4): EVERY negative row with at least neg_thr tokens takes its update as an atomic add (as the hot rows do), not as reload + store.  The
+    // unigram^0.75 draw -- under RndUnigramInt's quirk: over the alias targets only -- concentrates on a few thousand mid-frequency rows that are "cold" by
+    // the window's measure (token count) but are touched by another wavefront inside one's load..store interval a third of the time at 768 wavefronts
+    // (profiles/r06_staleness_rmat17.jsonl): the reload + store then overwrites that update.
+    int32_t fresh; int32_t neg_thr;
     unsigned int *stale_ver; unsigned long long *stale_hist; int64_t n_nodes;   // GEMHIP_SGNS_STALENESS builds only (see STALE below)
 };
 
@@ -705,8 +710,12 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             float *pp = A.SynNeg + (int64_t)(word >= 0 ? word : 0) * d;
             // FRESH HOT ROWS, bit 0: the centre word is a hot row -> its positive row is refreshed by every pair's returning atomic add (pos_update)
             bool word_hot = false;
-            if constexpr (!ALLC && RELOAD)
-                word_hot = (A.fresh & 1) && word >= 0 && A.hot_thr > 0 && A.counts[PART ? (int64_t)word * A.parts + A.word_part : (int64_t)word] >= A.hot_thr;
+            if constexpr (!ALLC && RELOAD) {
+                if (word >= 0 && A.hot_thr > 0) {      // a LOCALLY hot word (hotkey INT32_MAX: n2v.hip ensure_hotkey) always; a count-hot one under fresh bit 0
+                    const int32_t cw = A.counts[PART ? (int64_t)word * A.parts + A.word_part : (int64_t)word];
+                    word_hot = cw == INT32_MAX || ((A.fresh & 1) && cw >= A.hot_thr);
+                }
+            }
             STALE(unsigned int ver_c = 0u; int cnt_c = 1;)
             if (word >= 0) {
                 const int64_t t = A.token_offset + wl * len + pos;
@@ -878,6 +887,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                         unsigned hotm = 0u;
                         if constexpr (!ALLC && RELOAD) {
                             hotm = A.hot_thr > 0 ? (unsigned)__builtin_amdgcn_ballot_w64(lane < SGNS_NEG && C.cnt >= A.hot_thr) : 0u;
+                            if ((A.fresh & 4) && A.hot_thr > 0) hotm |= (unsigned)__builtin_amdgcn_ballot_w64(lane < SGNS_NEG && C.cnt >= A.neg_thr);     // bit 2: see SgnsArgs::fresh
                             if ((A.fresh & 2) && hotm) {         // FRESH bit 1: the gradient of a hot row is computed from the row as it is NOW
 #pragma unroll
                                 for (int j = 0; j < SGNS_NEG; ++j)
@@ -986,7 +996,22 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                             for (int c = 0; c < NV; ++c)
 #pragma unroll
                                 for (int k = 0; k < VEC; ++k) { neu[c][k] = fmaf(g, C.y[j][c][k], neu[c][k]); C.y[j][c][k] = fmaf(g, xc[c][k], C.y[j][c][k]); }
-                            g_st(skip ? dummy : A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
+                            if constexpr (RELOAD) {
+                                // Hogwild: the update leaves as an atomic add of g * xc, NEVER as a store of the register copy (round 6).  A pair lands here because a
+                                // target repeats -- on a power-law graph that is nearly always a HUB row, which other wavefronts update by atomic add several times
+                                // per microsecond: a plain store of `row as fetched at the top of this path + my update` wipes out every add that landed in
+                                // between (~1 us: the re-fetch round trip plus up to six sequential dot products), and it did so for all five rows of the pair.
+                                // (The register copy still carries the update forward to a later occurrence of the same target inside the pair.)
+                                if (!skip) {
+                                    float *pj = A.SynNeg + (int64_t)C.tgt[j] * d;
+#pragma unroll
+                                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                                        for (int k = 0; k < VEC; ++k)
+                                            if ((c * WAVE + lane) * VEC + k < dg)
+                                                __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(pj + (c * WAVE + lane) * VEC + k), g * xc[c][k]);
+                                }
+                            } else g_st(skip ? dummy : A.SynNeg + (int64_t)C.tgt[j] * d, C.y[j]);
                         }
                     }
 #pragma unroll
@@ -1126,16 +1151,28 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
             if (refc != 0) continue;
             float l[NV][VEC];
             lds_ld(rowsL + (size_t)s * RW, l);
-            if constexpr (DELTA) {
-                float o[NV][VEC], g[NV][VEC];
+            if constexpr (RELOAD) {        // what this wavefront changed, added to the row as it is now -- like every row that leaves the window mid-walk (round 6: was load + store)
+                float o[NV][VEC];
                 o_ld(s, o);
-                g_ld(A.SynPos + (int64_t)v * d, g);
+                float *prow = A.SynPos + (int64_t)v * d;
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) l[c][k] = g[c][k] + (l[c][k] - o[c][k]);
+                    for (int k = 0; k < VEC; ++k)
+                        if ((c * WAVE + lane) * VEC + k < dg)
+                            __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(prow + (c * WAVE + lane) * VEC + k), l[c][k] - o[c][k]);
+            } else {
+                if constexpr (DELTA) {
+                    float o[NV][VEC], g[NV][VEC];
+                    o_ld(s, o);
+                    g_ld(A.SynPos + (int64_t)v * d, g);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) l[c][k] = g[c][k] + (l[c][k] - o[c][k]);
+                }
+                g_st(A.SynPos + (int64_t)v * d, l);
             }
-            g_st(A.SynPos + (int64_t)v * d, l);
             if (lane == s) slot_node = -1;
         }
         __builtin_amdgcn_wave_barrier();

@@ -39,12 +39,14 @@ def learn(model, graph):
     _hip.warn_if_unconverged(model._stats, float(getattr(model, '_tol', 1e-5)), int(getattr(model, '_max_restarts', 20)), 'HOPE')
     model._node_num = n
     if getattr(model, '_verbose', False):
-        # hope.py:38-40 prints ||u diag(s) vt - S||_F of the dense S it formed; here ||S (I - V V^T)||_F from 32 deflated probe columns
-        # pushed through the Katz series (gemhip_hope_svd_error) -- opt-in (HOPE(..., verbose=True)): it rebuilds the plan outside the timed solve
-        err = C.c_double(); fro2 = C.c_double()
-        _hip.check(_hip.lib().gemhip_hope_svd_error(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), _hip.ptr(ww, C.c_float),
-                                                    float(model._beta), k, _hip.ptr(sig, C.c_float), _hip.ptr(V, C.c_float), 32, int(getattr(model, '_seed', 20260923)),
-                                                    C.byref(err), C.byref(fro2)))
+        # hope.py:38-40 prints ||u diag(s) vt - S||_F of the dense S it formed; here ||S (I - V V^T)||_F^2 (32 deflated probe columns pushed through the Katz
+        # series) + ||S V - U Sigma||_F^2 (exact; ~0 for a converged solve, so a wrong U shows as it would in the reference's print) -- gemhip_hope_svd_error_uv.
+        # Opt-in (HOPE(..., verbose=True)): it rebuilds the plan outside the timed solve
+        err = C.c_double(); fro2 = C.c_double(); uside = C.c_double()
+        _hip.check(_hip.lib().gemhip_hope_svd_error_uv(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), _hip.ptr(ww, C.c_float),
+                                                       float(model._beta), k, _hip.ptr(sig, C.c_float), _hip.ptr(U, C.c_float), _hip.ptr(V, C.c_float), 32,
+                                                       int(getattr(model, '_seed', 20260923)), C.byref(err), C.byref(fro2), C.byref(uside)))
+        model._svd_error_u_side = uside.value
         model._svd_error = err.value
         print('SVD error (low rank): %f' % err.value)
     X64 = np.empty((n, 2 * k), dtype=np.float64)              # [U sqrt(S) | V sqrt(S)] (hope.py:34-36), each half converted in place: one pass, no float32 concatenate

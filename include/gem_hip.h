@@ -242,6 +242,16 @@ int gemhip_sgns_set_hot_rows(gemhip_n2v_t h, int32_t min_count);
  * reference counterpart (the binary runs as many threads as the machine has cores). */
 int gemhip_sgns_plan_launch(const int32_t *counts, int64_t n, int32_t d, int32_t window, int32_t walk_len, int64_t nwalks, int32_t flags,
                             int32_t *kernel, int32_t *waves, int32_t *hot_threshold, double *n_eff, double *n_eff_cold);
+/* What the LAST gemhip_sgns_train / gemhip_sgns_train_part on this handle actually launched -- the planner's choice after every knob and
+ * environment override (GEMHIP_SGNS_MAX_WAVES, ...) and for the handle's own unigram-table layout: kernel (as gemhip_sgns_plan_launch), concurrent
+ * wavefronts, hot-row token threshold, and the FRESH HOT ROWS bits in force (0 when the launch had no hot rows).  bench.py reports this instead of
+ * replaying the planner.  Any out pointer may be NULL. */
+int gemhip_sgns_last_launch(gemhip_n2v_t h, int32_t *kernel, int32_t *waves, int32_t *hot_threshold, int32_t *fresh);
+/* FRESH HOT ROWS (Hogwild launches that have hot rows; gem_amd/csrc/sgns.hpp SgnsArgs::fresh).  bit 0: a hot centre word's positive row takes every
+ * pair's update as a returning atomic add and continues from the returned row; bit 1: hot negative rows are re-read right before the dot products.
+ * Both shorten the time between reading a hub row and adding a gradient computed from it.  No reference counterpart (the binary's Hogwild threads
+ * read and write rows in place). */
+int gemhip_sgns_set_fresh(gemhip_n2v_t h, int32_t bits);
 /* Building block of the SGNS kernel, exposed for its own parity test: in[64][6] per-lane partial sums -> out[64], lane l
  * receiving the wave total of value (l & 4) ? 4 + (l & 1) : (l & 3). */
 int gemhip_test_wave_sum6(const float *in_host, float *out_host);
@@ -364,6 +374,15 @@ int gemhip_hope_plan_svd_error(gemhip_hope_plan_t plan, int32_t k, const float *
                                double *err_out, double *frob2_out);
 int gemhip_hope_svd_error(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
                           const float *sigma, const float *V_sqrtS, int32_t probes, uint64_t seed, double *err_out, double *frob2_out);
+/* ... with the U side: ||u diag(s) vt - S||_F^2 = ||S (I - V V^T)||_F^2 + ||S V - U Sigma||_F^2 for orthonormal V (the two parts are orthogonal); the second
+ * term is computed exactly (the Katz series on V's k columns) and is ~0 for a converged solve, so a wrong or unconverged U shows in the number exactly as
+ * it does in hope.py:38-40's.  The V-only forms above report the truncation error an exact SVD with this V would have.  Columns with sigma[j] <= 0 (k
+ * above the rank of S) are skipped.  uside_out (optional): sqrt of the second term alone.  What HOPE(..., verbose=True) prints. */
+int gemhip_hope_plan_svd_error_uv(gemhip_hope_plan_t plan, int32_t k, const float *sigma, const float *U_sqrtS, const float *V_sqrtS, int32_t probes,
+                                  uint64_t seed, double *err_out, double *frob2_out, double *uside_out);
+int gemhip_hope_svd_error_uv(int64_t n, int64_t nnz, const int64_t *row_ptr, const int32_t *col, const float *w, float beta, int32_t k,
+                             const float *sigma, const float *U_sqrtS, const float *V_sqrtS, int32_t probes, uint64_t seed, double *err_out,
+                             double *frob2_out, double *uside_out);
 
 /* ------------------------------------------------ Laplacian Eigenmaps ("next")
  * Replaces gem/embedding/lap.py:21-37: eigs(nx.normalized_laplacian_matrix(graph.to_undirected()), k=d+1, which='SM').

@@ -406,6 +406,26 @@ void oracle_sgns_train_vocab_order(int64_t n_slots, const int32_t *slot_tab, int
  * and prefetches their rows.  tests/test_oracle_n2v.py ties it to the strict function (max |difference| after a small pass at fp32 rounding level);
  * goldens made with it say so in their `engine`.  d must be a multiple of 32.  slot_tab as in sgns_train_core (NULL: slot == entry). */
 typedef float v8f __attribute__((vector_size(32), aligned(4)));
+/* the six targets of the pair (centre position pos, window slot a) -- tg[0] the centre word, tg[1..neg] the negatives, -1 where TrainModel skips
+ * (Target == Word) -- with their SynNeg rows prefetched */
+static inline void wide_targets(int64_t n_slots, const int32_t *slot_tab, const float *UT, const int32_t *KT, uint64_t seed, int64_t wid, int32_t pos,
+                                int32_t a, int32_t epoch, int32_t neg, int32_t word, int32_t d, const float *SynNeg, int32_t *tg)
+{
+    tg[0] = word;
+    for (int32_t j = 1; j < neg + 1; ++j) {
+        const u32x4 rn = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32),
+                                (uint32_t)pos | ((uint32_t)a << 16), TAG_NEG | ((uint32_t)epoch << 8) | ((uint32_t)j << 16));
+        const uint32_t slot = mulhi_range(rn.x, (uint32_t)n_slots);
+        const int32_t X = slot_tab ? slot_tab[slot] : (int32_t)slot;
+        const int32_t target = (u01(rn.y) < UT[X]) ? X : KT[X];
+        tg[j] = (target == word) ? -1 : target;
+        if (tg[j] >= 0) {
+            const char *q = (const char *)(SynNeg + (size_t)target * d);
+            for (int32_t c = 0; c < d * 4; c += 64) __builtin_prefetch(q + c, 1, 1);
+        }
+    }
+}
+
 __attribute__((target("avx2")))
 int32_t oracle_sgns_train_wide(int64_t n_slots, const int32_t *slot_tab, int32_t d, int64_t nwalks, int32_t walk_len, const int32_t *walks,
                                int32_t window, int32_t neg, float alpha0, int32_t epochs, int32_t epoch, int64_t tokens_total,
@@ -413,12 +433,14 @@ int32_t oracle_sgns_train_wide(int64_t n_slots, const int32_t *slot_tab, int32_t
                                int32_t flags, float *SynPos, float *SynNeg)
 {
     (void)flags;
-    if (d % 32 != 0 || neg > 15) return -1;
+    if (d % 32 != 0 || neg > 15 || window > 4096) return -1;
     float *neu1e = (float *)aligned_alloc(64, sizeof(float) * (size_t)d);
+    int32_t *slots = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * window + 2));
     const int64_t denom = (int64_t)epochs * tokens_total + 1;
     for (int64_t wl = 0; wl < nwalks; ++wl) {
         const int32_t *walk = walks + wl * walk_len;
         const int64_t wid = walk_id_offset + wl;
+        if (wl + 1 < nwalks) __builtin_prefetch(walk + walk_len, 0, 1);
         for (int32_t pos = 0; pos < walk_len; ++pos) {
             const int64_t t = token_offset + wl * walk_len + pos;
             const float alpha = sgns_alpha(alpha0, t, denom);
@@ -426,26 +448,26 @@ int32_t oracle_sgns_train_wide(int64_t n_slots, const int32_t *slot_tab, int32_t
             if (word < 0) continue;
             const u32x4 rw = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32), (uint32_t)pos, TAG_WIN | ((uint32_t)epoch << 8));
             const int32_t b = (int32_t)(rw.x % (uint32_t)window);
+            /* the window slots this centre trains on, in TrainModel's order; the pair AFTER the one being trained has its targets drawn and its rows
+             * prefetched already (the draws are counter-based: computing them early changes nothing) */
+            int32_t np = 0;
             for (int32_t a = b; a < window * 2 + 1 - b; ++a) {
                 if (a == window) continue;
                 const int32_t cp = pos - window + a;
-                if (cp < 0 || cp >= walk_len) continue;
-                const int32_t ctx = walk[cp];
-                if (ctx < 0) continue;
+                if (cp < 0 || cp >= walk_len || walk[cp] < 0) continue;
+                slots[np++] = a;
+            }
+            int32_t tga[16], tgb[16];
+            int32_t *tg = tga, *tgn = tgb;
+            if (np > 0) wide_targets(n_slots, slot_tab, UT, KT, seed, wid, pos, slots[0], epoch, neg, word, d, SynNeg, tg);
+            for (int32_t ip = 0; ip < np; ++ip) {
+                const int32_t a = slots[ip];
+                const int32_t ctx = walk[pos - window + a];
                 float *xc = SynPos + (size_t)ctx * d;
-                int32_t tg[16];
-                tg[0] = word;
-                for (int32_t j = 1; j < neg + 1; ++j) {
-                    const u32x4 rn = philox(seed, (uint32_t)wid, (uint32_t)((uint64_t)wid >> 32),
-                                            (uint32_t)pos | ((uint32_t)a << 16), TAG_NEG | ((uint32_t)epoch << 8) | ((uint32_t)j << 16));
-                    const uint32_t slot = mulhi_range(rn.x, (uint32_t)n_slots);
-                    const int32_t X = slot_tab ? slot_tab[slot] : (int32_t)slot;
-                    const int32_t target = (u01(rn.y) < UT[X]) ? X : KT[X];
-                    tg[j] = (target == word) ? -1 : target;
-                    if (tg[j] >= 0) {
-                        const char *q = (const char *)(SynNeg + (size_t)target * d);
-                        for (int32_t c = 0; c < d * 4; c += 64) __builtin_prefetch(q + c, 1, 1);
-                    }
+                if (ip + 1 < np) {
+                    wide_targets(n_slots, slot_tab, UT, KT, seed, wid, pos, slots[ip + 1], epoch, neg, word, d, SynNeg, tgn);
+                    const char *q = (const char *)(SynPos + (size_t)walk[pos - window + slots[ip + 1]] * d);
+                    for (int32_t c = 0; c < d * 4; c += 64) __builtin_prefetch(q + c, 1, 1);
                 }
                 for (int32_t k = 0; k < d; k += 8) *(v8f *)(neu1e + k) = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
                 for (int32_t j = 0; j < neg + 1; ++j) {
@@ -473,10 +495,11 @@ int32_t oracle_sgns_train_wide(int64_t n_slots, const int32_t *slot_tab, int32_t
                     }
                 }
                 for (int32_t k = 0; k < d; k += 8) *(v8f *)(xc + k) += *(const v8f *)(neu1e + k);
+                int32_t *sw = tg; tg = tgn; tgn = sw;
             }
         }
     }
-    free(neu1e);
+    free(neu1e); free(slots);
     return 0;
 }
 

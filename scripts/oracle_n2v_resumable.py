@@ -21,10 +21,12 @@ ap.add_argument('--flags', type=int, default=27)
 ap.add_argument('--out', default=None)
 ap.add_argument('--chunk-walks', type=int, default=150000)
 ap.add_argument('--selftest', action='store_true')
+ap.add_argument('--sbm', default=None, help='nodes,edges,blocks: an SBM (gem_amd.graph.sbm_graph with --seed) instead of the R-MAT graph')
+ap.add_argument('--train-seed', type=int, default=20260923, help='the Philox seed of walks, initial table and draws (the seed the GPU tests train with)')
 ap.add_argument('--wide', action='store_true', help='oracle_sgns_train_wide: the dot product in 32 partial sums (about 4x the speed; the engine string says so)')
 ap.add_argument('--walks-cache', default=None, help='.npy the walk matrix is written to / memory-mapped from (the two layouts train on the same walks: one copy in the page cache)')
 a = ap.parse_args()
-D, L, R, WIN, SEED = 128, 80, 10, 10, 20260923
+D, L, R, WIN, SEED = 128, 80, 10, 10, a.train_seed
 
 
 def run(n, src, dst, flags, out, chunk, d=D, l=L, r=R, wide=False, walks_cache=None):
@@ -86,11 +88,18 @@ if a.selftest:
     print('selftest ok: chunked == one call, bit for bit, both layouts')
     sys.exit(0)
 
-g = rmat_graph(a.rmat_scale, a.edges, a.seed)
+if a.sbm:
+    from gem_amd.graph import sbm_graph
+    nn, ee, bb = [int(v) for v in a.sbm.split(',')]
+    g = sbm_graph(nn, ee, bb, a.seed)
+else:
+    g = rmat_graph(a.rmat_scale, a.edges, a.seed)
 n, src, dst, _, _ = edge_arrays(g)
 P, secs = run(n, src, dst, a.flags, a.out, a.chunk_walks, wide=a.wide, walks_cache=a.walks_cache)
 np.save(a.out, np.asarray(P, dtype=np.float32))
-PARAMS = dict(n=g.n, edges=a.edges, blocks=1, seed=a.seed, d=D, walk_len=L, num_walks=R, window=WIN, p=1.0, q=1.0, rmat_scale=a.rmat_scale, flags=a.flags)
+PARAMS = dict(n=g.n, edges=a.edges, blocks=1, seed=a.seed, d=D, walk_len=L, num_walks=R, window=WIN, p=1.0, q=1.0, rmat_scale=a.rmat_scale, flags=a.flags, train_seed=SEED)
+if a.sbm:
+    PARAMS.update(edges=ee, blocks=bb); del PARAMS['rmat_scale']
 engine = 'oracle/n2v_oracle.c (sequential restatement of SNAP)' + (', unigram table in the binary\'s vocabulary-order layout' if a.flags & 16 else '') + \
          (', oracle_sgns_train_wide (dot product in 32 interleaved partial sums)' if a.wide else '') + \
          '; run in resumable chunks (scripts/oracle_n2v_resumable.py)'

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Round 6: what does the FRESHNESS of hot rows buy on a power-law graph?  One Hogwild launch of node2vec.learn_embedding per configuration
-`W:fresh:flags` (GEMHIP_SGNS_MAX_WAVES : GEMHIP_SGNS_FRESH : unigram-table layout 11 | 27; W = 0 lets the planner choose) on R-MAT scale 17 / 20, each
+`W:fresh:flags[:hot_count[:neg_count]][*repeats]` (GEMHIP_SGNS_MAX_WAVES : GEMHIP_SGNS_FRESH : unigram-table layout 11 | 27 : GEMHIP_SGNS_HOT_COUNT :
+GEMHIP_SGNS_NEG_COUNT; W = 0 lets the planner choose) on R-MAT scale 17 / 20, each
 paired per node with the sequential oracle's APs of tests/golden/n2v_ref_oracle_rmat{17,20}*_e{16k,128k}.json (same graph, seed and node sample as
 tests/test_rmat_gpu.py).  With GEM_HIP_LIB=gem_amd/libgem_hip_stale.so (scripts/build_variant.sh stale -DGEMHIP_SGNS_STALENESS) every launch also
 appends its staleness histogram to $GEMHIP_SGNS_STALENESS_OUT.
@@ -33,10 +34,21 @@ g = rmat_graph(pr['rmat_scale'], pr['edges'], pr['seed'])
 nodes = gr.eligible_sample(g, len(next(iter(gold.values()))['ap']))
 os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
 log = open(a.out, 'a')
-for cfg in a.configs.split(','):
-    W, fresh, fl = [int(v) for v in cfg.split(':')]
+cfgs = []
+for cfg in a.configs.split(','):            # W:fresh:flags[:hot_count[:neg_count]][*repeats]
+    rep = 1
+    if '*' in cfg:
+        cfg, rep = cfg.split('*'); rep = int(rep)
+    cfgs += [cfg] * rep
+for cfg in cfgs:
+    f = [int(v) for v in cfg.split(':')]
+    W, fresh, fl = f[:3]
+    hot, negc = (f[3] if len(f) > 3 else -1), (f[4] if len(f) > 4 else 0)
     if fl not in gold:
         continue
+    if hot >= 0: os.environ['GEMHIP_SGNS_HOT_COUNT'] = str(hot)
+    else: os.environ.pop('GEMHIP_SGNS_HOT_COUNT', None)
+    os.environ['GEMHIP_SGNS_NEG_COUNT'] = str(negc)
     ref = gold[fl]
     if W > 0: os.environ['GEMHIP_SGNS_MAX_WAVES'] = str(W)
     else: os.environ.pop('GEMHIP_SGNS_MAX_WAVES', None)
@@ -47,7 +59,7 @@ for cfg in a.configs.split(','):
     wall = time.time() - t
     apv = gr.sampled_ap_gpu(g, None, X, nodes)
     dd = apv - np.asarray(ref['ap'])
-    rec = {'scale': a.scale, 'max_waves': W, 'fresh': fresh, 'flags': fl, 'sgns_s': round(m._stats['sgns_seconds'], 3), 'wall_s': round(wall, 2),
+    rec = {'scale': a.scale, 'max_waves': W, 'fresh': fresh, 'flags': fl, 'hot_count': hot, 'neg_count': negc, 'sgns_s': round(m._stats['sgns_seconds'], 3), 'wall_s': round(wall, 2),
            'MAP': float(apv.mean()), 'oracle_MAP': ref['MAP'], 'gap_pct': float(100 * dd.mean() / ref['MAP']),
            'gap_se_pct': float(100 * dd.std(ddof=1) / np.sqrt(len(dd)) / ref['MAP']), 'nodes': int(len(dd)), 'lib': os.environ.get('GEM_HIP_LIB', 'default')}
     s = json.dumps(rec)

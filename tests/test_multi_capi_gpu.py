@@ -255,6 +255,12 @@ def test_plugin_gf_n_gpus_is_the_one_gpu_table(ranks):
     many = GraphFactorization(n_gpus=ranks, virtual_ranks=True, **kw)
     XN = many.learn_embedding(graph=g, is_weighted=True, no_python=True)
     assert XN.dtype == np.float64 and np.array_equal(X1, XN)
+    # (seed=s with device_init=False is the numpy draw RandomState(s) through the one-shot gemhip_gf_train path -- the reference convention's
+    # reproducible form; seed=s alone draws on the device since round 5)
+    n, src, dst, w, _ = edge_arrays(g)
+    X0 = (0.01 * np.random.RandomState(5).randn(n, 32)).astype(np.float32)
+    ref = oracle.gf_train_f32(n, src, dst, None, 32, 0.05, 0.01, 6, X0)
+    assert np.abs(X1 - ref).max() <= 2e-5 * np.abs(ref).max()
     assert many._stats['driver'] == 'gemhip_gf_train_multi' and many._stats['n_gpus'] == ranks and many._stats['virtual_ranks']
     assert 'n_gpus' not in GraphFactorization.hyper_params
 

@@ -15,7 +15,7 @@ from gem_amd.embedding.gf import GraphFactorization
 from gem_amd.embedding.hope import HOPE
 from gem_amd.embedding.node2vec import node2vec
 from gem_amd.evaluation import reconstruction as gr
-from gem_amd.graph import edge_arrays
+from gem_amd.graph import edge_arrays, to_csr
 from test_n2v_gpu import Dev, SNAP
 
 pytestmark = pytest.mark.gpu
@@ -89,6 +89,23 @@ def test_verbose_prints_what_the_reference_prints(sbm1024, karate, capsys):
         want = float(np.linalg.norm((u[:, :k] * s[:k]) @ vt[:k] - S))
         assert abs(got - want) <= 0.01 * want, (got, want)
         assert abs(m._svd_error - got) < 1e-5 and 'verbose' not in HOPE.hyper_params
+        assert m._svd_error_u_side <= 2e-3 * want                  # a converged solve: the U side adds nothing visible
+        # ... and a WRONG U shows (the V-only estimate reported the ideal truncation error whatever U held): the print follows the dense value
+        row_ptr, col, ww = to_csr(n, src, dst, w)
+        sig = np.ascontiguousarray(m._sigma, dtype=np.float32)
+        U = np.ascontiguousarray(Y[:, :k], dtype=np.float32); V = np.ascontiguousarray(Y[:, k:], dtype=np.float32)
+        Ubad = U.copy(); Ubad[:, -1] *= 0.5                        # the leading left vector at half length
+        err = C.c_double(); us = C.c_double()
+        _hip.check(_hip.lib().gemhip_hope_svd_error_uv(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), _hip.ptr(ww, C.c_float), 0.01, k,
+                                                       _hip.ptr(sig, C.c_float), _hip.ptr(Ubad, C.c_float), _hip.ptr(V, C.c_float), 32, 1, C.byref(err), None, C.byref(us)))
+        un, vn = Ubad / np.sqrt(sig), V / np.sqrt(sig)
+        want_bad = float(np.linalg.norm((un * sig) @ vn.T - S))
+        assert abs(err.value - want_bad) <= 0.01 * want_bad and us.value == pytest.approx(0.5 * float(sig[-1]), rel=1e-3), (err.value, want_bad, us.value)
+        # k above the rank: a zero singular value is skipped, not an error
+        sig0 = sig.copy(); sig0[0] = 0.0
+        _hip.check(_hip.lib().gemhip_hope_svd_error_uv(n, len(col), _hip.ptr(row_ptr, C.c_int64), _hip.ptr(col, C.c_int32), _hip.ptr(ww, C.c_float), 0.01, k,
+                                                       _hip.ptr(sig0, C.c_float), _hip.ptr(U, C.c_float), _hip.ptr(V, C.c_float), 32, 1, C.byref(err), None, None))
+        assert err.value >= got * (1 - 1e-3)
     # the default stays silent
     HOPE(d=4, beta=0.01).learn_embedding(graph=karate)
     assert capsys.readouterr().out == ''
