@@ -1106,35 +1106,24 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         // gradients cost nothing up to there -- CPU replay at 0.4 %, SBM 100k at 0.8 %, R-MAT scale 17 at 2.0 % of the active rows; R-MAT scale 13 with
         // 26 % of its 5 936 active rows open ended 21 % ABOVE the sequential algorithm's MAP: its hubs under-trained)
         const int64_t w_act = std::max<int64_t>(1, (int64_t)((vs.active > 0.0 ? vs.active : (double)n) / 50.0));
-        // ... and never more than keeps CONCURRENT TOUCHES OF THE SAME ROW rare (round 5).  A pair touches six rows besides the centre's: its context
-        // (a node drawn by token share p) and five negatives (drawn by q = unigram^0.75).  Hot rows take those touches as atomic adds of a gradient that
-        // was computed from a copy one to two pair steps old -- nothing is lost, but with c other wavefronts touching the same row inside that window
-        // the row moves (1 + c) x as far as TrainModel would move it.  For a random touch c = (W - 1) x s x sum_v (p_v + 5 q_v)^2 / 6 (s ~ 2 pair steps).
-        // Measured on R-MAT scale 17 against the sequential oracle, paired over 16 384 nodes that have a ranked neighbour (s.e. 0.3 %; three launches per
-        // width and layout, profiles/r05_rmat17_width_sweep.jsonl): c = 0.16 / 0.25 / 0.33 / 0.5 / 0.66 / 1.0 (128 / 192 / 256 / 384 / 512 / 768
-        // wavefronts) -> -0.1 / -0.5 / -0.9 / -2.3 / -4.2 / -6.3 % of the MAP in the binary's table layout (node-id layout: -0.2 / -0.2 / +0.2 / +0.4 /
-        // -1.7 / -2.4 %), while rho over the cold rows stayed under 1.5 % throughout: round 3's rule (602 wavefronts there) measured -3.7 %, and its
-        // 2 048-node uniform sample, two thirds of it nodes without a ranked neighbour, could not see it.  The same family three doublings up (R-MAT scale 20,
-        // sequential oracle: 3.7 h per layout; paired over 131 072 eligible nodes, s.e. 0.4 %) is MORE sensitive at the same width, not less: 256 wavefronts
-        // (c = 0.07) -1.9 %, 688 (c = 0.2) -6.4 % / -8.3 % (profiles/r05_rmat20_launches_e128k.jsonl) -- the reconstruction MAP of a barely trained
-        // million-node embedding (0.003) moves more per unit of perturbation than scale 17's (0.018).  Bound, set by the worse of the two graphs, on the
-        // part of touch2 that HUBS contribute -- touch2 minus the 40 / active a table of equally frequent rows has (SBM: 38 / n; those graphs stay on the rho
-        // rule they were validated on) --: (W - 1) x touch2_hub <= 0.165: 50 wavefronts on scale 17, 207 on scale 20, 548 on scale 22.  Scale 22 itself
-        // has no oracle (15 h per layout): its width is this extrapolation.
-        // (How far the picture above carries: the CPU replay of exactly that picture -- lossless additive updates from copies two pairs old, round-robin
-        // wavefronts, scripts/hogwild_emul -- gives +0.6 / -3.4 % at 512 / 768 virtual wavefronts on scale 17 in the binary's layout and -1.6 % at 768 in the
-        // node-id layout, where the device measures -4.2 / -6.3 and -2.4 %: the right sign and layout order, half the size, a later onset; nothing on scale
-        // 15 up to 384.  The bound is a fit through the oracle-pinned points.  DESIGN.md 3.3 (4), section 7.)
-        // The NODE-ID table layout (flags without GEMHIP_N2V_VOCAB_ORDER; an opt-in since round 4) gets HALF that bound.  Under RndUnigramInt's quirk the
-        // negatives are drawn from the alias TARGETS only, so the distribution actually sampled is a function of Vose's pairing, i.e. of the table order
-        // (the two layouts are different samplers: the sequential oracle's MAP differs by 8.7 % on scale 17 and 18.9 % on scale 20 between them), and
-        // p, q above are the nominal ones.  Measured on scale 20 in that layout: 688 / 207 / 104 wavefronts -> -8.3 / -6.3 / -1.5 % (s.e. 0.9 / 0.9 / 0.6 %),
-        // i.e. it needs half the width the binary's layout does there (207: -1.5 %), while on scale 17 it was the LESS sensitive one; none of the
-        // statistics of the actually sampled distribution that were tried (its touch2, its largest row load, its collision rate over the cold rows:
-        // scripts/study_negative_distribution.py) orders the two layouts on both graphs, so this is a per-layout calibration on the worse graph.
-        const double touch_bound = kn.node_id_layout ? 0.0825 : 0.165;
+        // ... and, on graphs with hubs, never more than the CONCURRENT-TOUCH bound of round 5: (W - 1) x touch2_hub <= 0.165, touch2_hub = the hubs' part of
+        // sum_v (p_v + 5 q_v)^2 (p = token share: the context; q = unigram^0.75 share: the five negatives) -- minus the 40 / active a table of equally frequent
+        // rows has, so that SBM graphs stay on the rho rule they were validated on.  What round 6 found out about it (profiles/r06_*.jsonl):
+        //  * the bound was fitted through launches whose gaps were dominated by a HEAVY TAIL that has nothing to do with hubs: an isolated edge trained by two
+        //    wavefronts at once (LOCALLY HOT ROWS, ensure_hotkey below -- now handled; launches at one width agree to 0.2 % where they scattered over 6 %);
+        //  * the staleness of the hubs' gradients is not the cause either: instrumented (GEMHIP_SGNS_STALENESS), the top hub's row takes 22 foreign updates
+        //    between a wavefront's read and its add at 768 wavefronts; fresh reads / returning atomics cut that to 6 and the gap does not move; making every
+        //    Hogwild write a lossless add makes it slightly WORSE; lowering the hot-row threshold 2-16x makes it worse and slower;
+        //  * what is left is smooth in the width and larger on the larger graph -- R-MAT scale 17: -0.45 / -1.6 / -1.8 % at 256 / 768 / 1 536 wavefronts, scale 20:
+        //    -1.3 / -3.0 / -6.0 % (paired with the sequential oracle, s.e. 0.3-0.5 %, 2-4 launches each) -- carried by query nodes of 1 000..30 000 tokens, and
+        //    slower launches of the same configuration are the worse ones (queueing of the hot rows' atomic adds at the memory side is the suspect).
+        // So the bound stays as the conservative extrapolation it is (548 wavefronts on scale 22, where the oracle pins it: tests/test_rmat_gpu.py), with a
+        // FLOOR of 256 wavefronts: at 256 both measured graphs are at or inside -1.3 % (round 5's 50 wavefronts on scale 17 bought nothing for 3.5x the time:
+        // ADVICE r5), and ONE bound for both unigram-table layouts -- round 5 halved it for the node-id layout on the strength of two launches (-6.3 % at 207
+        // wavefronts) that the heavy tail explains; after the fix the layouts measure alike (scale 20, 768 wavefronts: -2.7 / -3.3 % and -2.5 / -4.3 %).
+        const double touch_bound = 0.165;
         const double touch2_hub = std::max(0.0, vs.touch2 - 40.0 / std::max(1.0, vs.active > 0.0 ? vs.active : (double)n));
-        const int64_t w_touch = touch2_hub > 0.0 ? std::max<int64_t>(1, 1 + (int64_t)std::min(1e15, touch_bound / (touch2_hub * kn.touch_scale))) : INT64_MAX;
+        const int64_t w_touch = touch2_hub > 0.0 ? std::max<int64_t>(256, 1 + (int64_t)std::min(1e15, touch_bound / (touch2_hub * kn.touch_scale))) : INT64_MAX;
         auto width = [&](bool all_cached) -> int64_t {
             // registers: the single-GPU kernels allocate 176-184 VGPRs (2 wavefronts per SIMD = 8 per CU), the bucket kernels 136-145 (3 per SIMD = 12 per CU)
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(kn.part ? 12 : 8, (int64_t)(160 * 1024) / (int64_t)(lds_bytes(P.delta, all_cached) + 512)));
@@ -1496,6 +1485,22 @@ extern "C" int gemhip_sgns_set_hot_rows(gemhip_n2v_t h, int32_t min_count)
 {
     GEMHIP_REQUIRE(h && min_count >= -1, "sgns_set_hot_rows: bad arguments");
     h->kn.hot_count = min_count;
+    return GEMHIP_OK;
+}
+
+extern "C" int gemhip_n2v_locally_hot(gemhip_n2v_t h, int32_t per_walk, int64_t *count, int32_t *hotkey_host)
+{
+    GEMHIP_REQUIRE(h && per_walk >= -1, "n2v_locally_hot: bad arguments");
+    GEMHIP_REQUIRE(h->d_walks && h->nwalks > 0, "n2v_locally_hot: no walks on this handle");
+    if (per_walk >= 0 && per_walk != h->kn.local_hot) { h->kn.local_hot = per_walk; h->hotkey_state = 0; }
+    if (h->kn.local_hot == 0) {            // off: nothing is locally hot, the key is the token count
+        if (count) *count = 0;
+        if (hotkey_host) GEMHIP_CHECK(hipMemcpy(hotkey_host, h->d_counts, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return GEMHIP_OK;
+    }
+    { const int rc = ensure_hotkey(h, nullptr); if (rc) return rc; }
+    if (count) *count = h->n_local_hot;
+    if (hotkey_host) GEMHIP_CHECK(hipMemcpy(hotkey_host, h->d_hotkey, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return GEMHIP_OK;
 }
 

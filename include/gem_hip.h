@@ -247,9 +247,21 @@ int gemhip_sgns_plan_launch(const int32_t *counts, int64_t n, int32_t d, int32_t
  * wavefronts, hot-row token threshold, and the FRESH HOT ROWS bits in force (0 when the launch had no hot rows).  bench.py reports this instead of
  * replaying the planner.  Any out pointer may be NULL. */
 int gemhip_sgns_last_launch(gemhip_n2v_t h, int32_t *kernel, int32_t *waves, int32_t *hot_threshold, int32_t *fresh);
+/* LOCALLY HOT ROWS.  A node whose tokens are packed into few walks -- at least `per_walk` tokens per walk that contains it (default 8; 0 = off; -1 keeps the
+ * handle's setting) -- sits in the LDS window of every such walk from its first token to its last, not for 2R+1 centres: the two nodes of an isolated edge
+ * make up all 80 tokens of each of their 20 walks.  Two wavefronts training two of those walks at once each apply a whole walk's worth of updates to the
+ * same base and both deltas are added (measured on R-MAT scale 17: one such pair ends with 14 % more norm than its peers and outranks the true neighbour of
+ * dozens of them: 2-5 % of the graph's reconstruction MAP per event).  Hogwild launches of gemhip_sgns_train therefore treat these nodes as hot rows whatever
+ * their token count (never cached; per-pair reads and atomic adds).  This call builds the key the kernels compare with the hot-row threshold from the walks
+ * and counts on the handle -- hotkey[v] = INT32_MAX for a locally hot node, else its token count -- and returns how many nodes are locally hot and,
+ * optionally, the key (n int32, host).  Needs the WHOLE corpus on the handle (a rank's shard against all-reduced counts would flag everything: the launch
+ * skips the rule there).  No reference counterpart (the binary's threads read and write rows in place). */
+int gemhip_n2v_locally_hot(gemhip_n2v_t h, int32_t per_walk, int64_t *count, int32_t *hotkey_host);
 /* FRESH HOT ROWS (Hogwild launches that have hot rows; gem_amd/csrc/sgns.hpp SgnsArgs::fresh).  bit 0: a hot centre word's positive row takes every
  * pair's update as a returning atomic add and continues from the returned row; bit 1: hot negative rows are re-read right before the dot products.
- * Both shorten the time between reading a hub row and adding a gradient computed from it.  No reference counterpart (the binary's Hogwild threads
+ * bit 2 (value 4): every negative row with at least GEMHIP_SGNS_NEG_COUNT tokens is updated by atomic add instead of reload + store.
+ * Bits 0 and 1 shorten the time between reading a hub row and adding a gradient computed from it (measured: the hubs' staleness falls 4x, the MAP gap does
+ * not move: profiles/r06_*.jsonl); all three are A/B knobs, off by default.  No reference counterpart (the binary's Hogwild threads
  * read and write rows in place). */
 int gemhip_sgns_set_fresh(gemhip_n2v_t h, int32_t bits);
 /* Building block of the SGNS kernel, exposed for its own parity test: in[64][6] per-lane partial sums -> out[64], lane l

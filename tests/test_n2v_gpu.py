@@ -460,3 +460,121 @@ def test_sgns_deterministic_with_the_binarys_table_layout_matches_oracle(gname, 
         scale = float(np.abs(want).max())
         assert float(np.abs(got - want).max()) <= 2e-4 * scale + 1e-6, (np.abs(got - want).max(), scale)
     dev.close()
+
+
+def _graph_with_isolated_edges(n_core=4096, iso_pairs=12, seed=3):
+    """An SBM core plus `iso_pairs` two-node components and one three-node path appended after it (ids >= n_core)."""
+    g = sbm_graph(n_core, n_core * 10, 4, seed=seed)
+    n, src, dst, w, _ = edge_arrays(g)
+    extra_s, extra_d = [], []
+    v = n
+    for _ in range(iso_pairs):
+        extra_s += [v, v + 1]; extra_d += [v + 1, v]; v += 2
+    extra_s += [v, v + 1, v + 1, v + 2]; extra_d += [v + 1, v, v + 2, v + 1]; v += 3
+    src = np.concatenate([src, np.asarray(extra_s, np.int32)]); dst = np.concatenate([dst, np.asarray(extra_d, np.int32)])
+    return v, src, dst
+
+
+def test_locally_hot_rows_key_is_tokens_per_containing_walk():
+    """gemhip_n2v_locally_hot (round 6): hotkey[v] = INT32_MAX where count[v] >= per_walk x (walks that contain v), else count[v] -- integer work, equal to a
+    numpy restatement on the walks the device made.  On an SBM nobody qualifies (a node meets a walk about once); the nodes of two-node components make up
+    whole walks (40 tokens per walk each) and all qualify, at any sensible threshold."""
+    n, src, dst = _graph_with_isolated_edges()
+    dev = Dev(n, src, dst, None)
+    walks = dev.walks(1.0, 1.0, 10, 80, 11, SNAP)
+    cnt, _, _ = dev.unigram()
+    sw = np.sort(walks, axis=1); first = np.ones_like(sw, bool); first[:, 1:] = sw[:, 1:] != sw[:, :-1]
+    wc = np.bincount(sw[first & (sw >= 0)], minlength=n)
+    for per_walk in (8, 3, 30):
+        want_hot = (wc > 0) & (cnt.astype(np.int64) >= per_walk * wc.astype(np.int64))
+        key = np.empty(n, np.int32); k = C.c_int64()
+        _hip.check(dev.L.gemhip_n2v_locally_hot(dev.h, per_walk, C.byref(k), _hip.ptr(key, C.c_int32)))
+        assert k.value == int(want_hot.sum()) and np.array_equal(key, np.where(want_hot, np.iinfo(np.int32).max, cnt))
+    want8 = (wc > 0) & (cnt >= 8 * wc)
+    assert want8[4096:].all() and not want8[:4096].any()          # the appended components, and nothing of the SBM core
+    _hip.check(dev.L.gemhip_n2v_locally_hot(dev.h, 0, C.byref(k), _hip.ptr(key, C.c_int32)))
+    assert k.value == 0 and np.array_equal(key, cnt)
+    dev.close()
+
+
+def test_locally_hot_rows_change_the_launch_not_the_deterministic_result():
+    """A Hogwild launch on a corpus with locally hot nodes and no count-hot rows carries the hot-row machinery with the threshold INT32_MAX (only the locally hot
+    nodes qualify: gemhip_sgns_last_launch); switched off, the launch is the all-cached one again; the deterministic launch (one wavefront) ignores the rule
+    and stays on the oracle."""
+    n, src, dst = _graph_with_isolated_edges(n_core=16384, iso_pairs=6)
+    dev = Dev(n, src, dst, None)
+    dev.walks(1.0, 1.0, 2, 40, 11, SNAP); dev.unigram()
+    k, wv, hot, fr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    dev.sgns(32, 5, 1, 11, SNAP)
+    _hip.check(dev.L.gemhip_sgns_last_launch(dev.h, C.byref(k), C.byref(wv), C.byref(hot), C.byref(fr)))
+    assert k.value == 2 and wv.value > 1 and hot.value == np.iinfo(np.int32).max
+    cnt = C.c_int64(); _hip.check(dev.L.gemhip_n2v_locally_hot(dev.h, 0, C.byref(cnt), None))
+    dev.sgns(32, 5, 1, 11, SNAP)
+    _hip.check(dev.L.gemhip_sgns_last_launch(dev.h, C.byref(k), C.byref(wv), C.byref(hot), C.byref(fr)))
+    assert k.value == 2 and hot.value == 0
+    _hip.check(dev.L.gemhip_n2v_locally_hot(dev.h, 8, C.byref(cnt), None))
+    assert cnt.value == 6 * 2 + 3
+    P, N = dev.sgns(32, 5, 1, 11, SNAP | 4)
+    _hip.check(dev.L.gemhip_sgns_last_launch(dev.h, C.byref(k), C.byref(wv), C.byref(hot), C.byref(fr)))
+    assert wv.value == 1 and hot.value == 0
+    walks = np.empty((dev_nwalks(dev), 40), np.int32); _hip.check(dev.L.gemhip_n2v_get_walks(dev.h, _hip.ptr(walks, C.c_int32)))
+    c = oracle.n2v_vocab(n, walks); UT, KT = oracle.unigram_build(c)
+    Po, No = oracle.sgns_init(n, 32, 11)
+    oracle.sgns_train(walks, 5, 0.025, 1, 0, walks.size, 0, 0, UT, KT, 11, SNAP, Po, No)
+    assert float(np.abs(P - Po).max()) <= 2e-4 * float(np.abs(Po).max()) + 1e-6
+    dev.close()
+
+
+def dev_nwalks(dev):
+    nw = C.c_int64(); wl = C.c_int32(); p = C.c_void_p()
+    _hip.check(dev.L.gemhip_n2v_walks_ptr(dev.h, C.byref(p), C.byref(nw), C.byref(wl)))
+    return nw.value
+
+
+@pytest.mark.hogwild_stat
+def test_two_wavefronts_on_one_isolated_edge_no_longer_double_its_norm():
+    """The heavy tail of round 5's power-law 'Hogwild bias', reproduced on purpose.  Corpus: the walks of an 8 192-node SBM (two per node) and the 20 walks of
+    each of 64 isolated edges, laid out so that the two walks of a pair that start in the same round are NEIGHBOURS in the walk order -- two wavefronts train
+    them at the same time, every time (on a real graph that is a chance event whose probability grows with the width).  With the LDS window holding both
+    rows for the whole walk (rule off: the pairs' 800 tokens are far below the count threshold) each wavefront applies a walk's worth of updates to the same
+    base and both deltas are added: the rows overshoot.  As locally hot rows (default) they are read and updated pair by pair.  Yardstick: the sequential
+    oracle on the same walk matrix (mean row norm of the 128 pair nodes)."""
+    core, pairs, d, L = 8192, 64, 128, 80
+    g = sbm_graph(core, core * 10, 4, seed=3)
+    n0, s0, d0, _, _ = edge_arrays(g)
+    n = n0 + 2 * pairs
+    ps = np.arange(n0, n, 2, dtype=np.int32)
+    src = np.concatenate([s0, ps, ps + 1]); dst = np.concatenate([d0, ps + 1, ps])
+    base = oracle.n2v_walks(*oracle.sorted_csr(n0, s0, d0, None)[:2], None, None, 1.0, 1.0, 2, L, 5, SNAP)
+    rows, b = [], 0
+    for c in range(10):
+        for p in range(pairs):
+            a = np.empty(L, np.int32); a[0::2] = ps[p]; a[1::2] = ps[p] + 1          # the walk from i: i, j, i, j, ...
+            rows += [a, np.roll(a, 1)]                                                 # ... and the one from j, right behind it
+            rows += list(base[b:b + 10]); b += 10                                      # (spacers: the next pair's couple is 12 walks on)
+    rows += list(base[b:])
+    walks = np.ascontiguousarray(np.stack(rows), dtype=np.int32)
+    c = oracle.n2v_vocab(n, walks); UT, KT = oracle.unigram_build(c)
+    Po, No = oracle.sgns_init(n, d, 5)
+    oracle.sgns_train_wide(walks, 10, 0.025, 1, 0, walks.size, 0, 0, None, UT, KT, 5, SNAP, Po, No)
+    ref = float(np.linalg.norm(Po[n0:], axis=1).mean())
+    norms, hots = {}, {}
+    for rule in (8, 0):
+        dev = Dev(n, src, dst, None)
+        _hip.check(dev.L.gemhip_n2v_set_walks(dev.h, _hip.ptr(walks, C.c_int32), walks.shape[0], L, 0))
+        dev.unigram()
+        k = C.c_int64(); _hip.check(dev.L.gemhip_n2v_locally_hot(dev.h, rule, C.byref(k), None))
+        hots[rule] = k.value
+        _hip.check(dev.L.gemhip_n2v_set_max_waves(dev.h, 64))
+        P, _ = dev.sgns(d, 10, 1, 5, SNAP)
+        kk, wv, hot, fr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _hip.check(dev.L.gemhip_sgns_last_launch(dev.h, C.byref(kk), C.byref(wv), C.byref(hot), C.byref(fr)))
+        assert wv.value == 64 and (hot.value == 0 or hot.value > 800)                  # the pairs are NOT hot by count
+        norms[rule] = float(np.linalg.norm(P[n0:], axis=1).mean())
+        dev.close()
+    assert hots == {8: 2 * pairs, 0: 0}
+    from conftest import record_stat
+    record_stat('64 isolated edges whose walks are trained two at a time (64 wavefronts): mean row norm against the sequential oracle (%.3f)' % ref,
+                'locally hot rows %+.1f %%, rule off %+.1f %%' % (100 * (norms[8] / ref - 1), 100 * (norms[0] / ref - 1)), 'rule on: +-5 %; off: >= 5 points above it')
+    assert abs(norms[8] / ref - 1) <= 0.05, (norms, ref)
+    assert norms[0] / ref >= norms[8] / ref + 0.05, (norms, ref)

@@ -70,42 +70,32 @@ def test_node2vec_hogwild_map_on_power_law_graph(rmat):
 
 @pytest.mark.hogwild_stat
 @pytest.mark.parametrize('layout', ['node_id', 'vocab_order'])
-@pytest.mark.parametrize('scale', [17, 20])
+@pytest.mark.parametrize('scale', [17, 20, 22])
 def test_rmat_default_concurrency_lands_on_the_sequential_oracle(scale, layout):
-    """The Hogwild defaults on a SECOND graph family at >= scale 17: R-MAT scale 17 -- 131 072 nodes, 1.86 M edges, max degree 9 510, the top hub 0.5 % of
-    all tokens -- against the sequential oracle's run on the same seed AND the same unigram-table layout: `node_id` = flags 11, `vocab_order` = flags 27,
-    the plugin default (the binary's layout).  ONE launch, bar 3 %.
+    """The Hogwild defaults on a SECOND graph family: R-MAT scale 17 (131 072 nodes, 1.86 M edges, max degree 9 510, the top hub 0.5 % of all tokens), scale
+    20 (1 048 576 nodes, 15.4 M edges, 432 M tokens) and scale 22 (BASELINE configs[4]: 4.2 M nodes, 62 M edges, 1.59 G tokens; golden made in round 6,
+    skipped until it is committed) against the sequential oracle's run on the same seed AND the same unigram-table layout: `node_id` = flags 11,
+    `vocab_order` = flags 27, the plugin default (the binary's layout).  ONE launch each.
 
-    The statistic (round 5).  Rounds 2-4 paired per-node APs over 2 048 uniformly sampled nodes (n2v_ref_oracle_rmat17*.json).  metrics.computeMAP
-    ranks the candidates j > i only, so 1 362 of those nodes score 0 by construction and the other 686 sum to 11: one node whose only neighbour lands
-    on rank 1 moves that "gap" by 9 % (round 4's driver run: +2.1, +7.7, +8.8 % on one box; -3.4 % on another).  The goldens read here
-    (n2v_ref_oracle_rmat17*_e16k.json, scripts/make_golden_n2v_scale.py --eligible-sample 16384 on the same 1 480 s oracle runs) hold the oracle's AP
-    for 16 384 nodes drawn from the 44 073 that HAVE a ranked neighbour (reconstruction.eligible_sample): the paired gap of one launch has a
-    standard error of 0.3 %.
-    The rule.  With that statistic round 3's launch rule (602 wavefronts here) measured -3.7 % (vocab order) / -3.4 % (node id) over nine launches on
-    two boxes, launch to launch anywhere between +0.9 and -6.7 %: the hubs' atomic updates carry gradients computed one to two pair steps earlier, and
-    with W wavefronts (W - 1) x s x sum (p_v + 5 q_v)^2 / 6 others touch the same row inside that window.  The planner now bounds that number at 0.2
-    (n2v.hip plan_sgns_launch; at 155 wavefronts: -0.41 % / +0.14 % over 24 launches on two boxes, profiles/r05_rmat17_launches.jsonl; the sweep measured
-    -0.1 ... -0.9 % at 128 - 256 wavefronts, profiles/r05_rmat17_width_sweep.jsonl).
-    Scale 20 (1 048 576 nodes, 15.4 M edges, 432 M tokens; 3.7 h of CPU per oracle run, scripts/oracle_n2v_resumable.py): the same family three doublings up
-    -- the largest power-law graph the sequential oracle has been run on (BASELINE configs[4] is scale 22) -- and MORE sensitive at the same width: with
-    the bound as first calibrated on scale 17 alone (688 wavefronts) it measured -6.4 % (binary's layout) / -8.3 % (node id), at 256 wavefronts -1.9 %
-    (profiles/r05_rmat20_launches_e128k.jsonl; paired over 131 072 eligible nodes, s.e. 0.4 %).  The bound was tightened to the worse graph ((W - 1) x
-    touch2_hub <= 0.165: 207 wavefronts here, 50 on scale 17): the default layout then measures -1.51 % (s.e. 0.34 %).  north_star's 1 % is NOT met at
-    scale 20; the bar here is 5 %.
-    The node-id layout at scale 20 measured -6.29 % (s.e. 0.92 %) at those 207 wavefronts (profiles/r05_pytest_gpu_final2_scale20_node_id_failed.log) and
-    -1.50 % (s.e. 0.64 %) at 104 (profiles/r05_rmat20_node_id_104_wavefronts.log): the two layouts are different SAMPLERS under RndUnigramInt's quirk
-    (only alias targets are ever drawn, so the distribution follows Vose's pairing, i.e. the table order: the oracle's own MAP differs by 18.9 % between
-    them here, 8.7 % on scale 17, +8.0 ... +9.4 % over four seeds on scale 14 with a seed-to-seed s.d. of 0.6 %: profiles/r05_oracle_layout_vs_seed_rmat14.json),
-    and none of the statistics of the sampled distribution that were tried orders their sensitivity on both graphs
-    (profiles/r05_negative_distribution_by_layout.json).  The planner therefore halves the bound for that layout (25 / 104 / 274 wavefronts on scale
-    17 / 20 / 22): a calibration on ONE launch, made with the last GPU minutes of the round -- the 104 wavefronts were set through GEMHIP_SGNS_MAX_WAVES,
-    which gives the same launch the rule now plans (tests/test_sgns_plan.py); scale 17 at 25 wavefronts has not been run."""
+    The statistic.  metrics.computeMAP ranks the candidates j > i only, so a uniformly sampled node of a power-law graph scores 0 by construction two times
+    out of three; the goldens hold the oracle's AP for nodes drawn from those that HAVE a ranked neighbour (reconstruction.eligible_sample: 16 384 of them
+    on scale 17 -- their APs sum to 265 --, 131 072 on scale 20 / 22), paired per node: s.e. 0.3-0.5 % per launch.
+    What the gap is made of (round 6; profiles/r06_*.jsonl).  (1) A heavy tail, now fixed: the two rows of an isolated edge make up every
+    token of their 20 walks and sat in the LDS windows of two wavefronts at once for a whole walk whenever two of those walks were in flight together
+    (probability ~ width); both walks' worth of updates were added and the pair ended with 14 % more norm than the ~80 other pairs of the graph, all nearly
+    collinear (cosine 0.93), whose true neighbour it then outranked: 2-5 % of the graph's MAP per event, launches at one width anywhere between -2 and -8 %.
+    Such nodes are now LOCALLY HOT (tokens per walk that contains them >= 8: never cached); launches at one width agree to 0.2 %.  (2) A smooth rest, not
+    understood: -0.45 / -1.6 / -1.8 % at 256 / 768 / 1 536 wavefronts on scale 17, -1.3 / -3.0 / -6.0 % on scale 20, the same in both layouts; it is NOT
+    the staleness of the hubs' gradients (fresh reads cut it 4x and change nothing), NOT lost updates (all-atomic writes are no better), NOT too few hot
+    rows (a lower threshold is worse).  The planner keeps round 5's concurrent-touch bound with a floor of 256 wavefronts: 256 on scale 17 and 20, 548 on
+    scale 22.  Bars: 1.5 % on scale 17 (expected -0.45 %), 2.5 % on scale 20 (-1.3 %: north_star's 1 % is not met there) and on scale 22."""
     import json, os
     from conftest import golden_path
     from gem_amd.evaluation import reconstruction as gr
     # scale 17: 16 384 eligible nodes (their APs sum to 288: s.e. 0.3 %); scale 20: 131 072 (sum 384; over 16 384 the APs sum to 49 and one launch has an s.e. of 1.4 %)
     path = golden_path('n2v_ref_oracle_rmat%d%s_%s.json' % (scale, '' if layout == 'node_id' else '_vocab_order', 'e16k' if scale == 17 else 'e128k'))
+    if scale == 22 and os.environ.get('GEM_TEST_RMAT22', '1') == '0':
+        pytest.skip('GEM_TEST_RMAT22=0')
     if not os.path.exists(path):
         pytest.skip('%s not generated (scripts/make_golden_n2v_scale.py --rmat-scale %d --engine oracle --eligible-sample 16384)' % (os.path.basename(path), scale))
     ref = json.load(open(path))
@@ -120,7 +110,7 @@ def test_rmat_default_concurrency_lands_on_the_sequential_oracle(scale, layout):
     d = ap - np.asarray(ref['ap'])
     gap, se = float(d.mean() / ref['MAP']), float(d.std(ddof=1) / np.sqrt(len(d)) / ref['MAP'])
     from conftest import record_stat
-    bar = 0.03 if scale == 17 else 0.05          # (scale 20: measured -1.51 % (s.e. 0.34 %) / -1.50 % (s.e. 0.64 %) in the binary's / the node-id layout: >= 5 s.e. of margin)
+    bar = 0.015 if scale == 17 else 0.025        # (measured at the planner's 256 wavefronts, round 6: -0.45 % (s.e. 0.3 %) on scale 17, -1.1 / -1.5 % (s.e. 0.4 %) on scale 20)
     record_stat('R-MAT scale %d, %s layout, one Hogwild launch against the sequential oracle (paired, %d nodes)' % (scale, layout, len(d)),
-                '%+.2f %% (s.e. %.2f %%)' % (100 * gap, 100 * se), '+-%d %%' % round(100 * bar))
+                '%+.2f %% (s.e. %.2f %%)' % (100 * gap, 100 * se), '+-%.1f %%' % (100 * bar))
     assert abs(gap) <= bar, (gap, se, ap.mean(), ref['MAP'])
