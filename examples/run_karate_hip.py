@@ -22,13 +22,18 @@ from gem.embedding.node2vec import node2vec
 if __name__ == '__main__':
     parser = ArgumentParser(description='Graph embedding on the karate graph, MI355X backend')
     parser.add_argument('-node2vec', '--node2vec', default='1')
-    run_n2v = bool(int(parser.parse_args().node2vec))
+    parser.add_argument('-sdne', '--sdne', default='0', help="1: end with GEM's sixth model, SDNE (a Keras auto-encoder, out of scope here: the stub constructs and refuses to train)")
+    args = parser.parse_args()
+    run_n2v = bool(int(args.node2vec))
     here = os.path.dirname(os.path.abspath(__file__))
     G = graph_util.loadGraphFromEdgeListTxt(os.path.join(here, '..', 'tests', 'golden', 'karate.edgelist'), directed=True).to_directed()
     models = [GraphFactorization(d=2, max_iter=50000, eta=1 * 10 ** -4, regu=1.0, data_set='karate'), HOPE(d=4, beta=0.01),
               LaplacianEigenmaps(d=2), LocallyLinearEmbedding(d=2)]
     if run_n2v:
         models.append(node2vec(d=2, max_iter=1, walk_len=80, num_walks=10, con_size=10, ret_p=1, inout_p=1))
+    if bool(int(args.sdne)):
+        from gem.embedding.sdne import SDNE
+        models.append(SDNE(d=2, beta=5, alpha=1e-5, nu1=1e-6, nu2=1e-6, K=3, n_units=[50, 15], n_iter=50, xeta=0.01, n_batch=500))
     for embedding in models:
         print('Num nodes: %d, num edges: %d' % (G.number_of_nodes(), G.number_of_edges()))
         t1 = time()

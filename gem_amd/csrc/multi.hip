@@ -130,6 +130,7 @@ struct Fabric {
         RcclApi &R = rccl();
         if (!R.ok) return fail(GEMHIP_E_UNSUPPORTED, "librccl.so.1 could not be loaded (%s): the multi-GPU entry points need RCCL", R.why.empty() ? "unknown reason" : R.why.c_str());
         comm.assign(N, nullptr);
+        (void)hipGetLastError();         // a sticky error left by an earlier, unrelated launch of this process would surface inside RCCL's init as "unhandled cuda error"
         NCCL_TRY(R.CommInitAll(comm.data(), N, dev.data()));
         return GEMHIP_OK;
     }
