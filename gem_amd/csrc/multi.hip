@@ -48,8 +48,22 @@ RcclApi &rccl()
 {
     static RcclApi R;
     if (R.lib || R.ok) return R;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        R.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // The RCCL that belongs to the HIP runtime THIS library is bound to: a process can hold two (PyTorch ships its own libamdhip64 / libhsa-runtime64 /
+    // librccl next to /opt/rocm's), and an RCCL bound to the other, never-initialised runtime fails inside ncclCommInitAll with "no ROCm-capable device"
+    // (seen in round 6 when torch was imported AFTER this library: dlopen("librccl.so.1") then returned torch's copy by soname).  dladdr on a HIP entry
+    // point names the runtime in use; its directory is searched first.
+    std::vector<std::string> names;
+    {
+        Dl_info info;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t cut = dir.rfind('/');
+            if (cut != std::string::npos) { dir.resize(cut); names.push_back(dir + "/librccl.so.1"); names.push_back(dir + "/librccl.so"); }
+        }
+    }
+    for (const char *fallback : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(fallback);
+    for (const std::string &name : names) {
+        R.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (R.lib) break;
         const char *e = dlerror();
         if (R.why.empty() && e) R.why = e;

@@ -152,3 +152,32 @@ def test_sbm16k_map_matches_race_free_snap():
     MAP = gr.evaluateStaticGraphReconstruction(g, m, Y, None)[0]
     assert abs(MAP - ref['snap']['t1']['MAP']) <= 0.01 * ref['snap']['t1']['MAP'], (MAP, ref['snap'])
     assert MAP > ref['snap']['t8']['MAP']
+
+
+@pytest.mark.hogwild_stat
+def test_partitioned_1m_two_virtual_ranks_inside_the_stated_n_gpu_tolerance():
+    """BASELINE configs[3] at N = 2: the partitioned schedule on SBM 1M/10M with two VIRTUAL ranks (the one-GPU box; the buckets of a round touch
+    disjoint rows, so running them rank after rank computes what two GPUs compute), 64 episodes, the plugin's table layout, against the sequential oracle's
+    run on the same seed (tests/golden/n2v_ref_oracle_1000k_vocab_order_s4096.json, paired over its 4 096 nodes).  The schedule trains a walk's pairs in N^2
+    passes spread over an episode instead of back to back, which optimises slightly BETTER than TrainModel's order (+2.8 ... +3.1 % at N = 2, 4, 8 in round 4;
+    the schedule's CPU emulation without any concurrency: +0.7 ... +1.7 %): the stated N >= 2 tolerance is +4 / -1 %, asserted here."""
+    import os
+    path = golden_path('n2v_ref_oracle_1000k_vocab_order_s4096.json')
+    if not os.path.exists(path):
+        pytest.skip('no 1M oracle run in the plugin layout committed')
+    ref = json.load(open(path))
+    p = ref['params']
+    g = sbm_graph(p['n'], p['edges'], p['blocks'], p['seed'])
+    n, src, dst, b = backend(g, p['d'])
+    b.vocab_order = True
+    job = multi_gpu.Node2VecPartitioned(b, multi_gpu.TorchComm(1), 0, 1, n, p['num_walks'], p['walk_len'], p['window'], 1, seed=20260923, flags=p['flags'], episodes=64)
+    P = job.run_virtual(2).cpu().numpy()
+    nodes = np.random.RandomState(0).choice(g.n, size=len(ref['ap']), replace=False)
+    ap = gr.sampled_ap_gpu(g, None, P, nodes)
+    dd = ap - np.asarray(ref['ap'])
+    gap, se = float(dd.mean() / ref['MAP']), float(dd.std(ddof=1) / np.sqrt(len(dd)) / ref['MAP'])
+    from conftest import record_stat
+    record_stat('SBM 1M/10M, partitioned schedule with 2 virtual ranks against the sequential oracle (paired, %d nodes)' % len(dd),
+                '%+.2f %% (s.e. %.2f %%); kernel seconds per rank %s' % (100 * gap, 100 * se, [round(v, 2) for v in getattr(job, 'virtual_rank_seconds', [])]), '-1 ... +4 %')
+    assert -0.01 <= gap <= 0.04, (gap, se)
+    b.close()

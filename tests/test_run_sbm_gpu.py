@@ -91,7 +91,11 @@ def test_verbose_prints_what_the_reference_prints(sbm1024, karate, capsys):
         assert abs(m._svd_error - got) < 1e-5 and 'verbose' not in HOPE.hyper_params
         assert m._svd_error_u_side <= 2e-3 * want                  # a converged solve: the U side adds nothing visible
         # ... and a WRONG U shows (the V-only estimate reported the ideal truncation error whatever U held): the print follows the dense value
-        row_ptr, col, ww = to_csr(n, src, dst, w)
+        s_, d_ = src, dst
+        if order is not None:                                      # hope.py:28 indexes rows by position in graph.nodes (karate: 0, 31, 21, ...), as _hope_impl does
+            pos = np.empty(n, dtype=np.int64); pos[order] = np.arange(n)
+            s_, d_ = pos[src].astype(np.int32), pos[dst].astype(np.int32)
+        row_ptr, col, ww = to_csr(n, s_, d_, w)
         sig = np.ascontiguousarray(m._sigma, dtype=np.float32)
         U = np.ascontiguousarray(Y[:, :k], dtype=np.float32); V = np.ascontiguousarray(Y[:, k:], dtype=np.float32)
         Ubad = U.copy(); Ubad[:, -1] *= 0.5                        # the leading left vector at half length
