@@ -109,6 +109,7 @@ _SIGS = {
     'gemhip_sgns_last_launch': (C.c_int, [C.c_void_p, i32p, i32p, i32p, i32p]),
     'gemhip_sgns_set_fresh': (C.c_int, [C.c_void_p, C.c_int32]),
     'gemhip_n2v_locally_hot': (C.c_int, [C.c_void_p, C.c_int32, i64p, i32p]),
+    'gemhip_n2v_locally_hot_corpus': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, i64p, C.c_void_p]),
     'gemhip_sgns_plan_launch': (C.c_int, [i32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, i32p, i32p, i32p, f64p, f64p]),
     'gemhip_test_wave_sum6': (C.c_int, [f32p, f32p]),
     'gemhip_sgns_set_tables': (C.c_int, [C.c_void_p, f32p, f32p]),

@@ -401,6 +401,11 @@ extern "C" int gemhip_n2v_train_multi(int64_t n, int64_t nnz, const int64_t *row
         if (!rc) rc = (flags & GEMHIP_N2V_VOCAB_ORDER) ? gemhip_n2v_build_unigram_parts_vocab_order(h[r], N, flags, corpus[r].p, (int64_t)N * shard_rows * walk_len, nullptr, nullptr, nullptr, nullptr)
                                                        : gemhip_n2v_build_unigram_parts(h[r], N, nullptr, nullptr);
     }
+    // ---- LOCALLY HOT ROWS of the gathered corpus (nodes whose tokens are packed into few walks: the ends of isolated edges): never cached by the bucket launches
+    for (int r = 0; r < N && !rc; ++r) {
+        rc = F.use(r);
+        if (!rc) rc = gemhip_n2v_locally_hot_corpus(h[r], corpus[r].p, (int64_t)N * shard_rows, walk_len, -1, nullptr, F.st[r]);
+    }
     // ---- episode table [episodes][3][N]: first row, walks present, first global walk id of every shard's slice; work items per shard = longest slice
     std::vector<int64_t> tab((size_t)episodes * 3 * N), seg_len(episodes, 1);
     for (int e = 0; e < episodes; ++e)

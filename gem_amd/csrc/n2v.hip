@@ -1409,9 +1409,11 @@ extern "C" int gemhip_sgns_train_part(gemhip_n2v_t h, const void *d_walks, int64
         // whole-walk mode): a node then sits in W x walk_len x count / tokens windows, which is what decides whether it is hot
         if (walk_len / h->parts <= 2 * std::min(window, 10) + 1) kn.window_span = walk_len;
     }
+    kn.has_local_hot = !(flags & 4) && h->hotkey_state == 2 && h->n_local_hot > 0;       // LOCALLY HOT ROWS of the gathered corpus (gemhip_n2v_locally_hot_corpus)
     const SgnsLaunchPlan P = plan_sgns_launch(vs, kn, (int64_t)A.n, d, window, walk_len, nwalks, flags);
     GEMHIP_REQUIRE(P.window, "sgns_train_part: d=%d window=%d walk_len=%d do not fit the LDS window kernel", d, window, walk_len);
     A.nwaves = (int32_t)P.waves; A.cache_radius = P.R; A.hot_thr = P.hot_thr;
+    if (kn.has_local_hot && P.delta && P.waves > 1) A.counts = h->d_hotkey;
     const size_t need = (size_t)P.waves * sgns_win_row_floats(d) * sizeof(float);
     if (need > h->dummy_bytes) {
         if (h->d_dummy) { GEMHIP_CHECK(hipDeviceSynchronize()); hipFree(h->d_dummy); h->d_dummy = nullptr; h->dummy_bytes = 0; }
@@ -1485,6 +1487,36 @@ extern "C" int gemhip_sgns_set_hot_rows(gemhip_n2v_t h, int32_t min_count)
 {
     GEMHIP_REQUIRE(h && min_count >= -1, "sgns_set_hot_rows: bad arguments");
     h->kn.hot_count = min_count;
+    return GEMHIP_OK;
+}
+
+// ... the same key from a walk CORPUS assembled from every rank's shard (the partitioned N-GPU schedule: gemhip_sgns_train_part trains buckets of it), with
+// the handle's -- all-reduced -- token counts: rows of -1 tokens (padding of shorter shards) count nothing.  Bucket launches on this handle then treat the
+// locally hot nodes as hot rows (hotkey is indexed by GLOBAL node id, like the counts the bucket kernels read).
+extern "C" int gemhip_n2v_locally_hot_corpus(gemhip_n2v_t h, const void *d_corpus, int64_t corpus_rows, int32_t walk_len, int32_t per_walk, int64_t *count, void *stream)
+{
+    GEMHIP_REQUIRE(h && d_corpus && corpus_rows >= 1 && walk_len >= 1 && per_walk >= -1, "n2v_locally_hot_corpus: bad arguments");
+    if (per_walk >= 0) h->kn.local_hot = per_walk;
+    h->hotkey_state = 0; h->n_local_hot = 0;
+    if (h->kn.local_hot == 0) { if (count) *count = 0; return GEMHIP_OK; }
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->d_hotkey) {
+        GEMHIP_CHECK(hipMalloc((void **)&h->d_hotkey, (size_t)h->n * sizeof(int32_t)));
+        GEMHIP_CHECK(hipMalloc((void **)&h->d_wcount, (size_t)h->n * sizeof(int32_t)));
+        GEMHIP_CHECK(hipMalloc((void **)&h->d_nlocal, sizeof(unsigned int)));
+    }
+    GEMHIP_CHECK(hipMemsetAsync(h->d_wcount, 0, (size_t)h->n * sizeof(int32_t), s));
+    GEMHIP_CHECK(hipMemsetAsync(h->d_nlocal, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(n2v_walk_presence_kernel, dim3((unsigned)std::min<int64_t>(corpus_rows, 256 * 32)), dim3(64), (size_t)walk_len * sizeof(int32_t), s, (const int32_t *)d_corpus,
+                       corpus_rows, walk_len, h->d_wcount);
+    hipLaunchKernelGGL(n2v_hotkey_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, h->n, h->d_counts, h->d_wcount, h->kn.local_hot, h->d_hotkey, h->d_nlocal);
+    GEMHIP_CHECK(hipGetLastError());
+    unsigned int nl = 0;
+    GEMHIP_CHECK(hipMemcpyAsync(&nl, h->d_nlocal, sizeof nl, hipMemcpyDeviceToHost, s));
+    GEMHIP_CHECK(hipStreamSynchronize(s));
+    h->n_local_hot = nl;
+    h->hotkey_state = 2;                 // built from a corpus: gemhip_sgns_train_part uses it; gemhip_sgns_train rebuilds its own from the handle's walks
+    if (count) *count = nl;
     return GEMHIP_OK;
 }
 

@@ -346,6 +346,8 @@ class Node2VecPartitioned(object):
         # per-partition unigram tables: node-id order, or (flags & 16 = GEMHIP_N2V_VOCAB_ORDER, the plugin default on one GPU) the binary's layout --
         # each partition's nodes in order of first appearance in the gathered corpus
         b.build_unigram_parts(W, corpus if (self.flags & _hip.N2V_VOCAB_ORDER) else None, self.flags)
+        if hasattr(b, 'locally_hot'):
+            b.locally_hot(corpus)                                           # nodes whose tokens are packed into few walks: hot rows of the bucket launches
         seg_dev = b.upload_table(tab)
         P_part, N_cur, N_tmp = b.init_part_tables(self.seed, g, W)          # partition g of SynPos / SynNeg (+ a receive buffer)
         self.pairs_trained = 0
@@ -384,6 +386,8 @@ class Node2VecPartitioned(object):
         tab, seg_len = self.episode_table()                                 # one shard (this rank's = everything)
         corpus = b.gather_corpus(self.comm, self.shard_rows, 1)
         b.build_unigram_parts(W, corpus if (self.flags & _hip.N2V_VOCAB_ORDER) else None, self.flags)
+        if hasattr(b, 'locally_hot'):
+            b.locally_hot(corpus)
         seg_dev = b.upload_table(tab)
         tabs = [b.init_part_tables(self.seed, g, W) for g in range(W)]
         Pp, Np = [t[0] for t in tabs], [t[1] for t in tabs]
@@ -477,6 +481,12 @@ class HipBackendN2V(object):
         else:
             _hip.check(self.L.gemhip_n2v_build_unigram_parts(self.h, parts, None, None))
         self.parts = parts
+
+    def locally_hot(self, corpus):
+        """gemhip_n2v_locally_hot_corpus on the gathered corpus: returns the number of locally hot nodes."""
+        k = C.c_int64()
+        _hip.check(self.L.gemhip_n2v_locally_hot_corpus(self.h, C.c_void_p(corpus.data_ptr()), corpus.shape[0], corpus.shape[1], -1, C.byref(k), self._stream()))
+        return k.value
 
     def init_part_tables(self, seed, rank, world):
         """Partition `rank` of the SAME initial tables a single GPU would draw (InitPosEmb / InitNegEmb)."""

@@ -257,6 +257,9 @@ int gemhip_sgns_last_launch(gemhip_n2v_t h, int32_t *kernel, int32_t *waves, int
  * optionally, the key (n int32, host).  Needs the WHOLE corpus on the handle (a rank's shard against all-reduced counts would flag everything: the launch
  * skips the rule there).  No reference counterpart (the binary's threads read and write rows in place). */
 int gemhip_n2v_locally_hot(gemhip_n2v_t h, int32_t per_walk, int64_t *count, int32_t *hotkey_host);
+/* ... from a walk corpus assembled from every rank's shard (device pointer, corpus_rows x walk_len int32, rows of -1 = padding) and the handle's all-reduced
+ * counts: the partitioned N-GPU schedule's form.  gemhip_sgns_train_part launches on the handle then treat the locally hot nodes as hot rows. */
+int gemhip_n2v_locally_hot_corpus(gemhip_n2v_t h, const void *d_corpus, int64_t corpus_rows, int32_t walk_len, int32_t per_walk, int64_t *count, void *stream);
 /* FRESH HOT ROWS (Hogwild launches that have hot rows; gem_amd/csrc/sgns.hpp SgnsArgs::fresh).  bit 0: a hot centre word's positive row takes every
  * pair's update as a returning atomic add and continues from the returned row; bit 1: hot negative rows are re-read right before the dot products.
  * bit 2 (value 4): every negative row with at least GEMHIP_SGNS_NEG_COUNT tokens is updated by atomic add instead of reload + store.

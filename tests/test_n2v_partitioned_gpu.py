@@ -181,3 +181,35 @@ def test_partitioned_1m_two_virtual_ranks_inside_the_stated_n_gpu_tolerance():
                 '%+.2f %% (s.e. %.2f %%); kernel seconds per rank %s' % (100 * gap, 100 * se, [round(v, 2) for v in getattr(job, 'virtual_rank_seconds', [])]), '-1 ... +4 %')
     assert -0.01 <= gap <= 0.04, (gap, se)
     b.close()
+
+
+def test_locally_hot_rows_reach_the_bucket_launches():
+    """Round 6: the partitioned schedule builds the locally-hot key from the GATHERED corpus (gemhip_n2v_locally_hot_corpus, called by Node2VecPartitioned and by
+    gemhip_n2v_train_multi): on an SBM with a dozen isolated edges appended exactly their ends qualify, a Hogwild bucket launch then carries the hot-row
+    machinery with the threshold INT32_MAX (only those nodes), and the deterministic schedule is untouched (equal to the run with the rule off, bit for bit)."""
+    from test_n2v_gpu import _graph_with_isolated_edges
+    n, src, dst = _graph_with_isolated_edges(n_core=16384, iso_pairs=12)
+    row_ptr, col, ww = to_csr(n, src, dst, None)
+    res = {}
+    for rule in (8, 0):
+        b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, 32)
+        job = multi_gpu.Node2VecPartitioned(b, multi_gpu.TorchComm(1), 0, 1, n, 2, 40, 5, 1, seed=3, flags=9, episodes=2)
+        if rule == 0:
+            b.locally_hot = lambda corpus: 0                 # rule off: the driver's hook does nothing
+        P = job.run_virtual(2)
+        k, wv, hot, fr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _hip.check(b.L.gemhip_sgns_last_launch(b.h, C.byref(k), C.byref(wv), C.byref(hot), C.byref(fr)))
+        res[rule] = (hot.value, wv.value, bool(torch.isfinite(P).all()))
+        b.close()
+    assert res[8][0] == np.iinfo(np.int32).max and res[8][1] > 1 and res[8][2]
+    assert res[0][0] == 0 and res[0][2]
+    # the count itself, and the deterministic schedule with and without the rule
+    b = multi_gpu.HipBackendN2V(n, row_ptr, col, ww, 32)
+    job = multi_gpu.Node2VecPartitioned(b, multi_gpu.TorchComm(1), 0, 1, n, 2, 40, 5, 1, seed=3, flags=9 | 4, episodes=2)
+    Pa = job.run_virtual(2).cpu().numpy()
+    corpus = b.gather_corpus(multi_gpu.TorchComm(1), job.shard_rows, 1)
+    assert b.locally_hot(corpus) == 12 * 2 + 3
+    b.locally_hot = lambda corpus: 0
+    Pb = multi_gpu.Node2VecPartitioned(b, multi_gpu.TorchComm(1), 0, 1, n, 2, 40, 5, 1, seed=3, flags=9 | 4, episodes=2).run_virtual(2).cpu().numpy()
+    assert np.array_equal(Pa, Pb)
+    b.close()
