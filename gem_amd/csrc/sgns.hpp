@@ -933,7 +933,7 @@ __global__ __launch_bounds__(64) void sgns_win_kernel(SgnsArgs A)
                             for (int j = 0; j < SGNS_NEG; ++j) {
                                 const bool hotj = (hotm >> j) & 1u;
                                 float *pj = A.SynNeg + (int64_t)C.tgt[j] * d;
-                                if (hotj) {
+                                if (hotj && g[j + 1] != 0.f) {          // (sigma clamped to 0 beyond -MaxExp: the update is exactly zero -- 128 atomic adds of 0.0 saved, nothing changed)
 #pragma unroll
                                     for (int c = 0; c < NV; ++c)
 #pragma unroll
