@@ -1227,10 +1227,9 @@ void spmm(Hope &H, bool transpose, float alpha, const float *X, int ldx, const f
         const dim3 grid16((unsigned)((blocks16 + NUM_XCD - 1) / NUM_XCD * NUM_XCD));
         const int c16 = (b + 15) / 16;
 #define SPMM16(C, U) hipLaunchKernelGGL((hope_spmm16_kernel<C, U>), grid16, blk, 0, H.s, H.n, rp, ci, va, alpha, X, ldx, Wadd, ldw, Y, ldy, b, wa, W2, ldw2, wb)
-        // neighbours in flight per row and round.  With the next round's (column, value) pairs prefetched, short rounds win: measured 2 / 4 / 8 / 16 at
-        // SBM 100k/1M (about 20 neighbours per row): see the dispatch below; round 2, without the prefetch: 4 / 8 / 16 = 5.5 / 5.2 / 5.8 ms of SpMM per solve
         // gathers in flight per row and round (GEMHIP_HOPE_SPMM16_U overrides): with a row's (column, value) pairs already in the group's registers the
-        // rounds are separated by arithmetic only, and the bound is registers: U x ceil(b / 16) values per lane
+        // rounds are separated by arithmetic only, and the bound is registers: U x ceil(b / 16) values per lane -- 8 up to 48 columns, 4 up to 80, 2 beyond
+        // (round 5: 4.21 -> 3.92 ms of SpMM per eigen-path solve at SBM 100k/1M against round 4's U = 4 with a per-round pair prefetch)
         static const int uenv = getenv("GEMHIP_HOPE_SPMM16_U") ? atoi(getenv("GEMHIP_HOPE_SPMM16_U")) : 0;
         const int uu = uenv > 0 ? uenv : (c16 <= 3 ? 8 : 4);
 #define SPMM16_BY_U(C) do { if (uu >= 8) SPMM16(C, 8); else if (uu >= 4) SPMM16(C, 4); else SPMM16(C, 2); } while (0)
