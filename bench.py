@@ -1050,11 +1050,13 @@ def main():
             extra['gf_rmat22'], w7 = time_workload('gf', a7, rank, world, comm, 20, 2, with_cpu=False)
             del w7
             torch.cuda.empty_cache()
-            if time.time() - T_START < float(os.environ.get('GEM_BENCH_RMAT_PQ_DEADLINE_S', '780')):
+            if time.time() - T_START < float(os.environ.get('GEM_BENCH_RMAT_PQ_DEADLINE_S', '560')):
                 # general (p, q) second-order walks at R-MAT scale (rejection sampling against the hubs' rows), (p, q) = (0.25, 4)
                 a9 = copy.copy(a6); a9.ret_p, a9.inout_q = 0.25, 4.0
                 extra['node2vec_rmat22_p0.25_q4'], w9 = time_workload('node2vec', a9, rank, world, comm, 1, 0, with_cpu=False)
                 del w9
+            else:
+                extra['node2vec_rmat22_p0.25_q4'] = 'skipped: bench already ran %.0f s (GEM_BENCH_RMAT_PQ_DEADLINE_S); python bench.py --workload node2vec --graph rmat --nodes 4194304 --edges 64000000 --ret-p 0.25 --inout-q 4 --steps 1 --warmup 0' % (time.time() - T_START)
             for k in ('node2vec_rmat20', 'node2vec_rmat22', 'gf_rmat22'):
                 extra[k]['cpu_baseline'] = {'value': None, 'kind': 'reference', 'note': 'not run: gem/c_exe/node2vec builds Sigma deg^2 second-order alias '
                                             'tables (max degree ~94k here) and exhausts host memory; gf.cpp per-edge rate: see gf_sbm1m_10m.cpu_baseline'}
