@@ -169,23 +169,44 @@ def test_node2vec_map_at_the_headline_size_within_one_percent_of_the_reference()
         kw = {} if flags is None else {'flags': flags}
         m = node2vec(d=pr['d'], max_iter=1, walk_len=pr['walk_len'], num_walks=pr['num_walks'], con_size=pr['window'], ret_p=1, inout_p=1, seed=seed, **kw)
         return gr.sampled_ap_gpu(g, None, m.learn_embedding(graph=g, is_weighted=True, no_python=True), nodes[:k])
+    from conftest import record_stat
+    snap_runs = {}
     if 'oracle' in refs:
         ref = refs['oracle']
         k = len(ref['ap'])
-        apo = np.asarray(ref['ap'])[:k]
-        gaps = [float((run(20260923, k, ref['params'].get('flags', 11)) - apo).mean() / apo.mean()) for _ in range(3)]
-        from conftest import record_stat
-        record_stat('SBM 1M/10M, flags %d, three Hogwild launches against the sequential oracle (paired, %d nodes)' % (ref['params'].get('flags', 11), k),
-                    '%s %%, mean %+.2f %%' % ((100 * np.round(gaps, 4)).tolist(), 100 * np.mean(gaps)), 'mean within +-1 %')
-        assert abs(np.mean(gaps)) <= 0.01, (gaps, ref['MAP'])
+        fl = ref['params'].get('flags', 11)
+        # round 6: the oracle ran on three more training seeds in the plugin's layout (golden/n2v_ref_oracle_1000k_vocab_order_s4096_seed{1,2,3}.json): every GPU
+        # seed below is PAIRED with the sequential algorithm's run on the SAME seed (same walks, same draws) -- three independent parity statements, not three
+        # launches of one -- and the same three embeddings then serve the unpaired comparison with the binary's single run
+        seeds = [(20260923, ref)]
+        if fl == 27:
+            for sd_ in (1, 2):
+                pth = golden_path('n2v_ref_oracle_1000k_vocab_order_s4096_seed%d.json' % sd_)
+                if os.path.exists(pth):
+                    seeds.append((sd_, json.load(open(pth))))
+        if len(seeds) == 1:
+            seeds = seeds * 3                                # (older goldens only: three launches of the one seed, as in rounds 3-5)
+        gaps = []
+        for seed, rf in seeds:
+            ap = run(seed, k, fl)
+            if fl == 27:
+                snap_runs[seed] = ap                 # (the plugin default layout: what the unpaired leg below runs)
+            apo = np.asarray(rf['ap'])[:k]
+            gaps.append(float((ap - apo).mean() / apo.mean()))
+        record_stat('SBM 1M/10M, flags %d, Hogwild launches on seeds %s, each against the sequential oracle on the same seed (paired, %d nodes)' % (fl, [s_ for s_, _ in seeds], k),
+                    '%s %%, mean %+.2f %%' % ((100 * np.round(gaps, 4)).tolist(), 100 * np.mean(gaps)), 'mean within +-1 %, each within +-1.5 %')
+        assert abs(np.mean(gaps)) <= 0.01 and max(abs(g_) for g_ in gaps) <= 0.015, (gaps, ref['MAP'])
     if 'snap' in refs:
         ref = refs['snap']
         k = len(ref['ap'])                             # the whole 4096-node sample: over its first 2048 nodes alone the same two runs sit at +2.1 % (sampling)
         aps = np.asarray(ref['ap'])[:k]
-        gaps = [float((run(seed, k) - aps).mean() / aps.mean()) for seed in (20260923, 1, 2)]
-        from conftest import record_stat
+        gaps = [float(((snap_runs[seed][:k] if seed in snap_runs and len(snap_runs[seed]) >= k else run(seed, k)) - aps).mean() / aps.mean()) for seed in (20260923, 1, 2)]
+        # The bar.  The reference's seed-to-seed spread, by its pinned restatement over four training seeds on this very node sample
+        # (profiles/r06_oracle_seed_spread_sbm1m.json): MAP 0.4957 / 0.4977 / 0.5005 / 0.4993, s.d. 0.42 %.  A 3-seed mean against ONE run of the reference
+        # therefore has an s.d. of 0.42 % x sqrt(1 + 1/3) = 0.48 %: the 2 % bar is 4.1 of those.  The binary's single run (0.4929) sits 1.1 % = 2.6 s.d. BELOW the
+        # restatement's mean, and that offset -- not the GPU -- is the +1.1 % measured here round after round (the GPU is within 0.5 % of the restatement, above).
         record_stat('SBM 1M/10M, three seeds against the reference binary\'s own run (unpaired, %d nodes)' % k,
-                    '%s %%, mean %+.2f %%' % ((100 * np.round(gaps, 4)).tolist(), 100 * np.mean(gaps)), 'mean within +-2 %')
+                    '%s %%, mean %+.2f %%' % ((100 * np.round(gaps, 4)).tolist(), 100 * np.mean(gaps)), 'mean within +-2 % (4.1 s.d. of a 3-seed mean against one reference seed)')
         assert abs(np.mean(gaps)) <= 0.02, (gaps, ref['MAP'])
 
 
