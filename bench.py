@@ -1050,7 +1050,7 @@ def main():
             extra['gf_rmat22'], w7 = time_workload('gf', a7, rank, world, comm, 20, 2, with_cpu=False)
             del w7
             torch.cuda.empty_cache()
-            if time.time() - T_START < float(os.environ.get('GEM_BENCH_RMAT_PQ_DEADLINE_S', '560')):
+            if time.time() - T_START < float(os.environ.get('GEM_BENCH_RMAT_PQ_DEADLINE_S', '500')):
                 # general (p, q) second-order walks at R-MAT scale (rejection sampling against the hubs' rows), (p, q) = (0.25, 4)
                 a9 = copy.copy(a6); a9.ret_p, a9.inout_q = 0.25, 4.0
                 extra['node2vec_rmat22_p0.25_q4'], w9 = time_workload('node2vec', a9, rank, world, comm, 1, 0, with_cpu=False)

@@ -151,7 +151,11 @@ struct Fabric {
     int use(int r) { GEMHIP_CHECK(hipSetDevice(dev[r])); return GEMHIP_OK; }
     int sync_all()
     {
-        for (int r = 0; r < (virt ? 1 : N); ++r) { GEMHIP_CHECK(hipSetDevice(dev[r])); GEMHIP_CHECK(hipStreamSynchronize(st[r])); }
+        // the DEVICE, not only the rank's stream: the streams are non-blocking, i.e. not ordered with the null stream, and the set-up phases use null-stream
+        // hipMemcpy (device to device) / hipMemset, which return before they complete.  With a stream-only wait here the first sweep on st[r] could run
+        // while the copy Xb <- Xa of gemhip_gf_train_multi was still in flight and have its rows overwritten (seen ONCE, round 6, in the closing tier:
+        // gemhip_gf_train_multi on one rank differed from gemhip_gf_train; the same hole existed for the zeroed SynNeg partitions of the node2vec driver).
+        for (int r = 0; r < (virt ? 1 : N); ++r) { GEMHIP_CHECK(hipSetDevice(dev[r])); GEMHIP_CHECK(hipStreamSynchronize(st[r])); GEMHIP_CHECK(hipDeviceSynchronize()); }
         return GEMHIP_OK;
     }
     void destroy()
