@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'scripts'))
 import numpy as np
 
 
-def ap_counting(X64, d_sorted, starts, nodes, batch=128, sort_from=48):
+def ap_counting(X64, d_sorted, starts, nodes, batch=64, sort_from=48):
     out = np.zeros(len(nodes))
     for b0 in range(0, len(nodes), batch):
         nb = nodes[b0:b0 + batch]

@@ -94,6 +94,8 @@ def test_rmat_default_concurrency_lands_on_the_sequential_oracle(scale, layout):
     from gem_amd.evaluation import reconstruction as gr
     # scale 17: 16 384 eligible nodes (their APs sum to 288: s.e. 0.3 %); scale 20: 131 072 (sum 384; over 16 384 the APs sum to 49 and one launch has an s.e. of 1.4 %)
     path = golden_path('n2v_ref_oracle_rmat%d%s_%s.json' % (scale, '' if layout == 'node_id' else '_vocab_order', 'e16k' if scale == 17 else 'e128k'))
+    if scale == 22 and not os.path.exists(path):          # (round 6 scored the scale-22 oracle runs over the 16 384-node sub-sample: the 131 072-node scoring did not fit the session)
+        path = golden_path('n2v_ref_oracle_rmat22%s_e16k.json' % ('' if layout == 'node_id' else '_vocab_order'))
     if scale == 22 and os.environ.get('GEM_TEST_RMAT22', '1') == '0':
         pytest.skip('GEM_TEST_RMAT22=0')
     if not os.path.exists(path):
@@ -110,7 +112,8 @@ def test_rmat_default_concurrency_lands_on_the_sequential_oracle(scale, layout):
     d = ap - np.asarray(ref['ap'])
     gap, se = float(d.mean() / ref['MAP']), float(d.std(ddof=1) / np.sqrt(len(d)) / ref['MAP'])
     from conftest import record_stat
-    bar = 0.015 if scale == 17 else 0.025        # (measured at the planner's 256 wavefronts, round 6: -0.45 % (s.e. 0.3 %) on scale 17, -1.1 / -1.5 % (s.e. 0.4 %) on scale 20)
+    bar = 0.015 if scale == 17 else 0.025 if len(ref['ap']) > 20000 else 0.04          # (a 16 384-node sample of scale 22 has an s.e. of ~1 % per launch)
+    # (measured at the planner's 256 wavefronts, round 6: -0.45 % (s.e. 0.3 %) on scale 17, -1.1 / -1.5 % (s.e. 0.4 %) on scale 20)
     record_stat('R-MAT scale %d, %s layout, one Hogwild launch against the sequential oracle (paired, %d nodes)' % (scale, layout, len(d)),
                 '%+.2f %% (s.e. %.2f %%)' % (100 * gap, 100 * se), '+-%.1f %%' % (100 * bar))
     assert abs(gap) <= bar, (gap, se, ap.mean(), ref['MAP'])
