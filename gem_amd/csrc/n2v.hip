@@ -1117,7 +1117,7 @@ static SgnsLaunchPlan plan_sgns_launch(const VocabStats &vs, const SgnsKnobs &kn
         //  * what is left is smooth in the width and larger on the larger graph -- R-MAT scale 17: -0.45 / -1.6 / -1.8 % at 256 / 768 / 1 536 wavefronts, scale 20:
         //    -1.3 / -3.0 / -6.0 % (paired with the sequential oracle, s.e. 0.3-0.5 %, 2-4 launches each) -- carried by query nodes of 1 000..30 000 tokens, and
         //    slower launches of the same configuration are the worse ones (queueing of the hot rows' atomic adds at the memory side is the suspect).
-        // So the bound stays as the conservative extrapolation it is (548 wavefronts on scale 22, where the oracle pins it: tests/test_rmat_gpu.py), with a
+        // So the bound stays as the conservative extrapolation it is (548 wavefronts on scale 22 -- both oracle runs exist since round 6, their scoring did not finish: no pin yet), with a
         // FLOOR of 256 wavefronts: at 256 both measured graphs are at or inside -1.3 % (round 5's 50 wavefronts on scale 17 bought nothing for 3.5x the time:
         // ADVICE r5), and ONE bound for both unigram-table layouts -- round 5 halved it for the node-id layout on the strength of two launches (-6.3 % at 207
         // wavefronts) that the heavy tail explains; after the fix the layouts measure alike (scale 20, 768 wavefronts: -2.7 / -3.3 % and -2.5 / -4.3 %).
